@@ -1,0 +1,197 @@
+/*
+ * wbcqp.h -- C ABI of the MI355X batched whole-body QP ("one control tick of inria_wbc, B robots at once").
+ *
+ * This is the drop-in boundary for the single hot path of resibots/inria_wbc
+ * (citations are into /root/reference/):
+ *
+ *   Controller::_solve                         src/controllers/controller.cpp:231-313
+ *     tsid_->computeProblemData(t, q, dq)      src/controllers/controller.cpp:244   (assembly half: HQPData)
+ *     solver_->solve(HQPData)                  src/controllers/controller.cpp:247   (tsid SolverHQuadProgFast
+ *                                                                                    + eiquadprog-fast GI solve)
+ *     getActuatorForces / getAccelerations     src/controllers/controller.cpp:250-251
+ *     getContactForces                         src/controllers/controller.cpp:260
+ *
+ * One "QP" below = that sequence for one robot instance.  Inputs are what the step before the path
+ * produces (pinocchio terms + each task's compute(): M, h, task rows, contact Jacobians, bounds);
+ * outputs are x = [dv; f], tau, status, active-set iterations.
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Nothing throws across this boundary: every
+ * entry point returns a wbcqp_status and wbcqp_last_error() gives the text.  A handle is bound to one
+ * HIP device and is not thread-safe; distinct handles may be used concurrently (the reference's
+ * Controller is single-threaded and non-copyable, controller.hpp:50-51).  After wbcqp_create and
+ * wbcqp_set_structure, the device-pointer solve entry points allocate nothing (upstream's solver
+ * runs under EIGEN_MALLOC_NOT_ALLOWED).
+ */
+#ifndef WBCQP_H
+#define WBCQP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WBCQP_VERSION 100 /* 0.1.0 */
+#define WBCQP_MAX_STRUCTURES 16
+#define WBCQP_MAX_INEQ_BLOCKS 16
+#define WBCQP_MAX_VARS 128 /* n = nv + 12*nc must fit two 64-lane passes */
+
+/* ---- return codes of the API itself ---- */
+typedef enum {
+    WBCQP_OK = 0,
+    WBCQP_ERR_INVALID = 1,     /* bad argument / inconsistent structure */
+    WBCQP_ERR_HIP = 2,         /* HIP runtime error (text in wbcqp_last_error) */
+    WBCQP_ERR_UNSUPPORTED = 3, /* size outside what the kernels support */
+    WBCQP_ERR_NO_DEVICE = 4,   /* no gfx950 device: there is NO CPU fallback */
+    WBCQP_ERR_RCCL = 5
+} wbcqp_status;
+
+/* ---- per-QP solver status: the tsid HQP status values the reference switches on
+ *      (controller.cpp:249, 284-307) ---- */
+typedef enum {
+    WBCQP_HQP_UNKNOWN = -1,
+    WBCQP_HQP_OPTIMAL = 0,
+    WBCQP_HQP_INFEASIBLE = 1,
+    WBCQP_HQP_UNBOUNDED = 2,
+    WBCQP_HQP_MAX_ITER_REACHED = 3,
+    WBCQP_HQP_ERROR = 4 /* redundant equalities */
+} wbcqp_hqp_status;
+
+/* kinds of level-0 inequality blocks, in the order the task stack added them
+ * (pos_tracker.cpp:161-189 walks tasks.yaml in file order) */
+typedef enum {
+    WBCQP_INEQ_BOUNDS = 0,    /* "bounds"           tasks.cpp:274-300  rows = +-e_col          */
+    WBCQP_INEQ_ACTUATION = 1, /* "actuation-bounds" tasks.cpp:303-324  rows = +-[M_a | -J_a']  */
+    WBCQP_INEQ_FORCE = 2      /* contact friction   tasks.cpp:329-368  17 x 12 per contact     */
+} wbcqp_ineq_kind;
+
+typedef enum {
+    WBCQP_F64 = 0, /* inputs/outputs double (the reference's Eigen double) */
+    WBCQP_F32 = 1  /* inputs/outputs float at the boundary; the solve still runs in f64 */
+} wbcqp_dtype;
+
+/*
+ * Constant structure of one task stack = what PosTracker::parse_tasks + tasks.cpp factories fix at
+ * construction time.  Variables x = [dv (nv); f (12 per contact)], n = nv + 12 nc.
+ * All arrays are HOST pointers, copied by wbcqp_set_structure.
+ */
+typedef struct {
+    int32_t nv, na, nc;
+    /* level 1 (cost): H = sum_t w_t A_t' A_t + hessian_reg I, g = -sum_t w_t A_t' b_t */
+    int32_t n_dense;               /* dense motion rows (se3 / com / momentum / self-collision), nv wide   */
+    int32_t n_tasks;               /* length of the per-QP weight vector w                                 */
+    const int32_t* dense_row_task; /* [n_dense] row -> index into w; rows of one task are consecutive      */
+    int32_t n_sel;                 /* selection rows (posture task, tasks.cpp:181-224): A = e_col'          */
+    const int32_t* sel_col;        /* [n_sel] column in [0, nv)                                            */
+    const int32_t* sel_task;       /* [n_sel] row -> index into w                                          */
+    const double* forcereg_mat;    /* [nc][6][12] diag(w_f) T   (Contact6d force regularisation task)      */
+    const int32_t* forcereg_task;  /* [nc] -> index into w      (weight w_force_feet, tasks.hpp:23)        */
+    /* level 0 (hard constraints) */
+    const double* force_gen;       /* [nc][6][12] T: contact-point forces -> 6-D wrench; Jc = T' A_c       */
+    const double* fric_mat;        /* [nc][17][12] friction pyramid + normal force rows                    */
+    const double* fric_lb;         /* [nc][17] */
+    const double* fric_ub;         /* [nc][17] */
+    int32_t n_bound;               /* rows of the joint bounds task                                        */
+    const int32_t* bound_col;      /* [n_bound] column in [0, nv)                                          */
+    int32_t act_bounds;            /* 1 if an actuation-bounds task exists (na rows)                       */
+    int32_t n_ineq_blocks;
+    const int32_t* ineq_kind;      /* [n_ineq_blocks] wbcqp_ineq_kind                                      */
+    const int32_t* ineq_arg;       /* [n_ineq_blocks] contact index for WBCQP_INEQ_FORCE                   */
+    double hessian_reg;            /* tsid default 1e-8                                                    */
+    int32_t max_iter;              /* eiquadprog-fast default 1000                                         */
+} wbcqp_structure;
+
+/* Sizes derived from a structure (what PosTracker prints under `verbose`, pos_tracker.cpp:150-158). */
+typedef struct {
+    int32_t n;    /* tsid nVar */
+    int32_t neq;  /* tsid nEq  = (nv - na) + 6 nc */
+    int32_t nin;  /* tsid nIn  (two-sided rows) */
+    int32_t nin2; /* one-sided rows of eiquadprog's CI = 2 nin */
+    int32_t r1;   /* level-1 rows = n_dense + n_sel + 6 nc */
+    /* element counts of the per-QP input arrays below */
+    int32_t len_M, len_h, len_A, len_b1, len_Ac, len_bc, len_blb, len_bub, len_tlb, len_tub, len_w;
+    int32_t lds_bytes;         /* dynamic LDS one wavefront needs */
+    int32_t waves_per_cu;      /* resident QPs per CU that LDS admits */
+    int64_t algorithmic_bytes; /* compact in+out bytes per QP at WBCQP_F64 */
+} wbcqp_layout;
+
+/*
+ * Per-QP inputs, each a contiguous [batch][len] row-major array of the handle's dtype.
+ * One wavefront reads one QP's rows, so consecutive lanes read consecutive addresses.
+ */
+typedef struct {
+    const void* M;   /* [batch][nv(nv+1)/2] inertia matrix, packed lower triangle (i>=j at i(i+1)/2+j)      */
+    const void* h;   /* [batch][nv]  non-linear effects                                                     */
+    const void* A;   /* [batch][n_dense][nv] dense level-1 task rows (TaskSE3Equality & co: ex_task.cpp:175-247,
+                        task-momentum-equality.cpp:144-173, task-self-collision.cpp:84-203)                   */
+    const void* b1;  /* [batch][r1] level-1 right-hand sides: dense | selection | force-regularisation      */
+    const void* Ac;  /* [batch][nc][6][nv] contact motion-task matrices (local frame)                       */
+    const void* bc;  /* [batch][nc][6]     contact motion-task right-hand sides                             */
+    const void* blb; /* [batch][n_bound]   acceleration bounds                                              */
+    const void* bub; /* [batch][n_bound]                                                                    */
+    const void* tlb; /* [batch][na]        torque bounds, before the -h_a shift (NULL if !act_bounds)       */
+    const void* tub; /* [batch][na]                                                                         */
+    const void* w;   /* [batch][n_tasks]   level-1 task weights (PosTracker::update_task_weights)           */
+} wbcqp_inputs;
+
+typedef struct {
+    void* x;          /* [batch][n]  = [dv; f]        (getAccelerations / getContactForces)  */
+    void* tau;        /* [batch][na] actuator torques (getActuatorForces)                    */
+    int32_t* status;  /* [batch] wbcqp_hqp_status                                            */
+    int32_t* iters;   /* [batch] active-set iterations (eiquadprog `iter`)                   */
+    void* objective;  /* [batch] 0.5x'Hx + g'x (SolverHQPBase::getObjectiveValue), may be NULL */
+    int32_t* n_active;/* [batch] size of the final active set incl. equalities, may be NULL  */
+} wbcqp_outputs;
+
+typedef struct {
+    int32_t device;   /* HIP device ordinal */
+    int32_t dtype;    /* wbcqp_dtype of every input/output array */
+    int32_t flags;    /* reserved, 0 */
+} wbcqp_desc;
+
+/* one homogeneous group of a ragged (mixed-robot) batch */
+typedef struct {
+    int32_t slot;     /* structure slot */
+    int32_t batch;
+    wbcqp_inputs in;  /* DEVICE pointers */
+    wbcqp_outputs out;
+} wbcqp_group;
+
+typedef struct wbcqp_handle wbcqp_handle;
+
+int wbcqp_version(void);
+/* text of the last error on this handle (or of the last failed wbcqp_create if handle == NULL) */
+const char* wbcqp_last_error(const wbcqp_handle* handle);
+
+/* Binds to a gfx950 device. Fails with WBCQP_ERR_NO_DEVICE when none is present (no CPU path). */
+int wbcqp_create(const wbcqp_desc* desc, wbcqp_handle** out);
+int wbcqp_destroy(wbcqp_handle* handle);
+
+/* Uploads a task stack into `slot` (0..WBCQP_MAX_STRUCTURES-1): the analogue of
+ * solver_->resize(nVar, nEq, nIn) at pos_tracker.cpp:102 plus the constant blocks. */
+int wbcqp_set_structure(wbcqp_handle* handle, int slot, const wbcqp_structure* st);
+/* Pure host computation; handle may be NULL (usable without a GPU). */
+int wbcqp_layout_of(const wbcqp_structure* st, wbcqp_layout* out);
+
+/* Solve `batch` QPs of one structure. All pointers are DEVICE pointers on the handle's device;
+ * the launch is asynchronous on `stream` (a hipStream_t, NULL = default stream). */
+int wbcqp_solve_batch(wbcqp_handle* handle, int slot, int batch,
+                      const wbcqp_inputs* in, const wbcqp_outputs* out, void* stream);
+/* Same with HOST pointers: stages through device buffers owned by the handle, blocks until done. */
+int wbcqp_solve_batch_host(wbcqp_handle* handle, int slot, int batch,
+                           const wbcqp_inputs* in, const wbcqp_outputs* out);
+/* Mixed-robot batch: one launch over several homogeneous groups (per-QP n differs between groups). */
+int wbcqp_solve_ragged(wbcqp_handle* handle, int n_groups, const wbcqp_group* groups, void* stream);
+
+/* Optional exchange step: all-gather joint torques of a batch sharded over ranks.
+ * `comm` is an ncclComm_t created by the caller (RCCL). send: [count] elements, recv: [nranks*count]. */
+int wbcqp_allgather_tau(wbcqp_handle* handle, void* comm, const void* send, void* recv,
+                        size_t count, void* stream);
+
+int wbcqp_sync(wbcqp_handle* handle, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WBCQP_H */

@@ -1,0 +1,308 @@
+"""Constant structure of a whole-body QP ("task stack"): what inria_wbc fixes at controller
+construction time and what therefore is NOT streamed per control tick.
+
+Mirrors what `PosTracker::parse_tasks` (/root/reference/src/controllers/pos_tracker.cpp:161-189)
+builds from a `tasks.yaml` through the factories of /root/reference/src/controllers/tasks.cpp:38-404:
+which level-1 rows exist and which weight they carry, which level-0 constraints exist and in which
+order they were added (yaml-cpp iterates the file in order), and the constant blocks of each
+6-D contact (tsid `Contact6d`: force generator, friction pyramid, force regularisation).
+
+Row inventories follow SURVEY.md Appendix B; the numeric constants are the ones in
+/root/reference/etc/{talos,icub,franka,tiago}/tasks.yaml.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+INEQ_BOUNDS = 0
+INEQ_ACTUATION = 1
+INEQ_FORCE = 2
+
+HESSIAN_REGULARIZATION = 1e-8  # tsid DEFAULT_HESSIAN_REGULARIZATION
+MAX_ITER = 1000  # eiquadprog-fast DEFAULT_MAX_ITER
+W_FORCE_FEET = 1e-3  # /root/reference/include/inria_wbc/controllers/tasks.hpp:23
+CONTACT6D_FORCE_REG_WEIGHTS = (1.0, 1.0, 1e-3, 2.0, 2.0, 2.0)  # tsid Contact6d ctor default
+
+
+def _skew(p: Sequence[float]) -> np.ndarray:
+    x, y, z = p
+    return np.array([[0.0, -z, y], [z, 0.0, -x], [-y, x, 0.0]])
+
+
+def contact6d_points(lxn: float, lyn: float, lxp: float, lyp: float, lz: float) -> np.ndarray:
+    """3x4 contact points in the order of tasks.cpp:353-358."""
+    return np.array([[-lxn, -lxn, lxp, lxp], [-lyn, lyp, -lyn, lyp], [lz, lz, lz, lz]], dtype=np.float64)
+
+
+def contact6d_force_generator(points: np.ndarray) -> np.ndarray:
+    """T (6x12) = per point [I3; skew(p_i)]  (tsid Contact6d::updateForceGeneratorMatrix)."""
+    T = np.zeros((6, 12))
+    for i in range(4):
+        T[0:3, 3 * i:3 * i + 3] = np.eye(3)
+        T[3:6, 3 * i:3 * i + 3] = _skew(points[:, i])
+    return T
+
+
+def contact6d_friction(normal: Sequence[float], mu: float, fmin: float, fmax: float) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """B (17x12), lb, ub of tsid Contact6d::updateForceInequalityConstraints:
+    rows 0-3 of the first point = (-/+t1 - mu n)', (-/+t2 - mu n)', replicated block-diagonally for the
+    4 points with lb = -1e10, ub = 0; row 16 = [n' n' n' n'] with lb = fmin, ub = fmax."""
+    n = np.asarray(normal, dtype=np.float64)
+    t1 = np.cross(n, [1.0, 0.0, 0.0])
+    if np.linalg.norm(t1) < 1e-5:
+        t1 = np.cross(n, [0.0, 1.0, 0.0])
+    t2 = np.cross(n, t1)
+    t1 = t1 / np.linalg.norm(t1)
+    t2 = t2 / np.linalg.norm(t2)
+    B = np.zeros((17, 12))
+    B[0, 0:3] = -t1 - mu * n
+    B[1, 0:3] = t1 - mu * n
+    B[2, 0:3] = -t2 - mu * n
+    B[3, 0:3] = t2 - mu * n
+    for i in range(1, 4):
+        B[4 * i:4 * i + 4, 3 * i:3 * i + 3] = B[0:4, 0:3]
+    for i in range(4):
+        B[16, 3 * i:3 * i + 3] = n
+    lb = -1e10 * np.ones(17)
+    ub = np.zeros(17)
+    lb[16] = fmin
+    ub[16] = fmax
+    return B, lb, ub
+
+
+@dataclass
+class Contact:
+    name: str
+    points: np.ndarray  # 3x4
+    normal: Tuple[float, float, float]
+    mu: float
+    fmin: float
+    fmax: float
+    force_reg_weights: Tuple[float, ...] = CONTACT6D_FORCE_REG_WEIGHTS
+
+    @property
+    def T(self) -> np.ndarray:
+        return contact6d_force_generator(self.points)
+
+    @property
+    def forcereg(self) -> np.ndarray:
+        """diag(w_f) * T  (tsid Contact6d::updateForceRegularizationTask)."""
+        return np.diag(self.force_reg_weights) @ self.T
+
+
+@dataclass
+class Structure:
+    """One task stack. Field meanings match `wbcqp_structure` in include/wbcqp.h."""
+    name: str
+    nv: int
+    na: int
+    contacts: List[Contact]
+    # level 1
+    task_names: List[str]  # index = position in the per-QP weight vector w
+    default_weights: np.ndarray  # [n_tasks]
+    dense_row_task: np.ndarray  # [n_dense] int32
+    sel_col: np.ndarray  # [n_sel] int32
+    sel_task: np.ndarray  # [n_sel] int32
+    forcereg_task: np.ndarray  # [nc] int32
+    # level 0
+    bound_col: np.ndarray  # [n_bound] int32
+    act_bounds: bool
+    ineq_blocks: List[Tuple[int, int]]  # (kind, arg) in task-stack order
+    hessian_reg: float = HESSIAN_REGULARIZATION
+    max_iter: int = MAX_ITER
+    kp: Dict[str, float] = field(default_factory=dict)  # task gains (only used by reference-stream generators)
+
+    # ---- sizes -------------------------------------------------------------------------
+    @property
+    def nc(self) -> int:
+        return len(self.contacts)
+
+    @property
+    def k(self) -> int:
+        return 12 * self.nc
+
+    @property
+    def n(self) -> int:
+        return self.nv + self.k
+
+    @property
+    def nu(self) -> int:
+        return self.nv - self.na
+
+    @property
+    def n_dense(self) -> int:
+        return int(self.dense_row_task.size)
+
+    @property
+    def n_sel(self) -> int:
+        return int(self.sel_col.size)
+
+    @property
+    def n_bound(self) -> int:
+        return int(self.bound_col.size)
+
+    @property
+    def n_tasks(self) -> int:
+        return len(self.task_names)
+
+    @property
+    def neq(self) -> int:
+        return self.nu + 6 * self.nc
+
+    @property
+    def nin(self) -> int:
+        """two-sided inequality rows (tsid nIn)."""
+        t = 0
+        for kind, _ in self.ineq_blocks:
+            t += {INEQ_BOUNDS: self.n_bound, INEQ_ACTUATION: self.na, INEQ_FORCE: 17}[kind]
+        return t
+
+    @property
+    def nin2(self) -> int:
+        """one-sided rows of eiquadprog's CI."""
+        return 2 * self.nin
+
+    @property
+    def r1(self) -> int:
+        return self.n_dense + self.n_sel + 6 * self.nc
+
+    # ---- constant blocks ---------------------------------------------------------------
+    def force_gen(self) -> np.ndarray:
+        return np.ascontiguousarray(np.stack([c.T for c in self.contacts]) if self.contacts else np.zeros((0, 6, 12)))
+
+    def forcereg_mat(self) -> np.ndarray:
+        return np.ascontiguousarray(np.stack([c.forcereg for c in self.contacts]) if self.contacts else np.zeros((0, 6, 12)))
+
+    def friction(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        if not self.contacts:
+            return np.zeros((0, 17, 12)), np.zeros((0, 17)), np.zeros((0, 17))
+        Bs, lbs, ubs = zip(*[contact6d_friction(c.normal, c.mu, c.fmin, c.fmax) for c in self.contacts])
+        return np.ascontiguousarray(np.stack(Bs)), np.ascontiguousarray(np.stack(lbs)), np.ascontiguousarray(np.stack(ubs))
+
+    # ---- per-QP record layout (element counts; include/wbcqp.h documents the same) ------
+    def field_lengths(self) -> Dict[str, int]:
+        return {
+            "M": self.nv * (self.nv + 1) // 2,
+            "h": self.nv,
+            "A": self.n_dense * self.nv,
+            "b1": self.r1,
+            "Ac": self.nc * 6 * self.nv,
+            "bc": self.nc * 6,
+            "blb": self.n_bound,
+            "bub": self.n_bound,
+            "tlb": self.na if self.act_bounds else 0,
+            "tub": self.na if self.act_bounds else 0,
+            "w": self.n_tasks,
+        }
+
+    def algorithmic_bytes(self, itemsize: int = 8) -> int:
+        """Compact-boundary bytes per QP: inputs + x + tau + status/iters."""
+        n_in = sum(self.field_lengths().values())
+        return itemsize * (n_in + self.n + self.na) + 8
+
+
+def _mk(name, nv, na, contacts, dense_tasks, posture, sc_tasks, has_bounds, has_act, level0_order, kp=None):
+    """dense_tasks: list of (name, rows, weight) in yaml order (se3/com/momentum);
+    posture: (name, weight) or None, with its yaml position given by `order` below;
+    sc_tasks: list of (name, weight) self-collision tasks (1 dense row each).
+    The weight vector w is ordered like tsid's level-1 list (order of addMotionTask/addRigidContact calls)."""
+    task_names: List[str] = []
+    weights: List[float] = []
+    dense_row_task: List[int] = []
+    sel_col: List[int] = []
+    sel_task: List[int] = []
+    forcereg_task: List[int] = []
+    for item in dense_tasks:
+        if item[0] == "__posture__":
+            _, pname, w = item
+            t = len(task_names)
+            task_names.append(pname)
+            weights.append(w)
+            for j in range(na):
+                sel_col.append(nv - na + j)
+                sel_task.append(t)
+        elif item[0] == "__contacts__":
+            for c in contacts:
+                t = len(task_names)
+                task_names.append("forcereg_" + c.name)
+                weights.append(W_FORCE_FEET)
+                forcereg_task.append(t)
+        else:
+            tname, rows, w = item
+            t = len(task_names)
+            task_names.append(tname)
+            weights.append(w)
+            dense_row_task.extend([t] * rows)
+    for tname, w in sc_tasks:
+        t = len(task_names)
+        task_names.append(tname)
+        weights.append(w)
+        dense_row_task.append(t)
+    if contacts and not forcereg_task:
+        raise ValueError("contacts given but no __contacts__ marker")
+    bound_col = np.arange(nv - na, nv, dtype=np.int32) if has_bounds else np.zeros(0, np.int32)
+    return Structure(
+        name=name, nv=nv, na=na, contacts=contacts, task_names=task_names,
+        default_weights=np.asarray(weights, dtype=np.float64),
+        dense_row_task=np.asarray(dense_row_task, dtype=np.int32),
+        sel_col=np.asarray(sel_col, dtype=np.int32), sel_task=np.asarray(sel_task, dtype=np.int32),
+        forcereg_task=np.asarray(forcereg_task, dtype=np.int32),
+        bound_col=bound_col, act_bounds=has_act, ineq_blocks=list(level0_order), kp=kp or {})
+
+
+def talos_structure(single_support: bool = False) -> Structure:
+    """/root/reference/etc/talos/tasks.yaml with talos.urdf: nv 50, na 44, two 6-D foot contacts
+    -> n 74, nEq 18, nIn 122 (244 one-sided), 97 level-1 rows.
+    single_support=True drops contact_lfoot like WalkOnSpot does (walk_on_spot.cpp:165-184):
+    n 62, nEq 12, nIn 105, 91 level-1 rows."""
+    pts = contact6d_points(lxn=0.11, lyn=0.069, lxp=0.1, lyp=0.069, lz=0.107)
+    cl = Contact("contact_lfoot", pts, (0.0, 0.0, 1.0), 0.3, 5.0, 1500.0)
+    cr = Contact("contact_rfoot", pts, (0.0, 0.0, 1.0), 0.3, 5.0, 1500.0)
+    contacts = [cr] if single_support else [cl, cr]
+    dense = [("head", 2, 1.0), ("head_pitch", 1, 100.0), ("head_yaw", 1, 100.0), ("lh", 6, 10.0), ("rh", 6, 10.0),
+             ("torso", 2, 10.0), ("lf", 6, 1000.0), ("rf", 6, 1000.0), ("com", 3, 1000.0),
+             ("__posture__", "posture", 1.75), ("momentum", 2, 0.0 if single_support else 1000.0), ("__contacts__",)]
+    sc = [("self_collision-left", 2000.0), ("self_collision-right", 2000.0), ("self_collision-elbow-right", 1000.0),
+          ("self_collision-elbow-left", 1000.0), ("self_collision-wrist-right", 1000.0), ("self_collision-wrist-left", 1000.0)]
+    level0 = [(INEQ_BOUNDS, 0), (INEQ_ACTUATION, 0)] + [(INEQ_FORCE, c) for c in range(len(contacts))]
+    kp = {"com": 30.0, "lf": 30.0, "rf": 30.0, "posture": 10.0}
+    return _mk("talos_single_support" if single_support else "talos", 50, 44, contacts, dense, None, sc, True, True, level0, kp)
+
+
+def icub_structure() -> Structure:
+    """/root/reference/etc/icub/tasks.yaml: nv 38, na 32, two contacts (normal 0,0,-1), bounds but no
+    actuation bounds -> n 62, nEq 18, nIn 66 (132), 83 level-1 rows."""
+    pts = contact6d_points(lxn=0.06, lyn=0.045, lxp=0.14, lyp=0.045, lz=0.065)
+    contacts = [Contact("contact_lfoot", pts, (0.0, 0.0, -1.0), 0.3, 5.0, 1500.0),
+                Contact("contact_rfoot", pts, (0.0, 0.0, -1.0), 0.3, 5.0, 1500.0)]
+    dense = [("lh", 6, 1.0), ("rh", 6, 1.0), ("lf", 6, 1000.0), ("rf", 6, 10.0), ("com", 3, 3000.0), ("momentum", 2, 1000.0),
+             ("__posture__", "posture", 0.05), ("torso", 3, 1.0), ("head", 5, 10.0), ("__contacts__",)]
+    sc = [("self_collision-left", 500.0), ("self_collision-right", 500.0)]
+    level0 = [(INEQ_BOUNDS, 0), (INEQ_FORCE, 0), (INEQ_FORCE, 1)]
+    return _mk("icub", 38, 32, contacts, dense, None, sc, True, False, level0, {"com": 50.0, "posture": 10.0})
+
+
+def franka_structure() -> Structure:
+    """/root/reference/etc/franka/tasks.yaml: fixed base, nv = na = 9, no constraints, 15 level-1 rows."""
+    dense = [("ee", 6, 100.0), ("__posture__", "posture", 0.75)]
+    return _mk("franka", 9, 9, [], dense, None, [], False, False, [], {"ee": 30.0, "posture": 30.0})
+
+
+def tiago_structure(nv: int = 12) -> Structure:
+    """/root/reference/etc/tiago/tasks.yaml: fixed base, bounds only; nv is not derivable without the URDF
+    (SURVEY App. B takes 12): 6 + 3 + nv + 4 level-1 rows, nIn = nv."""
+    dense = [("ee", 6, 1500.0), ("head", 3, 500.0), ("__posture__", "posture", 0.1)]
+    sc = [("sc-gripper", 1000.0), ("sc-wrist", 1000.0), ("sc-forearm", 1000.0), ("sc-elbow", 1000.0)]
+    return _mk("tiago", nv, nv, [], dense, None, sc, True, False, [(INEQ_BOUNDS, 0)])
+
+
+STRUCTURES = {
+    "talos": talos_structure,
+    "talos_single_support": lambda: talos_structure(single_support=True),
+    "icub": icub_structure,
+    "franka": franka_structure,
+    "tiago": tiago_structure,
+}
