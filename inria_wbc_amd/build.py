@@ -1,0 +1,53 @@
+"""Builds libwbcqp.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in CI containers too. The .so lands in
+inria_wbc_amd/lib/ (git-ignored, but shipped to the GPU box with the working tree).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+LIB = os.path.join(LIBDIR, "libwbcqp.so")
+SOURCES = ["wbcqp_api.hip"]
+HEADERS = ["wbcqp_device.hpp", os.path.join("..", "..", "include", "wbcqp.h")]
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X kernels cannot be built")
+    return exe
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}",
+           "-fno-gpu-rdc", "-ffp-contract=on", "-Wall", "-Wno-unused-function",
+           *extra_flags,
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp", "-ldl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

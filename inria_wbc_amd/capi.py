@@ -1,0 +1,251 @@
+"""ctypes binding of the C ABI in include/wbcqp.h (libwbcqp.so).
+
+This is plumbing: every call goes to the HIP library. There is no Python or CPU implementation of
+the solve behind it -- if the library is missing or no gfx950 device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from .structure import Structure
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwbcqp.so")
+
+WBCQP_OK = 0
+ERR_NAMES = {0: "OK", 1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "NO_DEVICE", 5: "RCCL"}
+F64, F32 = 0, 1
+FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
+
+# every symbol include/wbcqp.h declares
+EXPORTS = ("wbcqp_version", "wbcqp_last_error", "wbcqp_create", "wbcqp_destroy", "wbcqp_set_structure",
+           "wbcqp_layout_of", "wbcqp_solve_batch", "wbcqp_solve_batch_host", "wbcqp_solve_ragged",
+           "wbcqp_allgather_tau", "wbcqp_sync")
+
+c_i32_p = C.POINTER(C.c_int32)
+c_f64_p = C.POINTER(C.c_double)
+
+
+class WbcqpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("wbcqp error %d (%s): %s" % (code, ERR_NAMES.get(code, "?"), msg))
+        self.code = code
+
+
+class CStructure(C.Structure):
+    _fields_ = [
+        ("nv", C.c_int32), ("na", C.c_int32), ("nc", C.c_int32),
+        ("n_dense", C.c_int32), ("n_tasks", C.c_int32), ("dense_row_task", c_i32_p),
+        ("n_sel", C.c_int32), ("sel_col", c_i32_p), ("sel_task", c_i32_p),
+        ("forcereg_mat", c_f64_p), ("forcereg_task", c_i32_p),
+        ("force_gen", c_f64_p), ("fric_mat", c_f64_p), ("fric_lb", c_f64_p), ("fric_ub", c_f64_p),
+        ("n_bound", C.c_int32), ("bound_col", c_i32_p), ("act_bounds", C.c_int32),
+        ("n_ineq_blocks", C.c_int32), ("ineq_kind", c_i32_p), ("ineq_arg", c_i32_p),
+        ("hessian_reg", C.c_double), ("max_iter", C.c_int32),
+    ]
+
+
+class CLayout(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n", "neq", "nin", "nin2", "r1", "len_M", "len_h", "len_A", "len_b1", "len_Ac",
+                                         "len_bc", "len_blb", "len_bub", "len_tlb", "len_tub", "len_w", "lds_bytes",
+                                         "waves_per_cu")] + [("algorithmic_bytes", C.c_int64)]
+
+
+class CInputs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in FIELDS]
+
+
+class COutputs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("tau", C.c_void_p), ("status", C.c_void_p), ("iters", C.c_void_p),
+                ("objective", C.c_void_p), ("n_active", C.c_void_p)]
+
+
+class CDesc(C.Structure):
+    _fields_ = [("device", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_int32)]
+
+
+class CGroup(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("batch", C.c_int32), ("inp", CInputs), ("out", COutputs)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Loads libwbcqp.so. Import torch first when it is going to be used in the same process, so that
+    both share one HIP runtime (same soname libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s is missing: build it with `python -m inria_wbc_amd.build` (hipcc, gfx950). "
+            "There is no fallback implementation." % path)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib.wbcqp_version.restype = C.c_int
+    lib.wbcqp_last_error.restype = C.c_char_p
+    lib.wbcqp_last_error.argtypes = [C.c_void_p]
+    lib.wbcqp_create.argtypes = [C.POINTER(CDesc), C.POINTER(C.c_void_p)]
+    lib.wbcqp_destroy.argtypes = [C.c_void_p]
+    lib.wbcqp_set_structure.argtypes = [C.c_void_p, C.c_int, C.POINTER(CStructure)]
+    lib.wbcqp_layout_of.argtypes = [C.POINTER(CStructure), C.POINTER(CLayout)]
+    lib.wbcqp_solve_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CInputs), C.POINTER(COutputs), C.c_void_p]
+    lib.wbcqp_solve_batch_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CInputs), C.POINTER(COutputs)]
+    lib.wbcqp_solve_ragged.argtypes = [C.c_void_p, C.c_int, C.POINTER(CGroup), C.c_void_p]
+    lib.wbcqp_allgather_tau.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.wbcqp_sync.argtypes = [C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+class StructureBuffers:
+    """Host-side wbcqp_structure built from a `Structure`; keeps the numpy arrays alive."""
+
+    def __init__(self, st: Structure):
+        self._keep = []
+
+        def keep(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            if a.size == 0:
+                a = np.zeros(1, dtype=dtype)
+            self._keep.append(a)
+            return a
+
+        def ip(a):
+            return keep(a, np.int32).ctypes.data_as(c_i32_p)
+
+        def dp(a):
+            return keep(a, np.float64).ctypes.data_as(c_f64_p)
+
+        B, lb, ub = st.friction()
+        s = CStructure()
+        s.nv, s.na, s.nc = st.nv, st.na, st.nc
+        s.n_dense, s.n_tasks = st.n_dense, st.n_tasks
+        s.dense_row_task = ip(st.dense_row_task)
+        s.n_sel = st.n_sel
+        s.sel_col = ip(st.sel_col)
+        s.sel_task = ip(st.sel_task)
+        s.forcereg_mat = dp(st.forcereg_mat())
+        s.forcereg_task = ip(st.forcereg_task)
+        s.force_gen = dp(st.force_gen())
+        s.fric_mat, s.fric_lb, s.fric_ub = dp(B), dp(lb), dp(ub)
+        s.n_bound = st.n_bound
+        s.bound_col = ip(st.bound_col)
+        s.act_bounds = int(st.act_bounds)
+        s.n_ineq_blocks = len(st.ineq_blocks)
+        s.ineq_kind = ip([k for k, _ in st.ineq_blocks])
+        s.ineq_arg = ip([a for _, a in st.ineq_blocks])
+        s.hessian_reg = st.hessian_reg
+        s.max_iter = st.max_iter
+        self.c = s
+
+
+def layout_of(st: Structure) -> Dict[str, int]:
+    """wbcqp_layout_of: sizes, per-QP array lengths and LDS footprint (pure host; no GPU needed)."""
+    lib = load_library()
+    sb = StructureBuffers(st)
+    L = CLayout()
+    rc = lib.wbcqp_layout_of(C.byref(sb.c), C.byref(L))
+    if rc != WBCQP_OK:
+        raise WbcqpError(rc, (lib.wbcqp_last_error(None) or b"").decode())
+    return {k: getattr(L, k) for k, _ in CLayout._fields_}
+
+
+class Handle:
+    """wbcqp_handle bound to one HIP device."""
+
+    def __init__(self, device: int = 0, dtype: int = F64):
+        self.lib = load_library()
+        self.dtype = dtype
+        self.np_dtype = np.float64 if dtype == F64 else np.float32
+        self.device = device
+        self._h = C.c_void_p()
+        self._structs: Dict[int, Structure] = {}
+        desc = CDesc(device, dtype, 0)
+        rc = self.lib.wbcqp_create(C.byref(desc), C.byref(self._h))
+        if rc != WBCQP_OK:
+            raise WbcqpError(rc, (self.lib.wbcqp_last_error(None) or b"").decode())
+
+    def _check(self, rc: int):
+        if rc != WBCQP_OK:
+            raise WbcqpError(rc, (self.lib.wbcqp_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h:
+            self.lib.wbcqp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_structure(self, slot: int, st: Structure):
+        sb = StructureBuffers(st)
+        self._check(self.lib.wbcqp_set_structure(self._h, slot, C.byref(sb.c)))
+        self._structs[slot] = st
+
+    # ---- device-pointer path (torch tensors are only carriers of device memory) ----
+    def _pack(self, slot: int, batch: int, inputs, outputs):
+        st = self._structs[slot]
+        L = st.field_lengths()
+        cin = CInputs()
+        for k in FIELDS:
+            t = inputs.get(k)
+            if L[k] == 0 or t is None:
+                setattr(cin, k, None)
+                continue
+            assert t.is_cuda and t.is_contiguous() and t.numel() == batch * L[k], (k, tuple(t.shape), batch, L[k])
+            setattr(cin, k, t.data_ptr())
+        cout = COutputs()
+        for k in ("x", "tau", "status", "iters", "objective", "n_active"):
+            t = outputs.get(k)
+            setattr(cout, k, t.data_ptr() if t is not None and t.numel() else None)
+        return cin, cout
+
+    def solve_batch(self, slot: int, batch: int, inputs: Dict[str, "object"], outputs: Dict[str, "object"], stream: int = 0):
+        cin, cout = self._pack(slot, batch, inputs, outputs)
+        self._check(self.lib.wbcqp_solve_batch(self._h, slot, batch, C.byref(cin), C.byref(cout), C.c_void_p(stream)))
+
+    def solve_ragged(self, groups: Sequence[tuple], stream: int = 0):
+        """groups: sequence of (slot, batch, inputs, outputs) with device tensors."""
+        arr = (CGroup * len(groups))()
+        for i, (slot, batch, inputs, outputs) in enumerate(groups):
+            cin, cout = self._pack(slot, batch, inputs, outputs)
+            arr[i].slot, arr[i].batch, arr[i].inp, arr[i].out = slot, batch, cin, cout
+        self._check(self.lib.wbcqp_solve_ragged(self._h, len(groups), arr, C.c_void_p(stream)))
+
+    def sync(self, stream: int = 0):
+        self._check(self.lib.wbcqp_sync(self._h, C.c_void_p(stream)))
+
+    # ---- host-pointer path ----
+    def solve_batch_host(self, slot: int, inputs: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+        st = self._structs[slot]
+        L = st.field_lengths()
+        batch = int(np.asarray(inputs["h"]).reshape(-1, st.nv).shape[0])
+        keep = {}
+        cin = CInputs()
+        for k in FIELDS:
+            if L[k] == 0:
+                setattr(cin, k, None)
+                continue
+            a = np.ascontiguousarray(inputs[k], dtype=self.np_dtype).reshape(batch, L[k])
+            keep[k] = a
+            setattr(cin, k, a.ctypes.data)
+        out = dict(x=np.zeros((batch, st.n), self.np_dtype), tau=np.zeros((batch, max(st.na, 1)), self.np_dtype),
+                   status=np.full(batch, -99, np.int32), iters=np.zeros(batch, np.int32),
+                   objective=np.zeros(batch, self.np_dtype), n_active=np.zeros(batch, np.int32))
+        cout = COutputs(*[out[k].ctypes.data for k in ("x", "tau", "status", "iters", "objective", "n_active")])
+        self._check(self.lib.wbcqp_solve_batch_host(self._h, slot, batch, C.byref(cin), C.byref(cout)))
+        out["tau"] = out["tau"][:, :st.na]
+        return out
+
+    def allgather_tau(self, comm: int, send_ptr: int, recv_ptr: int, count: int, stream: int = 0):
+        self._check(self.lib.wbcqp_allgather_tau(self._h, C.c_void_p(comm), C.c_void_p(send_ptr), C.c_void_p(recv_ptr),
+                                                 count, C.c_void_p(stream)))

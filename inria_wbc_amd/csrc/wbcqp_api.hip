@@ -1,0 +1,465 @@
+// wbcqp_api.hip -- C ABI (include/wbcqp.h) over the one-wavefront-per-QP kernel.
+//
+// Replaces, for B robot instances at once, the two calls the reference makes per control tick
+// (/root/reference/src/controllers/controller.cpp:244 computeProblemData [assembly half] and :247
+// solver_->solve) plus the decode at :250-251.  There is no CPU path in this library: without a
+// gfx950 device wbcqp_create fails with WBCQP_ERR_NO_DEVICE.
+#include "wbcqp_device.hpp"
+
+#include "../../include/wbcqp.h"
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace wbcqp;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Slot {
+    bool set = false;
+    DevStruct host{};           // host copy (device pointers inside)
+    DevStruct* dev = nullptr;   // device copy
+    std::vector<void*> allocs;  // device arrays owned by this slot
+    wbcqp_layout layout{};
+};
+
+struct Staging {
+    void* dev = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct wbcqp_handle {
+    int device = 0;
+    int dtype = WBCQP_F64;
+    std::string err;
+    Slot slots[WBCQP_MAX_STRUCTURES];
+    Staging stage_in, stage_out;
+    int max_lds = 0;
+};
+
+namespace {
+
+int fail(wbcqp_handle* h, int code, const std::string& msg)
+{
+    if (h)
+        h->err = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, WBCQP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+int odd(int v) { return v | 1; }
+
+// Validates a structure and derives sizes + LDS layout. Pure host code.
+int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string& why)
+{
+    if (!st) { why = "structure is NULL"; return WBCQP_ERR_INVALID; }
+    if (st->nv <= 0 || st->na < 0 || st->na > st->nv || st->nc < 0) { why = "bad nv/na/nc"; return WBCQP_ERR_INVALID; }
+    if (st->n_dense < 0 || st->n_sel < 0 || st->n_tasks <= 0 || st->n_bound < 0) { why = "bad level-1 sizes"; return WBCQP_ERR_INVALID; }
+    if (st->n_ineq_blocks < 0 || st->n_ineq_blocks > WBCQP_MAX_INEQ_BLOCKS) { why = "too many inequality blocks"; return WBCQP_ERR_INVALID; }
+    std::memset(&D, 0, sizeof(D));
+    D.nv = st->nv; D.na = st->na; D.nc = st->nc; D.k = 12 * st->nc; D.n = D.nv + D.k; D.nu = D.nv - D.na;
+    if (D.n > WBCQP_MAX_VARS) { why = "n = nv + 12 nc exceeds WBCQP_MAX_VARS"; return WBCQP_ERR_UNSUPPORTED; }
+    D.n_dense = st->n_dense; D.n_tasks = st->n_tasks; D.n_sel = st->n_sel; D.n_bound = st->n_bound;
+    D.act_bounds = st->act_bounds ? 1 : 0;
+    D.neq = D.nu + 6 * D.nc;
+    D.r1 = D.n_dense + D.n_sel + 6 * D.nc;
+    D.n_blocks = st->n_ineq_blocks;
+    int off = 0;
+    bool has_act = false;
+    for (int b = 0; b < D.n_blocks; ++b) {
+        const int kind = st->ineq_kind[b];
+        int rows;
+        if (kind == WBCQP_INEQ_BOUNDS) rows = D.n_bound;
+        else if (kind == WBCQP_INEQ_ACTUATION) { rows = D.na; has_act = true; }
+        else if (kind == WBCQP_INEQ_FORCE) {
+            rows = 17;
+            if (st->ineq_arg[b] < 0 || st->ineq_arg[b] >= D.nc) { why = "force block names a missing contact"; return WBCQP_ERR_INVALID; }
+        }
+        else { why = "unknown inequality kind"; return WBCQP_ERR_INVALID; }
+        D.blk_kind[b] = kind; D.blk_arg[b] = st->ineq_arg[b]; D.blk_off[b] = off; D.blk_rows[b] = rows;
+        off += 2 * rows;
+    }
+    if (has_act != (D.act_bounds != 0)) { why = "act_bounds flag and inequality blocks disagree"; return WBCQP_ERR_INVALID; }
+    D.nin2 = off;
+    if (D.neq > D.n) { why = "more equalities than variables"; return WBCQP_ERR_INVALID; }
+    for (int r = 0; r < D.n_dense; ++r)
+        if (st->dense_row_task[r] < 0 || st->dense_row_task[r] >= D.n_tasks) { why = "dense_row_task out of range"; return WBCQP_ERR_INVALID; }
+    for (int r = 0; r < D.n_sel; ++r)
+        if (st->sel_col[r] < 0 || st->sel_col[r] >= D.nv || st->sel_task[r] < 0 || st->sel_task[r] >= D.n_tasks) { why = "selection row out of range"; return WBCQP_ERR_INVALID; }
+    for (int r = 0; r < D.n_bound; ++r)
+        if (st->bound_col[r] < 0 || st->bound_col[r] >= D.nv) { why = "bound_col out of range"; return WBCQP_ERR_INVALID; }
+    for (int c = 0; c < D.nc; ++c)
+        if (st->forcereg_task[c] < 0 || st->forcereg_task[c] >= D.n_tasks) { why = "forcereg_task out of range"; return WBCQP_ERR_INVALID; }
+    D.max_iter = st->max_iter > 0 ? st->max_iter : 1000;
+    D.hessian_reg = st->hessian_reg;
+
+    // ---- LDS layout (doubles) ----
+    const int n = D.n, nv = D.nv;
+    D.ldj = odd(n); D.ldm = odd(nv); D.ldc = odd(nv);
+    int o = 0;
+    auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; }; // keep 16-byte alignment
+    D.o_J = take(n * D.ldj);
+    int rsize = n * (n + 3) / 2 + 2;
+    if (D.n_dense * nv > rsize) rsize = D.n_dense * nv;
+    D.o_R = take(rsize);
+    D.o_M = take(nv * D.ldm);
+    D.o_Jc = take(D.k * D.ldc);
+    D.o_Ac = take(D.nc * 6 * nv);
+    D.o_h = take(nv);
+    D.o_x = take(n); D.o_np = take(n); D.o_d = take(n); D.o_z = take(n); D.o_xold = take(n);
+    D.o_r = take(n + 2); D.o_u = take(n + 2); D.o_uold = take(n + 2);
+    D.o_s = take(D.nin2);
+    D.o_blb = take(D.n_bound); D.o_bub = take(D.n_bound);
+    D.o_tl = take(D.na); D.o_tu = take(D.na);
+    D.o_bc = take(6 * D.nc);
+    D.o_cc = take(n + 2); D.o_ss = take(n + 2); D.o_xny = take(n + 2);
+    D.o_rdinv = take(n + 2); D.o_dinv = take(n + 2); D.o_g = take(n);
+    D.o_w = take(D.n_tasks); D.o_b1 = take(D.r1); D.o_q = take(n + 2);
+    D.o_int = o;
+    const int n_int = 2 * (n + 2) + 2 * D.nin2 + (n + 2);
+    o += (n_int + 1) / 2 + 2;
+    D.lds_doubles = o;
+
+    std::memset(&L, 0, sizeof(L));
+    L.n = n; L.neq = D.neq; L.nin = D.nin2 / 2; L.nin2 = D.nin2; L.r1 = D.r1;
+    L.len_M = nv * (nv + 1) / 2; L.len_h = nv; L.len_A = D.n_dense * nv; L.len_b1 = D.r1;
+    L.len_Ac = D.nc * 6 * nv; L.len_bc = D.nc * 6; L.len_blb = D.n_bound; L.len_bub = D.n_bound;
+    L.len_tlb = D.act_bounds ? D.na : 0; L.len_tub = L.len_tlb; L.len_w = D.n_tasks;
+    L.lds_bytes = o * 8;
+    L.waves_per_cu = L.lds_bytes > 0 ? (160 * 1024) / L.lds_bytes : 0;
+    if (L.waves_per_cu > 32) L.waves_per_cu = 32;
+    const int64_t n_in = (int64_t)L.len_M + L.len_h + L.len_A + L.len_b1 + L.len_Ac + L.len_bc + L.len_blb + L.len_bub +
+                         L.len_tlb + L.len_tub + L.len_w;
+    L.algorithmic_bytes = 8 * (n_in + n + D.na) + 8;
+    if (L.lds_bytes > 160 * 1024) { why = "QP does not fit the 160 KiB LDS of one CU"; return WBCQP_ERR_UNSUPPORTED; }
+    return WBCQP_OK;
+}
+
+template <typename T>
+int upload(wbcqp_handle* h, Slot& s, const T* src, size_t count, const T** dst)
+{
+    void* p = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(h, hipMalloc(&p, bytes));
+    s.allocs.push_back(p);
+    if (count) HIP_TRY(h, hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T*>(p);
+    return WBCQP_OK;
+}
+
+void release(Slot& s)
+{
+    for (void* p : s.allocs) (void)hipFree(p);
+    s.allocs.clear();
+    if (s.dev) (void)hipFree(s.dev);
+    s.dev = nullptr;
+    s.set = false;
+}
+
+template <typename TI>
+void fill_group(GroupArgs<TI>& g, const Slot& s, int batch, const wbcqp_inputs* in, const wbcqp_outputs* out)
+{
+    g.st = s.dev;
+    g.M = static_cast<const TI*>(in->M); g.h = static_cast<const TI*>(in->h); g.A = static_cast<const TI*>(in->A);
+    g.b1 = static_cast<const TI*>(in->b1); g.Ac = static_cast<const TI*>(in->Ac); g.bc = static_cast<const TI*>(in->bc);
+    g.blb = static_cast<const TI*>(in->blb); g.bub = static_cast<const TI*>(in->bub);
+    g.tlb = static_cast<const TI*>(in->tlb); g.tub = static_cast<const TI*>(in->tub); g.w = static_cast<const TI*>(in->w);
+    g.x = static_cast<TI*>(out->x); g.tau = static_cast<TI*>(out->tau); g.objective = static_cast<TI*>(out->objective);
+    g.status = out->status; g.iters = out->iters; g.n_active = out->n_active;
+    g.count = batch;
+}
+
+int check_io(wbcqp_handle* h, const Slot& s, int batch, const wbcqp_inputs* in, const wbcqp_outputs* out)
+{
+    if (batch < 0) return fail(h, WBCQP_ERR_INVALID, "negative batch");
+    if (batch == 0) return WBCQP_OK;
+    if (!in || !out) return fail(h, WBCQP_ERR_INVALID, "inputs/outputs struct is NULL");
+    const wbcqp_layout& L = s.layout;
+    auto need = [&](const void* p, int len, const char* name) -> bool {
+        if (len > 0 && !p) { h->err = std::string("input array ") + name + " is NULL"; return false; }
+        return true;
+    };
+    if (!need(in->M, L.len_M, "M") || !need(in->h, L.len_h, "h") || !need(in->A, L.len_A, "A") || !need(in->b1, L.len_b1, "b1") ||
+        !need(in->Ac, L.len_Ac, "Ac") || !need(in->bc, L.len_bc, "bc") || !need(in->blb, L.len_blb, "blb") ||
+        !need(in->bub, L.len_bub, "bub") || !need(in->tlb, L.len_tlb, "tlb") || !need(in->tub, L.len_tub, "tub") ||
+        !need(in->w, L.len_w, "w"))
+        return WBCQP_ERR_INVALID;
+    if (!out->x || !out->status || !out->iters || (s.host.na > 0 && !out->tau))
+        return fail(h, WBCQP_ERR_INVALID, "output arrays x, tau, status, iters are required");
+    return WBCQP_OK;
+}
+
+template <typename TI>
+int launch(wbcqp_handle* h, const GroupTable<TI>& tab, int total, int lds_bytes, hipStream_t stream)
+{
+    if (total == 0) return WBCQP_OK;
+    if (lds_bytes > h->max_lds) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<TI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        h->max_lds = lds_bytes;
+    }
+    hipLaunchKernelGGL(solve_kernel<TI>, dim3(total), dim3(kWave), lds_bytes, stream, tab);
+    HIP_TRY(h, hipGetLastError());
+    return WBCQP_OK;
+}
+
+int ensure(wbcqp_handle* h, Staging& s, size_t bytes)
+{
+    if (s.bytes >= bytes) return WBCQP_OK;
+    if (s.dev) (void)hipFree(s.dev);
+    s.dev = nullptr;
+    s.bytes = 0;
+    HIP_TRY(h, hipMalloc(&s.dev, bytes));
+    s.bytes = bytes;
+    return WBCQP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int wbcqp_version(void) { return WBCQP_VERSION; }
+
+const char* wbcqp_last_error(const wbcqp_handle* handle) { return handle ? handle->err.c_str() : g_create_error.c_str(); }
+
+int wbcqp_layout_of(const wbcqp_structure* st, wbcqp_layout* out)
+{
+    DevStruct D;
+    wbcqp_layout L;
+    std::string why;
+    int rc = derive(st, D, L, why);
+    if (rc != WBCQP_OK) return fail(nullptr, rc, why);
+    if (out) *out = L;
+    return WBCQP_OK;
+}
+
+int wbcqp_create(const wbcqp_desc* desc, wbcqp_handle** out)
+{
+    if (!desc || !out) return fail(nullptr, WBCQP_ERR_INVALID, "desc/out is NULL");
+    if (desc->dtype != WBCQP_F64 && desc->dtype != WBCQP_F32) return fail(nullptr, WBCQP_ERR_INVALID, "unknown dtype");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, WBCQP_ERR_NO_DEVICE, "no HIP device visible: wbcqp has no CPU fallback");
+    if (desc->device < 0 || desc->device >= count) return fail(nullptr, WBCQP_ERR_INVALID, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, desc->device);
+    if (e != hipSuccess) return fail(nullptr, WBCQP_ERR_HIP, hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, WBCQP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    e = hipSetDevice(desc->device);
+    if (e != hipSuccess) return fail(nullptr, WBCQP_ERR_HIP, hipGetErrorString(e));
+    wbcqp_handle* h = new wbcqp_handle();
+    h->device = desc->device;
+    h->dtype = desc->dtype;
+    *out = h;
+    return WBCQP_OK;
+}
+
+int wbcqp_destroy(wbcqp_handle* h)
+{
+    if (!h) return WBCQP_OK;
+    (void)hipSetDevice(h->device);
+    for (auto& s : h->slots) release(s);
+    if (h->stage_in.dev) (void)hipFree(h->stage_in.dev);
+    if (h->stage_out.dev) (void)hipFree(h->stage_out.dev);
+    delete h;
+    return WBCQP_OK;
+}
+
+int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES) return fail(h, WBCQP_ERR_INVALID, "slot out of range");
+    DevStruct D;
+    wbcqp_layout L;
+    std::string why;
+    int rc = derive(st, D, L, why);
+    if (rc != WBCQP_OK) return fail(h, rc, why);
+    HIP_TRY(h, hipSetDevice(h->device));
+    Slot& s = h->slots[slot];
+    release(s);
+    const int nc = D.nc;
+    // F'F and F' of the force-regularisation block, F = diag(w_f) T  (6 x 12)
+    std::vector<double> ftf((size_t)nc * 144 + 1, 0.0), ft((size_t)nc * 72 + 1, 0.0);
+    for (int c = 0; c < nc; ++c) {
+        const double* F = st->forcereg_mat + (size_t)c * 72;
+        for (int a = 0; a < 12; ++a) {
+            for (int b = 0; b < 12; ++b) {
+                double acc = 0.0;
+                for (int q = 0; q < 6; ++q) acc += F[q * 12 + a] * F[q * 12 + b];
+                ftf[(size_t)c * 144 + a * 12 + b] = acc;
+            }
+            for (int q = 0; q < 6; ++q) ft[(size_t)c * 72 + a * 6 + q] = F[q * 12 + a];
+        }
+    }
+#define UP(field, src, count)                                                   \
+    do {                                                                        \
+        int rc_ = upload(h, s, src, (size_t)(count), &D.field);                 \
+        if (rc_ != WBCQP_OK) { release(s); return rc_; }                        \
+    } while (0)
+    UP(dense_row_task, st->dense_row_task, D.n_dense);
+    UP(sel_col, st->sel_col, D.n_sel);
+    UP(sel_task, st->sel_task, D.n_sel);
+    UP(forcereg_task, st->forcereg_task, nc);
+    UP(bound_col, st->bound_col, D.n_bound);
+    UP(force_gen, st->force_gen, nc * 72);
+    UP(ftf, ftf.data(), nc * 144);
+    UP(ft, ft.data(), nc * 72);
+    UP(fric_mat, st->fric_mat, nc * 17 * 12);
+    UP(fric_lb, st->fric_lb, nc * 17);
+    UP(fric_ub, st->fric_ub, nc * 17);
+#undef UP
+    void* dv = nullptr;
+    HIP_TRY(h, hipMalloc(&dv, sizeof(DevStruct)));
+    s.dev = static_cast<DevStruct*>(dv);
+    HIP_TRY(h, hipMemcpy(s.dev, &D, sizeof(DevStruct), hipMemcpyHostToDevice));
+    s.host = D;
+    s.layout = L;
+    s.set = true;
+    return WBCQP_OK;
+}
+
+int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (n_groups < 0 || n_groups > kMaxGroups) return fail(h, WBCQP_ERR_INVALID, "n_groups must be in [0, 8]");
+    if (n_groups > 0 && !groups) return fail(h, WBCQP_ERR_INVALID, "groups is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int total = 0, lds = 0, used = 0;
+    GroupTable<double> t64{};
+    GroupTable<float> t32{};
+    for (int g = 0; g < n_groups; ++g) {
+        const wbcqp_group& G = groups[g];
+        if (G.slot < 0 || G.slot >= WBCQP_MAX_STRUCTURES || !h->slots[G.slot].set)
+            return fail(h, WBCQP_ERR_INVALID, "group uses a slot with no structure");
+        const Slot& s = h->slots[G.slot];
+        int rc = check_io(h, s, G.batch, &G.in, &G.out);
+        if (rc != WBCQP_OK) return rc;
+        if (G.batch == 0) continue;
+        if (h->dtype == WBCQP_F64) fill_group(t64.g[used], s, G.batch, &G.in, &G.out);
+        else fill_group(t32.g[used], s, G.batch, &G.in, &G.out);
+        ++used;
+        total += G.batch;
+        if (s.layout.lds_bytes > lds) lds = s.layout.lds_bytes;
+    }
+    t64.n = used;
+    t32.n = used;
+    if (h->dtype == WBCQP_F64) return launch(h, t64, total, lds, static_cast<hipStream_t>(stream));
+    return launch(h, t32, total, lds, static_cast<hipStream_t>(stream));
+}
+
+int wbcqp_solve_batch(wbcqp_handle* h, int slot, int batch, const wbcqp_inputs* in, const wbcqp_outputs* out, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (batch == 0) return WBCQP_OK;
+    if (!in || !out) return fail(h, WBCQP_ERR_INVALID, "inputs/outputs struct is NULL");
+    wbcqp_group G;
+    G.slot = slot;
+    G.batch = batch;
+    G.in = *in;
+    G.out = *out;
+    return wbcqp_solve_ragged(h, 1, &G, stream);
+}
+
+int wbcqp_solve_batch_host(wbcqp_handle* h, int slot, int batch, const wbcqp_inputs* in, const wbcqp_outputs* out)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES || !h->slots[slot].set) return fail(h, WBCQP_ERR_INVALID, "slot has no structure");
+    const Slot& s = h->slots[slot];
+    int rc = check_io(h, s, batch, in, out);
+    if (rc != WBCQP_OK || batch == 0) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const wbcqp_layout& L = s.layout;
+    const size_t es = (h->dtype == WBCQP_F64) ? 8 : 4;
+    const int lens[11] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub, L.len_tlb, L.len_tub, L.len_w};
+    const void* src[11] = {in->M, in->h, in->A, in->b1, in->Ac, in->bc, in->blb, in->bub, in->tlb, in->tub, in->w};
+    size_t in_bytes = 0;
+    size_t offs[11];
+    for (int f = 0; f < 11; ++f) {
+        offs[f] = in_bytes;
+        in_bytes += (((size_t)lens[f] * batch * es) + 255) & ~(size_t)255;
+    }
+    rc = ensure(h, h->stage_in, in_bytes + 256);
+    if (rc != WBCQP_OK) return rc;
+    const size_t o_x = 0;
+    const size_t o_tau = (o_x + (size_t)L.n * batch * es + 255) & ~(size_t)255;
+    const size_t o_obj = (o_tau + (size_t)s.host.na * batch * es + 255) & ~(size_t)255;
+    const size_t o_st = (o_obj + (size_t)batch * es + 255) & ~(size_t)255;
+    const size_t o_it = o_st + (((size_t)batch * 4 + 255) & ~(size_t)255);
+    const size_t o_na = o_it + (((size_t)batch * 4 + 255) & ~(size_t)255);
+    const size_t out_bytes = o_na + (size_t)batch * 4 + 256;
+    rc = ensure(h, h->stage_out, out_bytes);
+    if (rc != WBCQP_OK) return rc;
+    char* din = static_cast<char*>(h->stage_in.dev);
+    char* dout = static_cast<char*>(h->stage_out.dev);
+    for (int f = 0; f < 11; ++f)
+        if (lens[f] > 0) HIP_TRY(h, hipMemcpyAsync(din + offs[f], src[f], (size_t)lens[f] * batch * es, hipMemcpyHostToDevice, nullptr));
+    wbcqp_inputs di = {din + offs[0], din + offs[1], din + offs[2], din + offs[3], din + offs[4], din + offs[5],
+                       din + offs[6], din + offs[7], din + offs[8], din + offs[9], din + offs[10]};
+    wbcqp_outputs dso;
+    dso.x = dout + o_x; dso.tau = dout + o_tau; dso.objective = dout + o_obj;
+    dso.status = reinterpret_cast<int32_t*>(dout + o_st); dso.iters = reinterpret_cast<int32_t*>(dout + o_it);
+    dso.n_active = reinterpret_cast<int32_t*>(dout + o_na);
+    rc = wbcqp_solve_batch(h, slot, batch, &di, &dso, nullptr);
+    if (rc != WBCQP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out->x, dso.x, (size_t)L.n * batch * es, hipMemcpyDeviceToHost, nullptr));
+    if (s.host.na > 0) HIP_TRY(h, hipMemcpyAsync(out->tau, dso.tau, (size_t)s.host.na * batch * es, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(h, hipMemcpyAsync(out->status, dso.status, (size_t)batch * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(h, hipMemcpyAsync(out->iters, dso.iters, (size_t)batch * 4, hipMemcpyDeviceToHost, nullptr));
+    if (out->objective) HIP_TRY(h, hipMemcpyAsync(out->objective, dso.objective, (size_t)batch * es, hipMemcpyDeviceToHost, nullptr));
+    if (out->n_active) HIP_TRY(h, hipMemcpyAsync(out->n_active, dso.n_active, (size_t)batch * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(h, hipStreamSynchronize(nullptr));
+    return WBCQP_OK;
+}
+
+// RCCL is resolved at run time from whatever librccl the process already has (PyTorch's, or the
+// system one): the library itself carries no link-time dependency on it.
+int wbcqp_allgather_tau(wbcqp_handle* h, void* comm, const void* send, void* recv, size_t count, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (!comm || !send || !recv) return fail(h, WBCQP_ERR_INVALID, "comm/send/recv is NULL");
+    typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, void*);
+    static allgather_fn fn = nullptr;
+    if (!fn) {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+        if (!sym) {
+            void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (lib) sym = dlsym(lib, "ncclAllGather");
+        }
+        if (!sym) return fail(h, WBCQP_ERR_RCCL, "ncclAllGather not found (librccl not loadable)");
+        fn = reinterpret_cast<allgather_fn>(sym);
+    }
+    const int nccl_dtype = (h->dtype == WBCQP_F64) ? 8 /* ncclFloat64 */ : 7 /* ncclFloat32 */;
+    int rc = fn(send, recv, count, nccl_dtype, comm, stream);
+    if (rc != 0) return fail(h, WBCQP_ERR_RCCL, "ncclAllGather failed with code " + std::to_string(rc));
+    return WBCQP_OK;
+}
+
+int wbcqp_sync(wbcqp_handle* h, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return WBCQP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,161 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+These read like the reference's own loop tests (tests/test_determinism.cpp:24-57: run, compare every
+value with a tolerance), with the oracle standing where a second run of the reference would.
+"""
+import numpy as np
+import pytest
+
+from inria_wbc_amd import structure, synth
+from tests.util import TOL_F64, assert_parity, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def handle(built_lib):
+    import torch  # noqa: F401  (share one HIP runtime with torch when both are in the process)
+    from inria_wbc_amd import capi
+    h = capi.Handle(device=0, dtype=capi.F64)
+    yield h
+    h.close()
+
+
+@pytest.mark.parametrize("case", load_golden(), ids=lambda c: c[0])
+def test_golden_fixtures(handle, case):
+    fname, st, inputs, z = case
+    handle.set_structure(0, st)
+    got = handle.solve_batch_host(0, inputs)
+    ref = dict(x=z["x"], tau=z["tau"], status=z["status"], iters=z["iters"])
+    info = assert_parity(st, got, ref, what=fname)
+    assert info["iters_equal"] >= 0.8, (fname, got["iters"], ref["iters"])
+
+
+@pytest.mark.parametrize("name,batch,noise", [
+    ("franka", 64, 0.5), ("tiago", 64, 2.0), ("icub", 48, 0.5), ("icub", 32, 5.0),
+    ("talos", 64, 0.5), ("talos", 32, 5.0), ("talos_single_support", 32, 2.0)])
+def test_parity_vs_oracle(handle, oracle_mod, name, batch, noise):
+    st = structure.STRUCTURES[name]()
+    inputs = synth.generate(st, batch, synth.SEED_BASE[name] + 100, task_noise=noise)
+    ref = oracle_mod.tick_batch(st, inputs, nthreads=4)
+    handle.set_structure(1, st)
+    got = handle.solve_batch_host(1, inputs)
+    info = assert_parity(st, got, ref, what=name)
+    assert info["iters_equal"] >= 0.85, (name, got["iters"], ref["iters"])
+
+
+def test_determinism_and_batch_permutation(handle):
+    """Spirit of tests/test_determinism.cpp:44-57,118-138: repeated runs and a re-ordered input give
+    the same per-instance result -- here bit for bit."""
+    st = structure.talos_structure()
+    inputs = synth.generate(st, 48, synth.SEED_BASE["talos"] + 5000, task_noise=2.0)
+    handle.set_structure(2, st)
+    a = handle.solve_batch_host(2, inputs)
+    b = handle.solve_batch_host(2, inputs)
+    for k in ("x", "tau", "status", "iters"):
+        assert np.array_equal(a[k], b[k]), k
+    perm = np.random.default_rng(0).permutation(48)
+    c = handle.solve_batch_host(2, {k: v[perm] for k, v in inputs.items()})
+    for k in ("x", "tau", "status", "iters"):
+        assert np.array_equal(a[k][perm], c[k]), k
+
+
+def test_infeasible_and_redundant_status(handle, oracle_mod):
+    """Failure statuses the reference turns into exceptions (controller.cpp:284-307)."""
+    st = structure.talos_structure()
+    inputs = synth.generate(st, 4, synth.SEED_BASE["talos"] + 7000)
+    # QP 1: contradictory acceleration bounds -> infeasible (status 1)
+    inputs["blb"][1, 3] = 5.0
+    inputs["bub"][1, 3] = -5.0
+    # QP 2: two identical contact Jacobians -> redundant equalities (status 4)
+    inputs["Ac"][2] = np.tile(inputs["Ac"][2].reshape(2, -1)[0], 2)
+    ref = oracle_mod.tick_batch(st, inputs)
+    assert ref["status"][1] == 1 and ref["status"][2] == 4 and ref["status"][0] == 0
+    handle.set_structure(3, st)
+    got = handle.solve_batch_host(3, inputs)
+    assert np.array_equal(got["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert np.abs(got["x"][ok] - ref["x"][ok]).max() <= TOL_F64 * max(1.0, np.abs(ref["x"][ok]).max())
+
+
+def test_f32_boundary(built_lib, oracle_mod):
+    """BASELINE config 3 (iCub, fp32 at the boundary): inputs rounded to f32, solve in f64, outputs f32.
+    Parity bar: 1e-3 relative on ddq / tau against the fp64 oracle fed the same f32-rounded inputs."""
+    from inria_wbc_amd import capi
+    st = structure.icub_structure()
+    inputs = synth.generate(st, 64, synth.SEED_BASE["icub"] + 300, dtype=np.float32)
+    ref = oracle_mod.tick_batch(st, {k: v.astype(np.float64) for k, v in inputs.items()}, nthreads=4)
+    h = capi.Handle(device=0, dtype=capi.F32)
+    try:
+        h.set_structure(0, st)
+        got = h.solve_batch_host(0, inputs)
+    finally:
+        h.close()
+    assert got["x"].dtype == np.float32
+    assert np.array_equal(got["status"], ref["status"])
+    nv = st.nv
+    sx = np.maximum(1.0, np.abs(ref["x"][:, :nv]).max(axis=1, keepdims=True))
+    assert (np.abs(got["x"][:, :nv] - ref["x"][:, :nv]) / sx).max() <= 1e-3
+    stau = np.maximum(1.0, np.abs(ref["tau"]).max(axis=1, keepdims=True))
+    assert (np.abs(got["tau"] - ref["tau"]) / stau).max() <= 1e-3
+
+
+def test_device_pointer_path_and_ragged(handle, oracle_mod):
+    """Device-resident arrays + a mixed Franka/Tiago/iCub/Talos launch (BASELINE config 5)."""
+    import torch
+    names = ["franka", "tiago", "icub", "talos", "talos_single_support"]
+    rng = np.random.default_rng(5)
+    groups, refs, keep = [], [], []
+    for slot, name in enumerate(names):
+        st = structure.STRUCTURES[name]()
+        batch = int(rng.integers(5, 24))
+        inputs = synth.generate(st, batch, synth.SEED_BASE["ragged"] + 1000 * slot, task_noise=1.0)
+        refs.append((st, oracle_mod.tick_batch(st, inputs)))
+        handle.set_structure(8 + slot, st)
+        dev_in = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in inputs.items() if v.size}
+        dev_out = dict(x=torch.zeros(batch, st.n, dtype=torch.float64, device="cuda"),
+                       tau=torch.zeros(batch, max(st.na, 1), dtype=torch.float64, device="cuda"),
+                       status=torch.full((batch,), -99, dtype=torch.int32, device="cuda"),
+                       iters=torch.zeros(batch, dtype=torch.int32, device="cuda"))
+        keep.append((dev_in, dev_out))
+        groups.append((8 + slot, batch, dev_in, dev_out))
+    stream = torch.cuda.current_stream().cuda_stream
+    handle.solve_ragged(groups, stream=stream)
+    torch.cuda.synchronize()
+    for (st, ref), (_, _, _, dev_out) in zip(refs, groups):
+        got = dict(x=dev_out["x"].cpu().numpy(), tau=dev_out["tau"].cpu().numpy()[:, :st.na],
+                   status=dev_out["status"].cpu().numpy(), iters=dev_out["iters"].cpu().numpy())
+        assert_parity(st, got, ref, what="ragged:" + st.name)
+
+
+def test_full_size_properties(handle, oracle_mod):
+    """BASELINE config 2 at full size (Talos, B = 1024): every QP optimal; size-independent properties:
+    equality residuals, inequality feasibility within the solver's own psi tolerance, tau consistent with
+    x through the decode formula, and a 32-QP sample against the oracle."""
+    st = structure.talos_structure()
+    B = 1024
+    inputs = synth.generate(st, B, synth.SEED_BASE["talos"])
+    handle.set_structure(4, st)
+    got = handle.solve_batch_host(4, inputs)
+    assert (got["status"] == 0).all()
+    nv, nu, na = st.nv, st.nu, st.na
+    T = st.force_gen()
+    iu = np.tril_indices(nv)
+    worst_eq = 0.0
+    worst_tau = 0.0
+    for i in range(0, B, 16):
+        M = np.zeros((nv, nv)); M[iu] = inputs["M"][i]; M = M + M.T - np.diag(np.diag(M))
+        Ac = inputs["Ac"][i].reshape(st.nc, 6, nv)
+        Jc = np.concatenate([T[c].T @ Ac[c] for c in range(st.nc)], 0)
+        x = got["x"][i]; dv, f = x[:nv], x[nv:]
+        h = inputs["h"][i]
+        worst_eq = max(worst_eq, np.abs(M[:nu] @ dv - Jc[:, :nu].T @ f + h[:nu]).max())
+        worst_eq = max(worst_eq, np.abs(np.einsum("crj,j->cr", Ac, dv).ravel() - inputs["bc"][i]).max())
+        tau = M[nu:] @ dv + h[nu:] - Jc[:, nu:].T @ f
+        worst_tau = max(worst_tau, np.abs(tau - got["tau"][i]).max())
+        # bounds hold up to the solver's own stopping rule: sum of violations <= nIneq*eps*tr(H)*tr(J)*100 (GI step 1)
+        assert (tau >= inputs["tlb"][i] - 1.0).all() and (tau <= inputs["tub"][i] + 1.0).all()
+    assert worst_eq < 1e-6 and worst_tau < 1e-9, (worst_eq, worst_tau)
+    sub = {k: v[:32] for k, v in inputs.items()}
+    ref = oracle_mod.tick_batch(st, sub, nthreads=4)
+    assert_parity(st, {k: v[:32] for k, v in got.items()}, ref, what="talos-1024-sample")
