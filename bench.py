@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- QP solves/sec of the batched whole-body-QP tick on MI355X.
+
+One "step" = one pass of the hot path (assemble H,g -> GI active-set solve -> torque decode, i.e.
+controller.cpp:244-251 of the reference for every instance) over one batch of synthetic Talos QPs
+that is already resident in HBM.  Default workload = BASELINE.json configs[1]:
+Talos pos-tracker, batch 1024, fp64, one wavefront per QP, 1 x MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: the batch shards embarrassingly -- every rank owns `--batch` QPs of the same seeded stream
+(weak scaling), no collective on the solve path; the optional exchange step of BASELINE config 4
+(all-gather of joint torques over RCCL/xGMI) runs after the solve inside the timed step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# compact-boundary bytes per Talos fp64 QP (inputs 34 200 B + outputs 952 B)
+ALGORITHMIC_BYTES = {"talos": 35152, "icub": 23872, "franka": 1152}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=1024, help="QPs per GPU per step")
+    p.add_argument("--robot", default="talos", choices=["talos", "icub", "franka"])
+    p.add_argument("--squat", action="store_true", help="CoM reference follows etc/talos/squat.yaml (BASELINE config 4)")
+    p.add_argument("--no-allgather", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
+    p.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch from rocprofv3 PMC passes")
+    p.add_argument("--sweep", default=None, help="also time batch 1..8192 and write the table to this JSON file")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from inria_wbc_amd import build, capi, structure, synth
+    if rank == 0:
+        build.build()
+    if distributed:
+        dist.barrier()
+
+    st = structure.STRUCTURES[args.robot]()
+    B = args.batch
+    seed_key = "talos_squat" if (args.squat and args.robot == "talos") else args.robot
+    # rank r owns QPs [r*B, (r+1)*B) of the stream
+    inputs = synth.generate(st, B, synth.SEED_BASE[seed_key], first=rank * B, squat=args.squat)
+    dev = torch.device("cuda", local_rank)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
+    d_out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev),
+                 tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
+                 status=torch.full((B,), -99, dtype=torch.int32, device=dev),
+                 iters=torch.zeros(B, dtype=torch.int32, device=dev))
+    tau_all = torch.zeros(world * B, max(st.na, 1), dtype=torch.float64, device=dev) if distributed else None
+
+    h = capi.Handle(device=local_rank, dtype=capi.F64)
+    h.set_structure(0, st)
+    layout = capi.layout_of(st)
+    do_gather = distributed and not args.no_allgather
+    gather_state = {"ok": do_gather, "err": None}
+
+    def step():
+        h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+        if gather_state["ok"]:
+            try:
+                dist.all_gather_into_tensor(tau_all, d_out["tau"])
+            except Exception as e:  # keep the scaling run alive; the exchange step is optional
+                gather_state["ok"] = False
+                gather_state["err"] = repr(e)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+        ev[i][1].record()
+        if gather_state["ok"]:
+            dist.all_gather_into_tensor(tau_all, d_out["tau"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg_s = float(np.mean(kernel_ms)) * 1e-3
+
+    status = d_out["status"].cpu().numpy()
+    iters = d_out["iters"].cpu().numpy()
+    x_gpu = d_out["x"].cpu().numpy()
+    tau_gpu = d_out["tau"].cpu().numpy()[:, :st.na]
+
+    result = None
+    if rank == 0:
+        total_qps = world * B * args.steps
+        value = total_qps / elapsed
+        abytes = ALGORITHMIC_BYTES.get(args.robot, st.algorithmic_bytes())
+        achieved = abytes * B / kern_avg_s / 1e9
+        result = {
+            "metric": "QP solves/sec (Talos ~50-var WBC tick)" if args.robot == "talos" else "QP solves/sec (%s)" % args.robot,
+            "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s_pos_tracker%s_b%d_fp64_one_wave_per_qp" % (args.robot, "_squat" if args.squat else "", B),
+                       "batch_per_gpu": B, "n": st.n, "neq": st.neq, "nin": st.nin, "level1_rows": st.r1,
+                       "parallelism": "batch-shard x%d" % world,
+                       "allgather_tau": bool(gather_state["ok"]), "lds_bytes_per_qp": layout["lds_bytes"],
+                       "qps_resident_per_cu": layout["waves_per_cu"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic,
+                         "kernel": "wbcqp::solve_kernel<double>", "kernel_ms": kern_avg_s * 1e3,
+                         "algorithmic_bytes_per_qp": abytes},
+            "active_set": {"iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
+                           "iters_hist": np.bincount(np.minimum(iters, 15), minlength=16).tolist(),
+                           "status_optimal": int((status == 0).sum()), "batch": int(B)},
+        }
+        if gather_state["err"]:
+            result["config"]["allgather_error"] = gather_state["err"]
+
+        if not args.no_cpu_baseline and world == 1:
+            # the oracle is the checker here and the reported CPU baseline -- never the thing shipped
+            from oracle import oracle
+            oracle.build()
+            cores = os.cpu_count() or 1
+            nsamp = min(B, 256)
+            sub = {k: v[:nsamp] for k, v in inputs.items()}
+            t1 = time.perf_counter()
+            ref = oracle.tick_batch(st, sub, nthreads=1)
+            single = nsamp / (time.perf_counter() - t1)
+            # all-core run, repeated until the sample is ~cpu_seconds of CPU wall time (bounded)
+            reps, done, tcpu = 0, 0, 0.0
+            budget = max(1.0, args.cpu_seconds - nsamp / single)
+            while tcpu < budget and reps < 64:
+                t1 = time.perf_counter()
+                oracle.tick_batch(st, inputs, nthreads=cores)
+                tcpu += time.perf_counter() - t1
+                done += B
+                reps += 1
+            multi = done / tcpu
+            ok = ref["status"] == 0
+            xs = np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
+            result["cpu_baseline"] = {
+                "value": multi, "unit": "QP/s", "cores": cores, "kind": "port",
+                "sample": "%d x %d Talos QPs of the same batch, %d pthreads; single-thread %.0f QP/s on %d QPs" % (reps, B, cores, single, nsamp)
+                          if args.robot == "talos" else "%d x %d QPs, %d pthreads" % (reps, B, cores),
+                "single_thread": single,
+            }
+            result["parity"] = {
+                "sample": nsamp,
+                "max_rel_dx": float((np.abs(x_gpu[:nsamp] - ref["x"]).max(axis=1) / xs)[ok].max()),
+                "max_abs_dtau": float(np.abs(tau_gpu[:nsamp] - ref["tau"])[ok].max()) if st.na else 0.0,
+                "status_equal": bool(np.array_equal(status[:nsamp], ref["status"])),
+                "iters_equal_frac": float((iters[:nsamp] == ref["iters"]).mean()),
+            }
+
+        if args.sweep and world == 1:
+            table = []
+            for b in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
+                si = synth.generate(st, min(b, 1024), synth.SEED_BASE[seed_key])
+                reps_in = (b + 1023) // 1024
+                di = {k: torch.from_numpy(np.ascontiguousarray(np.tile(v, (reps_in, 1))[:b])).to(dev) for k, v in si.items() if v.size}
+                do = dict(x=torch.zeros(b, st.n, dtype=torch.float64, device=dev),
+                          tau=torch.zeros(b, max(st.na, 1), dtype=torch.float64, device=dev),
+                          status=torch.zeros(b, dtype=torch.int32, device=dev), iters=torch.zeros(b, dtype=torch.int32, device=dev))
+                for _ in range(2):
+                    h.solve_batch(0, b, di, do, stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                nrep = 10
+                for _ in range(nrep):
+                    h.solve_batch(0, b, di, do, stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / nrep
+                table.append({"batch": b, "ms": dt * 1e3, "qps": b / dt})
+            os.makedirs(os.path.dirname(os.path.abspath(args.sweep)), exist_ok=True)
+            with open(args.sweep, "w") as fh:
+                json.dump(table, fh, indent=1)
+        print(json.dumps(result), flush=True)
+
+    h.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
