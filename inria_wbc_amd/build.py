@@ -34,6 +34,18 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_stamps(verbose: bool = False) -> str:
+    """Diagnostic library with in-kernel phase stamps (never the one tests or bench load)."""
+    out = os.path.join(LIBDIR, "libwbcqp_stamps.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-ffp-contract=on",
+           "-DWBCQP_STAMPS", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out, "-ldl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     if not force and not needs_build():
         return LIB
@@ -51,3 +63,5 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--stamps" in sys.argv:
+        print(build_stamps(verbose=True))

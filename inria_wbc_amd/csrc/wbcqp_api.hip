@@ -44,6 +44,7 @@ struct wbcqp_handle {
     Slot slots[WBCQP_MAX_STRUCTURES];
     Staging stage_in, stage_out;
     int max_lds = 0;
+    long long* dbg = nullptr; // diagnostic builds only (wbcqp_debug_set_stamp_buffer)
 };
 
 namespace {
@@ -183,6 +184,7 @@ void fill_group(GroupArgs<TI>& g, const Slot& s, int batch, const wbcqp_inputs* 
     g.tlb = static_cast<const TI*>(in->tlb); g.tub = static_cast<const TI*>(in->tub); g.w = static_cast<const TI*>(in->w);
     g.x = static_cast<TI*>(out->x); g.tau = static_cast<TI*>(out->tau); g.objective = static_cast<TI*>(out->objective);
     g.status = out->status; g.iters = out->iters; g.n_active = out->n_active;
+    g.dbg = nullptr;
     g.count = batch;
 }
 
@@ -354,8 +356,8 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
         int rc = check_io(h, s, G.batch, &G.in, &G.out);
         if (rc != WBCQP_OK) return rc;
         if (G.batch == 0) continue;
-        if (h->dtype == WBCQP_F64) fill_group(t64.g[used], s, G.batch, &G.in, &G.out);
-        else fill_group(t32.g[used], s, G.batch, &G.in, &G.out);
+        if (h->dtype == WBCQP_F64) { fill_group(t64.g[used], s, G.batch, &G.in, &G.out); t64.g[used].dbg = h->dbg; }
+        else { fill_group(t32.g[used], s, G.batch, &G.in, &G.out); t32.g[used].dbg = h->dbg; }
         ++used;
         total += G.batch;
         if (s.layout.lds_bytes > lds) lds = s.layout.lds_bytes;
@@ -452,6 +454,19 @@ int wbcqp_allgather_tau(wbcqp_handle* h, void* comm, const void* send, void* rec
     int rc = fn(send, recv, count, nccl_dtype, comm, stream);
     if (rc != 0) return fail(h, WBCQP_ERR_RCCL, "ncclAllGather failed with code " + std::to_string(rc));
     return WBCQP_OK;
+}
+
+// Diagnostic hook, not part of include/wbcqp.h: per-QP phase cycle counters ([batch][20] int64, device memory)
+// are written only by a library built with -DWBCQP_STAMPS (inria_wbc_amd/build.py --stamps); single group only.
+int wbcqp_debug_set_stamp_buffer(wbcqp_handle* h, void* dev_ptr)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    h->dbg = static_cast<long long*>(dev_ptr);
+#ifdef WBCQP_STAMPS
+    return WBCQP_OK;
+#else
+    return WBCQP_ERR_UNSUPPORTED;
+#endif
 }
 
 int wbcqp_sync(wbcqp_handle* h, void* stream)

@@ -53,6 +53,7 @@ struct GroupArgs {
     const TI *M, *h, *A, *b1, *Ac, *bc, *blb, *bub, *tlb, *tub, *w;
     TI *x, *tau, *objective;
     int *status, *iters, *n_active;
+    long long* dbg; // per-QP phase cycle counters, only written by the WBCQP_STAMPS diagnostic build
     int count;
 };
 
@@ -533,8 +534,15 @@ __device__ __forceinline__ void compute_s(Ctx& c)
     }
 }
 
-template <typename TI>
-__device__ __forceinline__ double ld(const TI* p, size_t i) { return (double)p[i]; }
+// In-kernel phase stamps (diagnostic build only: -DWBCQP_STAMPS). Never compiled into the product library.
+#ifdef WBCQP_STAMPS
+constexpr int kStamps = 20;
+#define STAMP_DECL long long st_prev_ = clock64(); long long st_acc_[kStamps] = {};
+#define STAMP(i) { long long now_ = clock64(); st_acc_[i] += now_ - st_prev_; st_prev_ = now_; }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // the kernel: grid = total QPs, block = 64 threads = one wavefront = one QP
@@ -575,6 +583,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
     const size_t qp = (size_t)b;
     double* As = c.R; // dense task rows are staged in the (not yet used) R region
 
+    STAMP_DECL
     // ---------------- phase 0: one pass over the QP's HBM record ----------------
     for (int e = lane; e < n * ldj; e += kWave) c.J[e] = 0.0;
     {
@@ -639,6 +648,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         }
     }
 
+    STAMP(0)
     // ---------------- phase 1: H = sum_t w_t A_t'A_t (+ selection, force-reg, reg), g ----------------
     // lanes over columns j; four rows of H per pass; per-task partial sums then one scaled add
     // (the order Eigen evaluates H += w * A' * A per task)
@@ -719,6 +729,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
     }
     wsync();
 
+    STAMP(1)
     // ---------------- phase 2: Cholesky H = L L' in place (lower), skyline = block structure ----------------
     // row_start(i): first structurally non-zero column of row i (0 for dv rows, start of the contact block for force rows)
     for (int j = 0; j < n; ++j) {
@@ -743,6 +754,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         wsync();
     }
 
+    STAMP(2)
     // ---------------- phase 2b: J = L^-T. Row i of X = L^-1 is built from rows < i; X' is written into the
     // strict upper triangle of the same buffer (X(i,c) -> J[c][i]); the diagonal 1/L(i,i) sits in dinv ----------------
     for (int i = 1; i < n; ++i) {
@@ -782,6 +794,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
     }
     wsync();
 
+    STAMP(3)
     // ---------------- x = -H^-1 g = -J (J' g); f = 0.5 g'x ----------------
     for (int i = lane; i < n; i += kWave) c.np[i] = c.g[i];
     wsync();
@@ -806,6 +819,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
     }
     wsync();
 
+    STAMP(4)
     const double eps = 2.220446049250313e-16;
     const double inf = __builtin_huge_val();
     int status = -2; // running
@@ -819,9 +833,11 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         wsync();
         compute_d(c, k0, k1);
         wsync();
+        STAMP(5)
         update_z(c);
         update_r(c);
         wsync();
+        STAMP(6)
         double zz = 0.0, znp = 0.0, npx = 0.0;
         for (int j = lane; j < n; j += kWave) {
             const double zv = c.z[j];
@@ -845,7 +861,9 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         }
         f_value += 0.5 * (t2 * t2) * znp;
         wsync();
+        STAMP(7)
         if (!add_constraint(c)) status = HQP_ERROR; // redundant equalities
+        STAMP(8)
     }
 
     // ---------------- phase 4: inequality loop (GI steps 1, 2, 2a-2c) ----------------
@@ -879,6 +897,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
             }
             for (int i = lane; i < n; i += kWave) c.xold[i] = c.x[i];
             wsync();
+            STAMP(9)
 
             bool again_l2 = true;
             while (again_l2 && status == -2) {
@@ -903,6 +922,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
                     c.A[c.iq] = ip;
                 }
                 wsync();
+                STAMP(10)
 
                 // l2a
                 while (true) {
@@ -911,9 +931,11 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
                     else
                         compute_d(c, k0, k1);
                     wsync();
+                    STAMP(11)
                     update_z(c);
                     update_r(c);
                     wsync();
+                    STAMP(12)
                     const int iq = c.iq;
                     // step 2b: partial step length t1 (dual feasibility) and full step length t2
                     ValIdx bt{inf, 0x7fffffff};
@@ -947,7 +969,9 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
                             c.iai[l] = l;
                         }
                         wsync();
+                        STAMP(13)
                         delete_constraint(c, l);
+                        STAMP(15)
                         continue;
                     }
                     // (iii) primal + dual step
@@ -958,9 +982,12 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
                     wsync();
                     if (lane == 0) c.u[iq] = uiq + t;
                     wsync();
+                    STAMP(13)
                     if (t == t2) {
                         // full step: add ip to the active set
-                        if (!add_constraint(c)) {
+                        const bool added_ = add_constraint(c);
+                        STAMP(14)
+                        if (!added_) {
                             if (lane == 0) c.iaexcl[ip] = 0;
                             wsync();
                             delete_constraint(c, ip);
@@ -985,6 +1012,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
                     if (lane == 0) c.iai[l] = l;
                     wsync();
                     delete_constraint(c, l);
+                    STAMP(15)
                     double part = 0.0;
                     for (int j = k0 + lane; j < k1; j += kWave) part = fma(c.np[j], c.x[j], part);
                     part = wave_sum(part);
@@ -995,6 +1023,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         }
     }
 
+    STAMP(16)
     // ---------------- phase 5: decode + write-out ----------------
     // tau = h_a + M_a dv - J_a' f   (getActuatorForces)
     TI* xo = ga.x + qp * n;
@@ -1016,6 +1045,11 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         if (ga.objective) ga.objective[qp] = (TI)f_value;
         if (ga.n_active) ga.n_active[qp] = c.iq;
     }
+#ifdef WBCQP_STAMPS
+    STAMP(17)
+    if (lane == 0 && ga.dbg)
+        for (int i = 0; i < kStamps; ++i) ga.dbg[qp * kStamps + i] = st_acc_[i];
+#endif
 }
 
 #endif // __HIPCC__

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Per-phase cycle shares of the solve kernel from the -DWBCQP_STAMPS diagnostic build.
+
+Reads SHARES, not run time: the stamped build forbids overlaps the real kernel has
+(cdna_hip_programming.md section 7, In-kernel stamps). Usage (on the GPU box):
+    python inria_wbc_amd/build.py --stamps && python tools/phase_profile.py [--robot talos] [--batch 256] [--noise 0.5]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+NAMES = ["load", "assemble_Hg", "cholesky", "J=L^-T", "x0", "eq:build+d", "eq:z+r", "eq:step", "eq:add",
+         "in:s+psi+save", "in:argmin+build", "in:d", "in:z+r", "in:steplen+step", "in:add", "in:delete",
+         "loop-exit", "decode+store", "-", "-"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--robot", default="talos")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--noise", type=float, default=0.5)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import torch
+    from inria_wbc_amd import capi, structure, synth
+    capi.LIB_PATH = os.path.join(ROOT, "inria_wbc_amd", "lib", "libwbcqp_stamps.so")
+    lib = capi.load_library(capi.LIB_PATH)
+    st = structure.STRUCTURES[args.robot]()
+    B = args.batch
+    inputs = synth.generate(st, B, synth.SEED_BASE[args.robot], task_noise=args.noise)
+    dev = torch.device("cuda", 0)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
+    d_out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
+                 status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+    dbg = torch.zeros(B, 20, dtype=torch.int64, device=dev)
+    h = capi.Handle(0, capi.F64)
+    h.set_structure(0, st)
+    lib.wbcqp_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
+    rc = lib.wbcqp_debug_set_stamp_buffer(h._h, C.c_void_p(dbg.data_ptr()))
+    assert rc == 0, rc
+    for _ in range(2):
+        h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t = dbg.cpu().numpy().astype(np.float64)
+    iters = d_out["iters"].cpu().numpy()
+    tot = t.sum(axis=1)
+    mean = t.mean(axis=0)
+    print("robot %s batch %d noise %g: mean iters %.2f, mean cycles/QP %.0f (s_memtime ticks @100MHz? see note), max %.0f" %
+          (args.robot, B, args.noise, iters.mean(), tot.mean(), tot.max()))
+    rows = []
+    for i, nm in enumerate(NAMES):
+        if mean[i] > 0:
+            print("  %-18s %12.0f  %5.1f %%" % (nm, mean[i], 100 * mean[i] / mean.sum()))
+            rows.append({"phase": nm, "ticks": float(mean[i]), "share": float(mean[i] / mean.sum())})
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump({"robot": args.robot, "batch": B, "noise": args.noise, "iters_mean": float(iters.mean()),
+                       "ticks_per_qp": float(tot.mean()), "phases": rows}, fh, indent=1)
+    h.close()
+
+
+if __name__ == "__main__":
+    main()
