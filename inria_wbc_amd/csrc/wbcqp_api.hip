@@ -118,7 +118,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; }; // keep 16-byte alignment
     D.o_J = take(n * D.ldj);
     int rsize = n * (n + 3) / 2 + 2;
-    if (D.n_dense * nv > rsize) rsize = D.n_dense * nv;
+    if (D.n_dense * nv + 8 > rsize) rsize = D.n_dense * nv + 8; // + 8: the 8-row H pass may read past the last row
     D.o_R = take(rsize);
     D.o_M = take(nv * D.ldm);
     D.o_Jc = take(D.k * D.ldc);
@@ -130,9 +130,9 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     D.o_blb = take(D.n_bound); D.o_bub = take(D.n_bound);
     D.o_tl = take(D.na); D.o_tu = take(D.na);
     D.o_bc = take(6 * D.nc);
-    D.o_cc = take(n + 2); D.o_ss = take(n + 2); D.o_xny = take(n + 2);
+    D.o_prm = take(4 * (n + 2));
     D.o_rdinv = take(n + 2); D.o_dinv = take(n + 2); D.o_g = take(n);
-    D.o_w = take(D.n_tasks); D.o_b1 = take(D.r1); D.o_q = take(n + 2);
+    D.o_w = take(D.n_tasks); D.o_b1 = take(D.r1); D.o_q = take(n + 2); D.o_wrow = take(D.n_dense);
     D.o_int = o;
     const int n_int = 2 * (n + 2) + 2 * D.nin2 + (n + 2);
     o += (n_int + 1) / 2 + 2;

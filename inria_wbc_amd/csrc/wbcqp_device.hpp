@@ -42,7 +42,7 @@ struct DevStruct {
     // LDS layout: leading dimensions and element offsets (in doubles)
     int ldj, ldm, ldc;
     int o_J, o_R, o_M, o_Jc, o_Ac, o_h, o_x, o_np, o_d, o_z, o_xold, o_r, o_u, o_uold, o_s;
-    int o_blb, o_bub, o_tl, o_tu, o_bc, o_cc, o_ss, o_xny, o_rdinv, o_dinv, o_g, o_w, o_b1, o_q;
+    int o_blb, o_bub, o_tl, o_tu, o_bc, o_prm, o_rdinv, o_dinv, o_g, o_w, o_b1, o_q, o_wrow;
     int o_int; // int area: A[n+2], Aold[n+2], iai[nin2], iaexcl[nin2], gskip[n+2]
     int lds_doubles;
 };
@@ -172,6 +172,48 @@ __device__ __forceinline__ double gi_distance(double a, double b)
     return a1 * sqrt(2.0);
 }
 
+// inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts; identity 0.0)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_shift0(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_prefix_sum(double v)
+{
+    v += dpp_shift0<0x111, 0xf>(v); // row_shr:1
+    v += dpp_shift0<0x112, 0xf>(v); // row_shr:2
+    v += dpp_shift0<0x114, 0xf>(v); // row_shr:4
+    v += dpp_shift0<0x118, 0xf>(v); // row_shr:8
+    v += dpp_shift0<0x142, 0xa>(v); // row_bcast:15 into rows 1,3
+    v += dpp_shift0<0x143, 0xc>(v); // row_bcast:31 into rows 2,3
+    return v;
+}
+
+// loop helpers: body(i) for i in [begin, end), unrolled by U so that the LDS reads of U steps are in flight together
+template <int U, typename F>
+__device__ __forceinline__ void for_up(int begin, int end, F body)
+{
+    int i = begin;
+    for (; i + U <= end; i += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) body(i + u);
+    }
+    for (; i < end; ++i) body(i);
+}
+// body(i) for i = hi, hi-1, ..., lo  (inclusive)
+template <int U, typename F>
+__device__ __forceinline__ void for_down(int hi, int lo, F body)
+{
+    int i = hi;
+    for (; i - U + 1 >= lo; i -= U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) body(i - u);
+    }
+    for (; i >= lo; --i) body(i);
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-wave context: LDS pointers + sizes (all wave-uniform)
 // ------------------------------------------------------------------------------------------------
@@ -180,7 +222,7 @@ struct Ctx {
     int lane;
     int nv, na, nc, k, n, nu, neq, nin2, ldj, ldm, ldc;
     double *J, *R, *M, *Jc, *Ac, *h, *x, *np, *d, *z, *xold, *r, *u, *uold, *s;
-    double *blb, *bub, *tl, *tu, *bc, *cc, *ss, *xny, *rdinv, *dinv, *g, *w, *b1, *q;
+    double *blb, *bub, *tl, *tu, *bc, *prm, *rdinv, *dinv, *g, *w, *b1, *q, *wrow;
     int *A, *Aold, *iai, *iaexcl, *gskip;
     int iq;
     double R_norm;
@@ -190,22 +232,37 @@ struct Ctx {
 __device__ __forceinline__ int roff(int j) { return (j * (j + 3)) >> 1; }
 
 // d = J' np over the support [k0, k1) of np  (eiquadprog compute_d); lanes over columns
+template <bool TWO>
 __device__ __forceinline__ void compute_d(Ctx& c, int k0, int k1)
 {
     const int n = c.n, ldj = c.ldj, lane = c.lane;
     const int c0 = lane, c1 = lane + kWave;
-    const bool has1 = c1 < n;
-    const int c1s = has1 ? c1 : c0;
-    double a0 = 0.0, a1 = 0.0;
-    const double* Jp = c.J + (size_t)k0 * ldj;
+    const bool has1 = TWO && (c1 < n);
     if (c0 < n) {
-        for (int kk = k0; kk < k1; ++kk, Jp += ldj) {
-            double v = c.np[kk];
-            a0 = fma(Jp[c0], v, a0);
-            a1 = fma(Jp[c1s], v, a1);
+        const double* J0 = c.J + c0;
+        const double* J1 = c.J + (has1 ? c1 : c0);
+        const double* np = c.np;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        int kk = k0;
+        for (; kk + 8 <= k1; kk += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const double v0 = np[kk + u], v1 = np[kk + u + 1];
+                a0 = fma(J0[(kk + u) * ldj], v0, a0);
+                b0 = fma(J0[(kk + u + 1) * ldj], v1, b0);
+                if (TWO) {
+                    a1 = fma(J1[(kk + u) * ldj], v0, a1);
+                    b1 = fma(J1[(kk + u + 1) * ldj], v1, b1);
+                }
+            }
         }
-        c.d[c0] = a0;
-        if (has1) c.d[c1] = a1;
+        for (; kk < k1; ++kk) {
+            const double v0 = np[kk];
+            a0 = fma(J0[kk * ldj], v0, a0);
+            if (TWO) a1 = fma(J1[kk * ldj], v0, a1);
+        }
+        c.d[c0] = a0 + b0;
+        if (has1) c.d[c1] = a1 + b1;
     }
 }
 // d = sign * J[row, :]   (np = sign * e_row)
@@ -215,93 +272,171 @@ __device__ __forceinline__ void compute_d_unit(Ctx& c, int row, double sign)
 }
 
 // z = J[:, iq:] d[iq:]  (update_z); lanes over rows
+template <bool TWO>
 __device__ __forceinline__ void update_z(Ctx& c)
 {
     const int n = c.n, ldj = c.ldj, lane = c.lane, iq = c.iq;
     const int k0 = lane, k1 = lane + kWave;
-    const bool has1 = k1 < n;
+    const bool has1 = TWO && (k1 < n);
     if (k0 < n) {
         const double* J0 = c.J + (size_t)k0 * ldj;
         const double* J1 = c.J + (size_t)(has1 ? k1 : k0) * ldj;
-        double a0 = 0.0, a1 = 0.0;
-        for (int cc = iq; cc < n; ++cc) {
-            double v = c.d[cc];
-            a0 = fma(J0[cc], v, a0);
-            a1 = fma(J1[cc], v, a1);
+        const double* d = c.d;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        int cc = iq;
+        for (; cc + 8 <= n; cc += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const double v0 = d[cc + u], v1 = d[cc + u + 1];
+                a0 = fma(J0[cc + u], v0, a0);
+                b0 = fma(J0[cc + u + 1], v1, b0);
+                if (TWO) {
+                    a1 = fma(J1[cc + u], v0, a1);
+                    b1 = fma(J1[cc + u + 1], v1, b1);
+                }
+            }
         }
-        c.z[k0] = a0;
-        if (has1) c.z[k1] = a1;
+        for (; cc < n; ++cc) {
+            const double v0 = d[cc];
+            a0 = fma(J0[cc], v0, a0);
+            if (TWO) a1 = fma(J1[cc], v0, a1);
+        }
+        c.z[k0] = a0 + b0;
+        if (has1) c.z[k1] = a1 + b1;
     }
 }
 
-// r = R[:iq,:iq]^-1 d[:iq]  (update_r): column-oriented back substitution, lanes over rows,
-// the pivot element travels by readlane; rdinv holds 1/R(j,j).
+// r = R[:iq,:iq]^-1 d[:iq]  (update_r): column-oriented back substitution, lanes over rows; the pivot
+// travels by readlane; 1/R(j,j) and the column entries of four steps are fetched ahead of the chain.
+template <bool TWO>
 __device__ __forceinline__ void update_r(Ctx& c)
 {
     const int iq = c.iq, lane = c.lane;
     if (iq == 0) return;
     double v0 = (lane < iq) ? c.d[lane] : 0.0;
-    double v1 = (lane + kWave < iq) ? c.d[lane + kWave] : 0.0;
-    for (int j = iq - 1; j >= 0; --j) {
-        double dj = (j < kWave) ? bcast_lane(v0, j) : bcast_lane(v1, j - kWave);
-        double rj = dj * c.rdinv[j];
-        const double* Rc = c.R + roff(j);
+    double v1 = (TWO && lane + kWave < iq) ? c.d[lane + kWave] : 0.0;
+    auto step = [&](int j, double rd, double ra, double rb) {
+        double dj;
+        if (TWO)
+            dj = (j < kWave) ? bcast_lane(v0, j) : bcast_lane(v1, j - kWave);
+        else
+            dj = bcast_lane(v0, j);
+        const double rj = dj * rd;
         if (lane == (j & (kWave - 1))) c.r[j] = rj;
-        if (lane < j) v0 = fma(-rj, Rc[lane], v0);
-        if (lane + kWave < j) v1 = fma(-rj, Rc[lane + kWave], v1);
+        if (lane < j) v0 = fma(-rj, ra, v0);
+        if (TWO && lane + kWave < j) v1 = fma(-rj, rb, v1);
+    };
+    int j = iq - 1;
+    for (; j >= 3; j -= 4) {
+        double rd[4], ra[4], rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = j - u;
+            const double* Rc = c.R + roff(jj);
+            rd[u] = c.rdinv[jj];
+            ra[u] = Rc[min(lane, jj)];
+            rb[u] = TWO ? Rc[min(lane + kWave, jj)] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) step(j - u, rd[u], ra[u], rb[u]);
+    }
+    for (; j >= 0; --j) {
+        const double* Rc = c.R + roff(j);
+        step(j, c.rdinv[j], Rc[min(lane, j)], TWO ? Rc[min(lane + kWave, j)] : 0.0);
     }
 }
 
 // add_constraint (eiquadprog): Givens sweep that zeroes d[iq+1:], updates J, appends a column to R.
-// The rotation parameters come from suffix sums of d^2 (closed form of the upstream hypot chain);
-// the sweep itself runs lane-per-row with the running element kept in a register.
+// The rotation parameters come from suffix sums of d^2 (closed form of the upstream hypot chain, one DPP
+// scan); the sweep runs lane-per-row with the running element in a register and the loads of 4 steps in flight.
+template <bool TWO>
 __device__ __forceinline__ bool add_constraint(Ctx& c)
 {
     const int n = c.n, ldj = c.ldj, lane = c.lane, iq = c.iq;
-    // suffix sums Q_i = sum_{m>=i} d_m^2, kept in q[]
+    // suffix sums Q_i = sum_{m>=i} d_m^2 : lane l owns element 63-l (and 127-l), so a prefix scan over lanes is a suffix scan over i
+    const int e0 = kWave - 1 - lane, e1 = 2 * kWave - 1 - lane;
+    double q0, q1 = 0.0, hi_total = 0.0;
+    if (TWO) {
+        const double v1 = (e1 < n) ? c.d[e1] : 0.0;
+        q1 = wave_prefix_sum(v1 * v1);
+        hi_total = bcast_lane(q1, kWave - 1);
+    }
+    {
+        const double v0 = (e0 < n) ? c.d[e0] : 0.0;
+        q0 = wave_prefix_sum(v0 * v0) + hi_total;
+    }
     int last_nz = -1;
-    for (int i = lane; i < n; i += kWave) {
-        double acc = 0.0;
-        for (int m = n - 1; m >= i; --m) {
-            double v = c.d[m];
-            acc = fma(v, v, acc);
-        }
-        c.q[i] = acc;
-        if (acc > 0.0) last_nz = max(last_nz, i);
+    if (e0 < n) {
+        c.q[e0] = q0;
+        if (q0 > 0.0) last_nz = e0;
+    }
+    if (TWO && e1 < n) {
+        c.q[e1] = q1;
+        if (q1 > 0.0) last_nz = e1;
     }
     last_nz = wave_max_int(last_nz);
     wsync();
     const int jstart = min(n - 1, last_nz + 1); // steps j > jstart have h == 0 and are skipped upstream
-    if (jstart >= iq + 1) {
+    const bool any = jstart >= iq + 1;
+    if (any) {
         for (int j = iq + 1 + lane; j <= jstart; j += kWave) {
             const int i = j - 1;
-            double hj = sqrt(c.q[i]);
-            double ej = (c.d[j] < 0.0 ? -1.0 : 1.0) * sqrt(c.q[j]);
-            double cc = c.d[i] / hj, ss = ej / hj;
+            const double qi = c.q[i], qj = c.q[j], di = c.d[i], dj = c.d[j];
+            const double rh = 1.0 / sqrt(qi);
+            const double ej = (dj < 0.0 ? -1.0 : 1.0) * sqrt(qj);
+            double cc = di * rh, ss = ej * rh;
             if (cc < 0.0) {
                 cc = -cc;
                 ss = -ss;
             }
-            c.cc[j] = cc;
-            c.ss[j] = ss;
-            c.xny[j] = ss / (1.0 + cc);
+            double* pr = c.prm + 4 * j;
+            pr[0] = cc;
+            pr[1] = ss;
+            pr[2] = ss / (1.0 + cc);
         }
         wsync();
         const int k0 = lane, k1 = lane + kWave;
-        const bool has1 = k1 < n;
+        const bool has1 = TWO && (k1 < n);
         if (k0 < n) {
             double* J0 = c.J + (size_t)k0 * ldj;
             double* J1 = c.J + (size_t)(has1 ? k1 : k0) * ldj;
-            double t2a = J0[jstart], t2b = J1[jstart];
-            for (int j = jstart; j > iq; --j) {
-                const double cc = c.cc[j], ss = c.ss[j], xny = c.xny[j];
-                double t1a = J0[j - 1], t1b = J1[j - 1];
-                double na_ = fma(t2a, ss, t1a * cc);
-                double nb_ = fma(t2b, ss, t1b * cc);
-                J0[j] = fma(xny, t1a + na_, -t2a);
-                if (has1) J1[j] = fma(xny, t1b + nb_, -t2b);
+            const double* prm = c.prm;
+            double t2a = J0[jstart], t2b = TWO ? J1[jstart] : 0.0;
+            int j = jstart;
+            for (; j - 3 > iq; j -= 4) {
+                double t1a[4], t1b[4], pc[4], ps[4], px[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    t1a[u] = J0[j - u - 1];
+                    if (TWO) t1b[u] = J1[j - u - 1];
+                    pc[u] = prm[4 * (j - u)];
+                    ps[u] = prm[4 * (j - u) + 1];
+                    px[u] = prm[4 * (j - u) + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double na_ = fma(t2a, ps[u], t1a[u] * pc[u]);
+                    J0[j - u] = fma(px[u], t1a[u] + na_, -t2a);
+                    t2a = na_;
+                    if (TWO) {
+                        const double nb_ = fma(t2b, ps[u], t1b[u] * pc[u]);
+                        if (has1) J1[j - u] = fma(px[u], t1b[u] + nb_, -t2b);
+                        t2b = nb_;
+                    }
+                }
+            }
+            for (; j > iq; --j) {
+                const double pc = prm[4 * j], ps = prm[4 * j + 1], px = prm[4 * j + 2];
+                const double t1a = J0[j - 1];
+                const double na_ = fma(t2a, ps, t1a * pc);
+                J0[j] = fma(px, t1a + na_, -t2a);
                 t2a = na_;
-                t2b = nb_;
+                if (TWO) {
+                    const double t1b = J1[j - 1];
+                    const double nb_ = fma(t2b, ps, t1b * pc);
+                    if (has1) J1[j] = fma(px, t1b + nb_, -t2b);
+                    t2b = nb_;
+                }
             }
             J0[iq] = t2a;
             if (has1) J1[iq] = t2b;
@@ -309,7 +444,7 @@ __device__ __forceinline__ bool add_constraint(Ctx& c)
     }
     // new column of R = d[0..iq] with d[iq] replaced by the accumulated norm
     double diq;
-    if (jstart >= iq + 1)
+    if (any)
         diq = (c.d[iq] < 0.0 ? -1.0 : 1.0) * sqrt(c.q[iq]);
     else
         diq = c.d[iq];
@@ -329,6 +464,7 @@ __device__ __forceinline__ bool add_constraint(Ctx& c)
 // delete_constraint (eiquadprog): drop active constraint l; the Givens chain that restores R's
 // triangle is sequential (short: only inequality columns move), the matching J update is a
 // lane-per-row sweep like add_constraint's.
+template <bool TWO>
 __device__ __forceinline__ void delete_constraint(Ctx& c, int l)
 {
     const int n = c.n, ldj = c.ldj, lane = c.lane, neq = c.neq;
@@ -371,8 +507,9 @@ __device__ __forceinline__ void delete_constraint(Ctx& c, int l)
             if (lane == 0) c.gskip[j] = 1;
             continue;
         }
-        cc = cc / h;
-        ss = ss / h;
+        const double rh = 1.0 / h;
+        cc = cc * rh;
+        ss = ss * rh;
         double rjj;
         if (cc < 0.0) {
             rjj = -h;
@@ -385,10 +522,12 @@ __device__ __forceinline__ void delete_constraint(Ctx& c, int l)
         if (lane == 0) {
             Rj[j + 1] = 0.0;
             Rj[j] = rjj;
+            c.rdinv[j] = (cc < 0.0 ? -rh : rh) * 1.0;
             c.rdinv[j] = 1.0 / rjj;
-            c.cc[j] = cc;
-            c.ss[j] = ss;
-            c.xny[j] = xny;
+            double* pr = c.prm + 4 * j;
+            pr[0] = cc;
+            pr[1] = ss;
+            pr[2] = xny;
             c.gskip[j] = 0;
         }
         for (int kc = j + 1 + lane; kc < iq; kc += kWave) {
@@ -404,13 +543,14 @@ __device__ __forceinline__ void delete_constraint(Ctx& c, int l)
     // J columns qq..iq: ascending sweep, running element in a register
     {
         const int k0 = lane, k1 = lane + kWave;
-        const bool has1 = k1 < n;
+        const bool has1 = TWO && (k1 < n);
         if (k0 < n) {
             double* J0 = c.J + (size_t)k0 * ldj;
             double* J1 = c.J + (size_t)(has1 ? k1 : k0) * ldj;
-            double t1a = J0[qq], t1b = J1[qq];
+            double t1a = J0[qq], t1b = TWO ? J1[qq] : 0.0;
             for (int j = qq; j < iq; ++j) {
-                double t2a = J0[j + 1], t2b = J1[j + 1];
+                const double t2a = J0[j + 1];
+                const double t2b = TWO ? J1[j + 1] : 0.0;
                 if (c.gskip[j]) {
                     // columns j, j+1 untouched by this step
                     J0[j] = t1a;
@@ -419,13 +559,16 @@ __device__ __forceinline__ void delete_constraint(Ctx& c, int l)
                     t1b = t2b;
                     continue;
                 }
-                const double cc = c.cc[j], ss = c.ss[j], xny = c.xny[j];
-                double na_ = fma(t2a, ss, t1a * cc);
-                double nb_ = fma(t2b, ss, t1b * cc);
+                const double* pr = c.prm + 4 * j;
+                const double cc = pr[0], ss = pr[1], xny = pr[2];
+                const double na_ = fma(t2a, ss, t1a * cc);
                 J0[j] = na_;
-                if (has1) J1[j] = nb_;
                 t1a = fma(xny, na_ + t1a, -t2a);
-                t1b = fma(xny, nb_ + t1b, -t2b);
+                if (TWO) {
+                    const double nb_ = fma(t2b, ss, t1b * cc);
+                    if (has1) J1[j] = nb_;
+                    t1b = fma(xny, nb_ + t1b, -t2b);
+                }
             }
             J0[iq] = t1a;
             if (has1) J1[iq] = t1b;
@@ -455,7 +598,7 @@ __device__ __forceinline__ void build_eq_row(Ctx& c, int i, int& k0, int& k1, do
     }
 }
 
-// Decodes CI row ip: builds np in LDS, returns support, ci0, and for bound rows the column (unit < 0 if not a unit row)
+// Decodes CI row ip: builds np in LDS, returns support, ci0, and for bound rows the column (unit_col < 0 if not a unit row)
 __device__ __forceinline__ void build_ineq_row(Ctx& c, int ip, int& k0, int& k1, double& ci0, int& unit_col, double& unit_sign)
 {
     const DevStruct& S = *c.S;
@@ -513,10 +656,29 @@ __device__ __forceinline__ void compute_s(Ctx& c)
             for (int rr = lane; rr < rows; rr += kWave) {
                 const int row = nu + rr;
                 const double* Mr = c.M + row * c.ldm;
-                double a0 = 0.0, a1 = 0.0;
-                for (int j = 0; j < nv; ++j) a0 = fma(Mr[j], c.x[j], a0);
-                for (int m = 0; m < k; ++m) a1 = fma(c.Jc[m * c.ldc + row], c.x[nv + m], a1);
-                double t = a0 - a1;
+                const double* Jcr = c.Jc + row;
+                const double* x = c.x;
+                const int ldc = c.ldc;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                int j = 0;
+                for (; j + 8 <= nv; j += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        a0 = fma(Mr[j + u], x[j + u], a0);
+                        a1 = fma(Mr[j + u + 1], x[j + u + 1], a1);
+                    }
+                }
+                for (; j < nv; ++j) a0 = fma(Mr[j], x[j], a0);
+                int m = 0;
+                for (; m + 8 <= k; m += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        a2 = fma(Jcr[(m + u) * ldc], x[nv + m + u], a2);
+                        a3 = fma(Jcr[(m + u + 1) * ldc], x[nv + m + u + 1], a3);
+                    }
+                }
+                for (; m < k; ++m) a2 = fma(Jcr[m * ldc], x[nv + m], a2);
+                const double t = (a0 + a1) - (a2 + a3);
                 c.s[off + rr] = t - c.tl[rr];
                 c.s[off + rows + rr] = -t + c.tu[rr];
             }
@@ -526,12 +688,28 @@ __device__ __forceinline__ void compute_s(Ctx& c)
             if (lane < 17) {
                 const double* B = S.fric_mat + ((size_t)ct * 17 + lane) * 12;
                 double a = 0.0;
+#pragma unroll
                 for (int m = 0; m < 12; ++m) a = fma(B[m], c.x[nv + 12 * ct + m], a);
                 c.s[off + lane] = a - S.fric_lb[ct * 17 + lane];
                 c.s[off + 17 + lane] = -a + S.fric_ub[ct * 17 + lane];
             }
         }
     }
+}
+
+// global -> LDS copy with 8 loads in flight per lane
+template <typename TI>
+__device__ __forceinline__ void copy_in(const TI* __restrict__ src, double* dst, int len, int lane)
+{
+    int e = lane;
+    for (; e + 7 * kWave < len; e += 8 * kWave) {
+        TI v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[e + u * kWave];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[e + u * kWave] = (double)v[u];
+    }
+    for (; e < len; e += kWave) dst[e] = (double)src[e];
 }
 
 // In-kernel phase stamps (diagnostic build only: -DWBCQP_STAMPS). Never compiled into the product library.
@@ -545,22 +723,12 @@ constexpr int kStamps = 20;
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// the kernel: grid = total QPs, block = 64 threads = one wavefront = one QP
+// one QP on one wavefront.  TWO = (n > 64): every lane also owns index lane+64
 // ------------------------------------------------------------------------------------------------
-template <typename TI>
-__global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
+template <typename TI, bool TWO>
+__device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStruct& S, const int b, double* lds)
 {
-    extern __shared__ __align__(16) double lds[];
     const int lane = threadIdx.x;
-
-    int b = blockIdx.x, gi = 0;
-    while (gi + 1 < tab.n && b >= tab.g[gi].count) {
-        b -= tab.g[gi].count;
-        ++gi;
-    }
-    const GroupArgs<TI>& ga = tab.g[gi];
-    const DevStruct& S = *ga.st;
-
     Ctx c;
     c.S = &S;
     c.lane = lane;
@@ -570,8 +738,9 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
     c.h = lds + S.o_h; c.x = lds + S.o_x; c.np = lds + S.o_np; c.d = lds + S.o_d; c.z = lds + S.o_z;
     c.xold = lds + S.o_xold; c.r = lds + S.o_r; c.u = lds + S.o_u; c.uold = lds + S.o_uold; c.s = lds + S.o_s;
     c.blb = lds + S.o_blb; c.bub = lds + S.o_bub; c.tl = lds + S.o_tl; c.tu = lds + S.o_tu; c.bc = lds + S.o_bc;
-    c.cc = lds + S.o_cc; c.ss = lds + S.o_ss; c.xny = lds + S.o_xny; c.rdinv = lds + S.o_rdinv;
+    c.prm = lds + S.o_prm; c.rdinv = lds + S.o_rdinv;
     c.dinv = lds + S.o_dinv; c.g = lds + S.o_g; c.w = lds + S.o_w; c.b1 = lds + S.o_b1; c.q = lds + S.o_q;
+    c.wrow = lds + S.o_wrow;
     int* ia = reinterpret_cast<int*>(lds + S.o_int);
     const int n = c.n, nv = c.nv, na = c.na, nc = c.nc, k = c.k, nu = c.nu, neq = c.neq, nin2 = c.nin2;
     const int ldj = c.ldj, ldm = c.ldm, ldc = c.ldc;
@@ -582,55 +751,46 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
     const int n_dense = S.n_dense, n_sel = S.n_sel, n_bound = S.n_bound, r1 = S.r1, n_tasks = S.n_tasks;
     const size_t qp = (size_t)b;
     double* As = c.R; // dense task rows are staged in the (not yet used) R region
+    double* Mst = c.J; // packed M is staged in the J region before H is assembled there
 
     STAMP_DECL
     // ---------------- phase 0: one pass over the QP's HBM record ----------------
-    for (int e = lane; e < n * ldj; e += kWave) c.J[e] = 0.0;
-    {
-        const int lenM = nv * (nv + 1) / 2;
-        const TI* Mp = ga.M + qp * lenM;
-        for (int e = lane; e < lenM; e += kWave) {
-            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while (i * (i + 1) / 2 > e) --i;
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            const int j = e - i * (i + 1) / 2;
-            const double v = (double)Mp[e];
+    const int lenM = nv * (nv + 1) / 2;
+    copy_in(ga.M + qp * lenM, Mst, lenM, lane);
+    copy_in(ga.A + qp * (size_t)(n_dense * nv), As, n_dense * nv, lane);
+    copy_in(ga.h + qp * nv, c.h, nv, lane);
+    copy_in(ga.b1 + qp * r1, c.b1, r1, lane);
+    copy_in(ga.w + qp * n_tasks, c.w, n_tasks, lane);
+    if (nc > 0) {
+        copy_in(ga.Ac + qp * (size_t)(nc * 6 * nv), c.Ac, nc * 6 * nv, lane);
+        copy_in(ga.bc + qp * (nc * 6), c.bc, nc * 6, lane);
+    }
+    if (n_bound > 0) {
+        copy_in(ga.blb + qp * n_bound, c.blb, n_bound, lane);
+        copy_in(ga.bub + qp * n_bound, c.bub, n_bound, lane);
+    }
+    if (S.act_bounds) {
+        copy_in(ga.tlb + qp * na, c.tl, na, lane);
+        copy_in(ga.tub + qp * na, c.tu, na, lane);
+    }
+    wsync();
+    // expand packed M into the full symmetric matrix; lb - h_a, ub - h_a (computeProblemData, actuation tasks)
+    for (int i = 0; i < nv; ++i) {
+        const int base = i * (i + 1) / 2;
+        for (int j = lane; j <= i; j += kWave) {
+            const double v = Mst[base + j];
             c.M[i * ldm + j] = v;
             c.M[j * ldm + i] = v;
         }
-        const TI* hp = ga.h + qp * nv;
-        for (int j = lane; j < nv; j += kWave) c.h[j] = (double)hp[j];
-        const TI* Ap = ga.A + qp * (size_t)(n_dense * nv);
-        for (int e = lane; e < n_dense * nv; e += kWave) As[e] = (double)Ap[e];
-        const TI* bp = ga.b1 + qp * r1;
-        for (int e = lane; e < r1; e += kWave) c.b1[e] = (double)bp[e];
-        const TI* wp = ga.w + qp * n_tasks;
-        for (int e = lane; e < n_tasks; e += kWave) c.w[e] = (double)wp[e];
-        if (nc > 0) {
-            const TI* Acp = ga.Ac + qp * (size_t)(nc * 6 * nv);
-            for (int e = lane; e < nc * 6 * nv; e += kWave) c.Ac[e] = (double)Acp[e];
-            const TI* bcp = ga.bc + qp * (nc * 6);
-            for (int e = lane; e < nc * 6; e += kWave) c.bc[e] = (double)bcp[e];
-        }
-        if (n_bound > 0) {
-            const TI* lp = ga.blb + qp * n_bound;
-            const TI* up = ga.bub + qp * n_bound;
-            for (int e = lane; e < n_bound; e += kWave) {
-                c.blb[e] = (double)lp[e];
-                c.bub[e] = (double)up[e];
-            }
-        }
     }
-    wsync();
     if (S.act_bounds) {
-        // lb - h_a, ub - h_a (computeProblemData, actuation tasks)
-        const TI* lp = ga.tlb + qp * na;
-        const TI* up = ga.tub + qp * na;
         for (int e = lane; e < na; e += kWave) {
-            c.tl[e] = (double)lp[e] - c.h[nu + e];
-            c.tu[e] = (double)up[e] - c.h[nu + e];
+            const double ha = c.h[nu + e];
+            c.tl[e] -= ha;
+            c.tu[e] -= ha;
         }
     }
+    for (int r = lane; r < n_dense; r += kWave) c.wrow[r] = c.w[S.dense_row_task[r]];
     // Jc = T' A_c  (12 x nv per contact)
     for (int ct = 0; ct < nc; ++ct) {
         const double* T = S.force_gen + ct * 72;
@@ -639,6 +799,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
             double a[6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) a[r] = Acc[r * nv + j];
+#pragma unroll
             for (int m = 0; m < 12; ++m) {
                 double sacc = 0.0;
 #pragma unroll
@@ -647,49 +808,35 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
             }
         }
     }
-
+    wsync();
+    for (int e = lane; e < n * ldj; e += kWave) c.J[e] = 0.0;
+    wsync();
     STAMP(0)
-    // ---------------- phase 1: H = sum_t w_t A_t'A_t (+ selection, force-reg, reg), g ----------------
-    // lanes over columns j; four rows of H per pass; per-task partial sums then one scaled add
-    // (the order Eigen evaluates H += w * A' * A per task)
+
+    // ---------------- phase 1: H = sum_r w_r a_r a_r' (+ selection, force-reg, reg), g ----------------
+    // lanes over columns j, eight rows of H per pass; the lane's own operand carries the row weight
     for (int j = lane; j < nv; j += kWave) {
-        for (int ib = 0; ib < nv; ib += 4) {
-            double acc[4] = {0.0, 0.0, 0.0, 0.0}, ta[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int r = 0; r < n_dense; ++r) {
-                const double* Ar = As + r * nv;
-                const double aj = Ar[j];
+        const double* Aj = As + j;
+        for (int ib = 0; ib < nv; ib += 8) {
+            double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const double* Ai = As + ib;
+            for_up<2>(0, n_dense, [&](int r) {
+                const double ajw = Aj[r * nv] * c.wrow[r];
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int i = min(ib + qd, nv - 1);
-                    ta[qd] = fma(Ar[i], aj, ta[qd]);
-                }
-                const int t = S.dense_row_task[r];
-                const bool last = (r + 1 == n_dense) || (S.dense_row_task[r + 1] != t);
-                if (last) {
-                    const double wt = c.w[t];
+                for (int qd = 0; qd < 8; ++qd) acc[qd] = fma(Ai[r * nv + qd], ajw, acc[qd]);
+            });
 #pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        acc[qd] = fma(wt, ta[qd], acc[qd]);
-                        ta[qd] = 0.0;
-                    }
-                }
-            }
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
+            for (int qd = 0; qd < 8; ++qd)
                 if (ib + qd < nv) c.J[(ib + qd) * ldj + j] = acc[qd];
         }
-        // g_j = - sum_t w_t sum_{r in t} A(r,j) b(r)
-        double gacc = 0.0, gt = 0.0;
-        for (int r = 0; r < n_dense; ++r) {
-            gt = fma(As[r * nv + j], c.b1[r], gt);
-            const int t = S.dense_row_task[r];
-            const bool last = (r + 1 == n_dense) || (S.dense_row_task[r + 1] != t);
-            if (last) {
-                gacc = fma(-c.w[t], gt, gacc);
-                gt = 0.0;
-            }
+        double g0 = 0.0, g1 = 0.0;
+        int r = 0;
+        for (; r + 2 <= n_dense; r += 2) {
+            g0 = fma(Aj[r * nv] * c.wrow[r], c.b1[r], g0);
+            g1 = fma(Aj[(r + 1) * nv] * c.wrow[r + 1], c.b1[r + 1], g1);
         }
-        c.g[j] = gacc;
+        for (; r < n_dense; ++r) g0 = fma(Aj[r * nv] * c.wrow[r], c.b1[r], g0);
+        c.g[j] = -(g0 + g1);
     }
     for (int m = lane; m < k; m += kWave) c.g[nv + m] = 0.0;
     wsync();
@@ -712,6 +859,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         }
         if (lane < 12) {
             double sacc = 0.0;
+#pragma unroll
             for (int qd = 0; qd < 6; ++qd) sacc = fma(Ft[lane * 6 + qd], bb[qd], sacc);
             c.g[nv + 12 * ct + lane] = -wt * sacc;
         }
@@ -728,80 +876,104 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         c1 = wave_sum(tr);
     }
     wsync();
-
     STAMP(1)
+
     // ---------------- phase 2: Cholesky H = L L' in place (lower), skyline = block structure ----------------
-    // row_start(i): first structurally non-zero column of row i (0 for dv rows, start of the contact block for force rows)
+    // first structurally non-zero column of row i: 0 for dv rows, start of the contact block for force rows
     for (int j = 0; j < n; ++j) {
         const int fj = (j < nv) ? 0 : nv + 12 * ((j - nv) / 12);
         const int i0 = lane, i1 = lane + kWave;
-        const bool act0 = (i0 >= j) && (i0 < n), act1 = (i1 >= j) && (i1 < n);
+        const bool act0 = (i0 >= j) && (i0 < n), act1 = TWO && (i1 >= j) && (i1 < n);
         const double* Lj = c.J + j * ldj;
         const double* L0 = c.J + (act0 ? i0 : j) * ldj;
         const double* L1 = c.J + (act1 ? i1 : j) * ldj;
-        double a0 = L0[j], a1 = L1[j];
-        for (int p = fj; p < j; ++p) {
-            const double ljp = Lj[p];
-            a0 = fma(-L0[p], ljp, a0);
-            a1 = fma(-L1[p], ljp, a1);
+        double a0 = L0[j], a1 = TWO ? L1[j] : 0.0, e0 = 0.0, e1 = 0.0;
+        int p = fj;
+        for (; p + 8 <= j; p += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const double l0 = Lj[p + u], l1 = Lj[p + u + 1];
+                a0 = fma(-L0[p + u], l0, a0);
+                e0 = fma(-L0[p + u + 1], l1, e0);
+                if (TWO) {
+                    a1 = fma(-L1[p + u], l0, a1);
+                    e1 = fma(-L1[p + u + 1], l1, e1);
+                }
+            }
         }
-        const double piv = (j < kWave) ? bcast_lane(a0, j) : bcast_lane(a1, j - kWave);
-        const double ljj = sqrt(piv);
-        const double inv = 1.0 / ljj;
-        if (act0) c.J[i0 * ldj + j] = (i0 == j) ? ljj : a0 * inv;
-        if (act1) c.J[i1 * ldj + j] = (i1 == j) ? ljj : a1 * inv;
+        for (; p < j; ++p) {
+            const double l0 = Lj[p];
+            a0 = fma(-L0[p], l0, a0);
+            if (TWO) a1 = fma(-L1[p], l0, a1);
+        }
+        a0 += e0;
+        a1 += e1;
+        double piv;
+        if (TWO)
+            piv = (j < kWave) ? bcast_lane(a0, j) : bcast_lane(a1, j - kWave);
+        else
+            piv = bcast_lane(a0, j);
+        // L(j,j) itself is never read again: only 1/L(j,j) is (column scaling here, diagonal of J = L^-T later)
+        const double inv = rsqrt(piv);
+        if (act0) c.J[i0 * ldj + j] = (i0 == j) ? inv : a0 * inv;
+        if (act1) c.J[i1 * ldj + j] = (i1 == j) ? inv : a1 * inv;
         if (lane == 0) c.dinv[j] = inv;
         wsync();
     }
-
     STAMP(2)
+
     // ---------------- phase 2b: J = L^-T. Row i of X = L^-1 is built from rows < i; X' is written into the
-    // strict upper triangle of the same buffer (X(i,c) -> J[c][i]); the diagonal 1/L(i,i) sits in dinv ----------------
+    // upper triangle of the same buffer (X(i,c) -> J[c][i]). Once row i of L has been consumed it is dead, so its
+    // lower part is zeroed and its diagonal already holds 1/L(i,i): later steps then read, for every lane c,
+    // J[c][p] = 0 (p < c), X(c,c) (p = c), X(p,c) (p > c) without any masking. ----------------
     for (int i = 1; i < n; ++i) {
         const int fi = (i < nv) ? 0 : nv + 12 * ((i - nv) / 12);
-        const double* Li = c.J + i * ldj;
+        double* Li = c.J + i * ldj;
         const double di = c.dinv[i];
         const int c0 = lane, c1 = lane + kWave;
-        const bool act0 = (c0 >= fi) && (c0 < i), act1 = (c1 >= fi) && (c1 < i);
+        const bool act0 = (c0 >= fi) && (c0 < i), act1 = TWO && (c1 >= fi) && (c1 < i);
         const double* X0 = c.J + (act0 ? c0 : 0) * ldj; // X(p, c0) at J[c0][p]
         const double* X1 = c.J + (act1 ? c1 : 0) * ldj;
-        const double dc0 = act0 ? c.dinv[c0] : 0.0, dc1 = act1 ? c.dinv[c1] : 0.0;
-        double a0 = 0.0, a1 = 0.0;
-        for (int p = fi; p < i; ++p) {
-            const double lip = Li[p];
-            const double x0 = (p > c0) ? X0[p] : ((p == c0) ? dc0 : 0.0);
-            const double x1 = (p > c1) ? X1[p] : ((p == c1) ? dc1 : 0.0);
-            a0 = fma(lip, x0, a0);
-            a1 = fma(lip, x1, a1);
+        double a0 = 0.0, a1 = 0.0, e0 = 0.0, e1 = 0.0;
+        int p = fi;
+        for (; p + 8 <= i; p += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const double l0 = Li[p + u], l1 = Li[p + u + 1];
+                a0 = fma(l0, X0[p + u], a0);
+                e0 = fma(l1, X0[p + u + 1], e0);
+                if (TWO) {
+                    a1 = fma(l0, X1[p + u], a1);
+                    e1 = fma(l1, X1[p + u + 1], e1);
+                }
+            }
         }
-        if (act0) c.J[c0 * ldj + i] = -a0 * di;
-        if (act1) c.J[c1 * ldj + i] = -a1 * di;
+        for (; p < i; ++p) {
+            const double l0 = Li[p];
+            a0 = fma(l0, X0[p], a0);
+            if (TWO) a1 = fma(l0, X1[p], a1);
+        }
+        if (act0) c.J[c0 * ldj + i] = -(a0 + e0) * di;
+        if (act1) c.J[c1 * ldj + i] = -(a1 + e1) * di;
+        for (int pz = lane; pz < i; pz += kWave) Li[pz] = 0.0;
         wsync();
     }
-    // finalise: diagonal, zero strict lower triangle
     double c2;
     {
         double tr = 0.0;
-        for (int i = lane; i < n; i += kWave) {
-            const double v = c.dinv[i];
-            tr += v;
-        }
+        for (int i = lane; i < n; i += kWave) tr += c.dinv[i];
         c2 = wave_sum(tr);
-        for (int i = 0; i < n; ++i) {
-            double* Ji = c.J + i * ldj;
-            for (int cc = lane; cc <= i; cc += kWave) Ji[cc] = (cc == i) ? c.dinv[i] : 0.0;
-        }
     }
     wsync();
-
     STAMP(3)
+
     // ---------------- x = -H^-1 g = -J (J' g); f = 0.5 g'x ----------------
     for (int i = lane; i < n; i += kWave) c.np[i] = c.g[i];
     wsync();
-    compute_d(c, 0, n); // d = J' g
+    compute_d<TWO>(c, 0, n); // d = J' g
     wsync();
     c.iq = 0;
-    update_z(c); // z = J d
+    update_z<TWO>(c); // z = J d
     wsync();
     double f_value;
     {
@@ -818,8 +990,8 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         c.A[i] = 0;
     }
     wsync();
-
     STAMP(4)
+
     const double eps = 2.220446049250313e-16;
     const double inf = __builtin_huge_val();
     int status = -2; // running
@@ -831,11 +1003,11 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         double ce0;
         build_eq_row(c, i, k0, k1, ce0);
         wsync();
-        compute_d(c, k0, k1);
+        compute_d<TWO>(c, k0, k1);
         wsync();
         STAMP(5)
-        update_z(c);
-        update_r(c);
+        update_z<TWO>(c);
+        update_r<TWO>(c);
         wsync();
         STAMP(6)
         double zz = 0.0, znp = 0.0, npx = 0.0;
@@ -862,7 +1034,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
         f_value += 0.5 * (t2 * t2) * znp;
         wsync();
         STAMP(7)
-        if (!add_constraint(c)) status = HQP_ERROR; // redundant equalities
+        if (!add_constraint<TWO>(c)) status = HQP_ERROR; // redundant equalities
         STAMP(8)
     }
 
@@ -929,11 +1101,11 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
                     if (ucol >= 0)
                         compute_d_unit(c, ucol, usign);
                     else
-                        compute_d(c, k0, k1);
+                        compute_d<TWO>(c, k0, k1);
                     wsync();
                     STAMP(11)
-                    update_z(c);
-                    update_r(c);
+                    update_z<TWO>(c);
+                    update_r<TWO>(c);
                     wsync();
                     STAMP(12)
                     const int iq = c.iq;
@@ -970,7 +1142,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
                         }
                         wsync();
                         STAMP(13)
-                        delete_constraint(c, l);
+                        delete_constraint<TWO>(c, l);
                         STAMP(15)
                         continue;
                     }
@@ -985,12 +1157,12 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
                     STAMP(13)
                     if (t == t2) {
                         // full step: add ip to the active set
-                        const bool added_ = add_constraint(c);
+                        const bool added_ = add_constraint<TWO>(c);
                         STAMP(14)
                         if (!added_) {
                             if (lane == 0) c.iaexcl[ip] = 0;
                             wsync();
-                            delete_constraint(c, ip);
+                            delete_constraint<TWO>(c, ip);
                             for (int i = lane; i < nin2; i += kWave) c.iai[i] = i;
                             wsync();
                             for (int i = lane; i < c.iq; i += kWave) {
@@ -1011,7 +1183,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
                     // partial step: drop l, refresh s(ip)
                     if (lane == 0) c.iai[l] = l;
                     wsync();
-                    delete_constraint(c, l);
+                    delete_constraint<TWO>(c, l);
                     STAMP(15)
                     double part = 0.0;
                     for (int j = k0 + lane; j < k1; j += kWave) part = fma(c.np[j], c.x[j], part);
@@ -1034,8 +1206,8 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
             const int row = nu + rr;
             const double* Mr = c.M + row * ldm;
             double a0 = c.h[row], a1 = 0.0;
-            for (int j = 0; j < nv; ++j) a0 = fma(Mr[j], c.x[j], a0);
-            for (int m = 0; m < k; ++m) a1 = fma(c.Jc[m * ldc + row], c.x[nv + m], a1);
+            for_up<8>(0, nv, [&](int j) { a0 = fma(Mr[j], c.x[j], a0); });
+            for_up<8>(0, k, [&](int m) { a1 = fma(c.Jc[m * ldc + row], c.x[nv + m], a1); });
             to[rr] = (TI)(a0 - a1);
         }
     }
@@ -1050,6 +1222,26 @@ __global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
     if (lane == 0 && ga.dbg)
         for (int i = 0; i < kStamps; ++i) ga.dbg[qp * kStamps + i] = st_acc_[i];
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel: grid = total QPs, block = 64 threads = one wavefront = one QP
+// ------------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(kWave) void solve_kernel(const GroupTable<TI> tab)
+{
+    extern __shared__ __align__(16) double lds[];
+    int b = blockIdx.x, gi = 0;
+    while (gi + 1 < tab.n && b >= tab.g[gi].count) {
+        b -= tab.g[gi].count;
+        ++gi;
+    }
+    const GroupArgs<TI>& ga = tab.g[gi];
+    const DevStruct& S = *ga.st;
+    if (S.n > kWave)
+        solve_one<TI, true>(ga, S, b, lds);
+    else
+        solve_one<TI, false>(ga, S, b, lds);
 }
 
 #endif // __HIPCC__
