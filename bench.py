@@ -42,7 +42,8 @@ def parse():
     p.add_argument("--no-allgather", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
-    p.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch from rocprofv3 PMC passes")
+    p.add_argument("--traffic", type=float, default=None,
+                   help="HBM bytes per launch from rocprofv3 PMC passes (default: scaled from profiles/pmc_latest.json)")
     p.add_argument("--sweep", default=None, help="also time batch 1..8192 and write the table to this JSON file")
     return p.parse_args()
 
@@ -128,6 +129,15 @@ def main():
     x_gpu = d_out["x"].cpu().numpy()
     tau_gpu = d_out["tau"].cpu().numpy()[:, :st.na]
 
+    traffic = args.traffic
+    if traffic is None and args.robot == "talos":
+        try:  # committed PMC measurement (separate --pmc passes), scaled to this launch's batch
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
+                pmc = json.load(fh)
+            traffic = (2.0 * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024.0 * B / pmc["batch"]
+        except Exception:
+            traffic = None
+
     result = None
     if rank == 0:
         total_qps = world * B * args.steps
@@ -145,7 +155,7 @@ def main():
                        "allgather_tau": bool(gather_state["ok"]), "lds_bytes_per_qp": layout["lds_bytes"],
                        "qps_resident_per_cu": layout["waves_per_cu"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "wbcqp::solve_kernel<double>", "kernel_ms": kern_avg_s * 1e3,
                          "algorithmic_bytes_per_qp": abytes},
             "active_set": {"iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
