@@ -1,0 +1,125 @@
+"""CPU tests of the host side: task-stack structures, the C-ABI library surface (loads, exports
+every symbol include/wbcqp.h declares, layout without a GPU, fails loudly without a device), reference streams."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from inria_wbc_amd import structure, synth, trajs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name,n,neq,nin,r1,dense", [
+    ("franka", 9, 0, 0, 15, 6), ("icub", 62, 18, 66, 83, 39), ("talos", 74, 18, 122, 97, 41),
+    ("talos_single_support", 62, 12, 105, 91, 41)])
+def test_structure_dimensions_match_survey_appendix_b(name, n, neq, nin, r1, dense):
+    st = structure.STRUCTURES[name]()
+    assert (st.n, st.neq, st.nin, st.r1, st.n_dense) == (n, neq, nin, r1, dense)
+    assert st.nin2 == 2 * nin
+
+
+def test_talos_stack_constants():
+    st = structure.talos_structure()
+    w = dict(zip(st.task_names, st.default_weights))
+    assert w["lf"] == 1000.0 and w["com"] == 1000.0 and w["posture"] == 1.75 and w["head"] == 1.0
+    assert w["forcereg_contact_lfoot"] == 1e-3  # tasks.hpp:23
+    B, lb, ub = st.friction()
+    assert B.shape == (2, 17, 12) and lb[0, 16] == 5.0 and ub[0, 16] == 1500.0 and (lb[0, :16] == -1e10).all()
+    # normal (0,0,1), mu 0.3: first pyramid row = (-t1 - mu n) with t1 = n x e_x = e_y
+    assert np.allclose(B[0, 0, :3], [0.0, -1.0, -0.3])
+    T = st.force_gen()[0]
+    assert np.allclose(T[:3, :3], np.eye(3)) and np.allclose(T[3:, :3], structure._skew([-0.11, -0.069, 0.107]))
+    assert st.algorithmic_bytes() == 35184  # SURVEY 8(d) counts 15 weights (35 152 B); this stack carries 19
+    assert structure.icub_structure().algorithmic_bytes() == 2 * 11936
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "wbcqp.h")).read()
+    declared = set(re.findall(r"\b(wbcqp_[a-z_]+)\s*\(", hdr))
+    from inria_wbc_amd import capi
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    lib = ctypes.CDLL(built_lib)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.wbcqp_version() == 100
+
+
+def test_layout_without_gpu(built_lib):
+    from inria_wbc_amd import capi
+    for name, mk in structure.STRUCTURES.items():
+        st = mk()
+        L = capi.layout_of(st)
+        assert (L["n"], L["neq"], L["nin"], L["nin2"], L["r1"]) == (st.n, st.neq, st.nin, st.nin2, st.r1)
+        fl = st.field_lengths()
+        for k in capi.FIELDS:
+            assert L["len_" + k] == fl[k], (name, k)
+        assert 0 < L["lds_bytes"] <= 160 * 1024 and L["waves_per_cu"] >= 1
+        assert L["algorithmic_bytes"] == st.algorithmic_bytes()
+
+
+def test_invalid_structures_are_rejected(built_lib):
+    from inria_wbc_amd import capi
+    st = structure.talos_structure()
+    st.dense_row_task = st.dense_row_task.copy(); st.dense_row_task[3] = 99
+    with pytest.raises(capi.WbcqpError) as e:
+        capi.layout_of(st)
+    assert e.value.code == 1
+    big = structure.tiago_structure(nv=130)
+    with pytest.raises(capi.WbcqpError) as e:
+        capi.layout_of(big)
+    assert e.value.code == 3
+
+
+def test_no_cpu_fallback(built_lib):
+    """Without a gfx950 device the product path must fail loudly (this container has none)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from inria_wbc_amd import capi
+    with pytest.raises(capi.WbcqpError) as e:
+        capi.Handle(device=0)
+    assert e.value.code == 4 and "no CPU fallback" in str(e.value)
+
+
+def test_min_jerk_matches_closed_form():
+    """trajectory_generator.hpp:23-78 and etc/talos/squat.yaml: 2000 + 2000 samples, -0.2 m in z."""
+    pos, vel, acc = trajs.move_com_stream([0.0, 0.0, 0.9], [[0.0, 0.0, -0.2]], "001", 1e-3, 2.0, loop=True)
+    assert pos.shape == (4000, 3) and vel.shape == (4000, 3) and acc.shape == (4000, 3)
+    assert np.allclose(pos[0], [0, 0, 0.9]) and abs(pos[1999, 2] - 0.7) < 1e-6 and abs(pos[3999, 2] - 0.9) < 1e-6
+    s = 0.25
+    assert abs(pos[500, 2] - (0.9 - 0.2 * (10 * s ** 3 - 15 * s ** 4 + 6 * s ** 5))) < 1e-12
+    # derivatives are consistent with finite differences of the position stream
+    fd = (pos[2:2000, 2] - pos[:1998, 2]) / 2e-3
+    assert np.abs(fd - vel[1:1999, 2]).max() < 1e-5
+    assert (pos[:, :2] == [0.0, 0.0]).all()
+
+
+def test_synthetic_batches_are_feasible_and_order_independent():
+    st = structure.talos_structure()
+    a = synth.generate(st, 6, synth.SEED_BASE["talos"])
+    b = synth.generate(st, 3, synth.SEED_BASE["talos"], first=3)
+    for k in synth.FIELDS:
+        assert np.array_equal(a[k][3:], b[k])
+    one = synth.generate_one(st, synth.SEED_BASE["talos"])
+    nv, nu = st.nv, st.nu
+    M = np.zeros((nv, nv)); M[np.tril_indices(nv)] = one["M"]; M = M + M.T - np.diag(np.diag(M))
+    assert np.linalg.eigvalsh(M).min() > 0
+    dv, f = one["_dv_star"], one["_f_star"]
+    Ac = one["Ac"].reshape(st.nc, 6, nv); T = st.force_gen()
+    Jc = np.concatenate([T[c].T @ Ac[c] for c in range(st.nc)], 0)
+    assert np.abs(M[:nu] @ dv - Jc[:, :nu].T @ f + one["h"][:nu]).max() < 1e-9
+    tau = M[nu:] @ dv + one["h"][nu:] - Jc[:, nu:].T @ f
+    assert (tau > one["tlb"]).all() and (tau < one["tub"]).all()
+    B, lb, ub = st.friction()
+    for c in range(st.nc):
+        v = B[c] @ f[12 * c:12 * c + 12]
+        assert (v > lb[c]).all() and (v < ub[c]).all()
+    # squat stream (BASELINE config 4): instance i takes tick i mod 4000 of etc/talos/squat.yaml
+    sq = synth.generate(st, 2, synth.SEED_BASE["talos_squat"], first=1000, squat=True)
+    pl = synth.generate(st, 2, synth.SEED_BASE["talos_squat"], first=1000, squat=False)
+    rows = np.where(st.dense_row_task == st.task_names.index("com"))[0]
+    d = sq["b1"][:, rows] - pl["b1"][:, rows]
+    assert np.allclose(d[0], synth.squat_com_rhs(st, 1000, 30.0)) and abs(d[0, 2]) > 0 and d[0, 0] == 0
