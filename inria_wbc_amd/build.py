@@ -46,6 +46,29 @@ def build_stamps(verbose: bool = False) -> str:
     return out
 
 
+HOST = os.path.join(CSRC, "host")
+
+
+def build_host(verbose: bool = False) -> dict:
+    """C++ host facade (mirror of the reference's controller / behavior plugin surface) + its two programs, with g++."""
+    build()
+    inc = ["-I", os.path.join(HOST, "include"), "-I", os.path.join(_HERE, "..", "include")]
+    common = ["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unused-function", "-Wno-return-type", *inc]
+    link = ["-L", LIBDIR, "-lwbcqp", "-Wl,-rpath," + LIBDIR]
+    lib = os.path.join(LIBDIR, "libinria_wbc_hip.so")
+    out = {"lib": lib, "test_facade": os.path.join(LIBDIR, "test_facade"), "qp_timer_test": os.path.join(LIBDIR, "qp_timer_test")}
+    cmds = [
+        common + ["-fPIC", "-shared", os.path.join(HOST, "src", "registry.cpp"), "-o", lib] + link,
+        common + [os.path.join(HOST, "tests", "test_facade.cpp"), os.path.join(HOST, "src", "registry.cpp"), "-o", out["test_facade"]] + link,
+        common + [os.path.join(HOST, "tests", "qp_timer_test.cpp"), os.path.join(HOST, "src", "registry.cpp"), "-o", out["qp_timer_test"]] + link,
+    ]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     if not force and not needs_build():
         return LIB
@@ -65,3 +88,5 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--stamps" in sys.argv:
         print(build_stamps(verbose=True))
+    if "--host" in sys.argv:
+        print(build_host(verbose=True))

@@ -1,0 +1,272 @@
+// Batched stand-in for inria_wbc::controllers::Controller (/root/reference/include/inria_wbc/controllers/controller.hpp:46-233,
+// /root/reference/src/controllers/controller.cpp:161-313): same method names and tick contract, but every getter
+// returns one row per robot instance.  The per-tick hot path -- computeProblemData's assembly + solver_->solve +
+// decode (controller.cpp:244-251) -- goes through the C ABI of libwbcqp (include/wbcqp.h) in ONE call for all
+// B instances.  What the reference gets from pinocchio and from each task's compute() (the step before the path)
+// is supplied by a ProblemSource.
+#ifndef IWBC_HIP_CONTROLLER_HPP
+#define IWBC_HIP_CONTROLLER_HPP
+
+#include <cmath>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <inria_wbc/controllers/task_stack.hpp>
+#include <inria_wbc/exceptions.hpp>
+#include <inria_wbc/utils/factory.hpp>
+#include <inria_wbc/utils/yaml_lite.hpp>
+
+#include "wbcqp.h"
+
+namespace inria_wbc {
+    namespace controllers {
+
+        // dense row-major matrix: [rows = instances][cols]
+        struct MatrixXd {
+            int rows = 0, cols = 0;
+            std::vector<double> data;
+            MatrixXd() = default;
+            MatrixXd(int r, int c, double v = 0.0) : rows(r), cols(c), data((size_t)r * c, v) {}
+            double& operator()(int r, int c) { return data[(size_t)r * cols + c]; }
+            double operator()(int r, int c) const { return data[(size_t)r * cols + c]; }
+            double* row(int r) { return data.data() + (size_t)r * cols; }
+            const double* row(int r) const { return data.data() + (size_t)r * cols; }
+        };
+        using VectorXi = std::vector<int>;
+
+        // same keys as the reference (controller.cpp:165-187): "positions", "joint_velocities", "floating_base_position", ...
+        using SensorData = std::unordered_map<std::string, MatrixXd>;
+
+        struct behavior_types {
+            static constexpr const char* FIXED_BASE = "FIXED_BASE";
+            static constexpr const char* SINGLE_SUPPORT = "SINGLE_SUPPORT";
+            static constexpr const char* DOUBLE_SUPPORT = "DOUBLE_SUPPORT";
+        };
+
+        // Per-tick inputs of the path for B instances, laid out exactly as wbcqp_inputs wants them ([B][len], row-major).
+        struct TickInputs {
+            int batch = 0;
+            std::vector<double> M, h, A, b1, Ac, bc, blb, bub, tlb, tub, w;
+            void resize(int B, const wbcqp_layout& L)
+            {
+                batch = B;
+                M.assign((size_t)B * L.len_M, 0.0); h.assign((size_t)B * L.len_h, 0.0); A.assign((size_t)B * L.len_A, 0.0);
+                b1.assign((size_t)B * L.len_b1, 0.0); Ac.assign((size_t)B * L.len_Ac, 0.0); bc.assign((size_t)B * L.len_bc, 0.0);
+                blb.assign((size_t)B * L.len_blb, 0.0); bub.assign((size_t)B * L.len_bub, 0.0);
+                tlb.assign((size_t)B * L.len_tlb, 0.0); tub.assign((size_t)B * L.len_tub, 0.0); w.assign((size_t)B * L.len_w, 0.0);
+            }
+        };
+
+        // "The step before the path": rigid-body terms and task rows for every instance at time t
+        // (pinocchio computeAllTerms + each task's compute() in the reference; out of scope here).
+        class ProblemSource {
+        public:
+            virtual ~ProblemSource() {}
+            virtual int batch() const = 0;
+            // fills every array of `in` except the reference-driven parts the controller adds afterwards
+            virtual void compute(double t, const MatrixXd& q, const MatrixXd& v, const tasks::TaskStack& stack, const wbcqp_layout& L, TickInputs& in) = 0;
+            // current CoM position / velocity per instance (3 columns) for the CoM task's PD law
+            virtual void com(MatrixXd& pos, MatrixXd& vel) const = 0;
+        };
+
+        // TrajectorySample of tsid: value / first / second derivative
+        struct TrajectorySample {
+            std::vector<double> pos, vel, acc;
+            explicit TrajectorySample(int n = 0) : pos(n, 0.0), vel(n, 0.0), acc(n, 0.0) {}
+        };
+
+        class Controller {
+        public:
+            explicit Controller(const yaml::Node& config)
+            {
+                yaml::Node c = IWBC_CHECK(config["CONTROLLER"]);
+                base_path_ = c["base_path"] ? c["base_path"].as<std::string>() : std::string(".");
+                dt_ = IWBC_CHECK(c["dt"].as<double>());
+                floating_base_ = IWBC_CHECK(c["floating_base"].as<bool>());
+                verbose_ = c["verbose"] ? c["verbose"].as<bool>() : false;
+                t_ = 0.0;
+            }
+            Controller(const Controller&) = delete;
+            Controller& operator=(const Controller&) = delete;
+            virtual ~Controller()
+            {
+                if (handle_) wbcqp_destroy(handle_);
+            }
+
+            const std::string& base_path() const { return base_path_; }
+            virtual void update(const SensorData& sensor_data = {})
+            {
+                // open loop when no sensor is given (controller.cpp:203-205); closed loop reads the same keys as the reference
+                auto qi = sensor_data.find("positions"), vi = sensor_data.find("joint_velocities");
+                if (closed_loop_ && qi != sensor_data.end() && vi != sensor_data.end()) {
+                    IWBC_ASSERT(qi->second.rows == batch_ && vi->second.rows == batch_, "closed loop: one sensor row per instance");
+                    _solve(qi->second, vi->second);
+                }
+                else
+                    _solve();
+            }
+
+            int batch_size() const { return batch_; }
+            double t() const { return t_; }
+            double dt() const { return dt_; }
+            bool verbose() const { return verbose_; }
+            void set_verbose(bool b) { verbose_ = b; }
+            virtual void set_behavior_type(const std::string& bt) { behavior_type_ = bt; }
+            const std::string& behavior_type() const { return behavior_type_; }
+
+            // one row per instance (the reference returns one Eigen::VectorXd)
+            const MatrixXd& tau() const { return tau_; }
+            const MatrixXd& ddq() const { return a_tsid_; }
+            const MatrixXd& dq() const { return v_tsid_; }
+            const MatrixXd& q() const { return q_tsid_; }
+            const MatrixXd& q_solver() const { return q_tsid_; }
+            const MatrixXd& q_tsid() const { return q_tsid_; }
+            const std::vector<std::string>& activated_contacts() const { return activated_contacts_; }
+            // 12 force components per activated contact and instance (tsid getContactForces, controller.cpp:258-261)
+            const std::unordered_map<std::string, MatrixXd>& activated_contacts_forces() const { return activated_contacts_forces_; }
+            const VectorXi& qp_status() const { return status_; }
+            const VectorXi& qp_iterations() const { return iters_; }
+            virtual double cost(const std::string& task_name) const = 0;
+
+            void set_problem_source(const std::shared_ptr<ProblemSource>& src)
+            {
+                IWBC_ASSERT(src, "Invalid problem source");
+                source_ = src;
+                batch_ = src->batch();
+                _reset();
+            }
+
+        protected:
+            virtual void _reset() {}
+            // builds this tick's inputs (source + references) -- implemented by PosTracker
+            virtual void _build_inputs(const MatrixXd& q, const MatrixXd& v) = 0;
+            virtual const tasks::TaskStack& _stack() const = 0;
+            virtual int _slot() const = 0;
+            virtual const wbcqp_layout& _layout() const = 0;
+
+            void _solve() { _solve(q_tsid_, v_tsid_); }
+
+            // Controller::_solve (controller.cpp:231-313) for B instances
+            void _solve(const MatrixXd& q, const MatrixXd& dq)
+            {
+                IWBC_ASSERT(handle_, "no solver: the controller was not fully constructed");
+                IWBC_ASSERT(source_, "no problem source set (set_problem_source)");
+                const tasks::TaskStack& st = _stack();
+                const wbcqp_layout& L = _layout();
+                _build_inputs(q, dq);
+                const int B = batch_, n = L.n, na = st.na(), nv = st.nv();
+                x_.assign((size_t)B * n, 0.0);
+                tau_ = MatrixXd(B, na);
+                status_.assign(B, WBCQP_HQP_UNKNOWN);
+                iters_.assign(B, 0);
+                objective_.assign(B, 0.0);
+                wbcqp_inputs in = {in_.M.data(), in_.h.data(), in_.A.data(), in_.b1.data(), in_.Ac.data(), in_.bc.data(),
+                                   in_.blb.data(), in_.bub.data(), in_.tlb.data(), in_.tub.data(), in_.w.data()};
+                wbcqp_outputs out = {x_.data(), tau_.data.data(), status_.data(), iters_.data(), objective_.data(), nullptr};
+                int rc = wbcqp_solve_batch_host(handle_, _slot(), B, &in, &out);
+                if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_solve_batch_host failed: ", wbcqp_last_error(handle_));
+                for (int i = 0; i < B; ++i) {
+                    if (status_[i] != WBCQP_HQP_OPTIMAL) {
+                        // same text as controller.cpp:285-307, with the instance appended
+                        std::string error = "Controller failed, can't solve problem. ";
+                        error += "Status : " + std::to_string(status_[i]);
+                        switch (status_[i]) {
+                        case -1: error += " => Unknown"; break;
+                        case 1: error += " => Infeasible "; break;
+                        case 2: error += " => Unbounded "; break;
+                        case 3: error += " => Max iter reached "; break;
+                        case 4: error += " => Error "; break;
+                        default: error += " => Uknown status";
+                        }
+                        error += " (t=" + std::to_string(t_) + ")";
+                        error += " [instance " + std::to_string(i) + "]";
+                        throw IWBC_EXCEPTION(error);
+                    }
+                }
+                // a_tsid = dv ; v_tsid = dq + dt dv ; q = integrate(q, dt v)  (controller.cpp:250-256)
+                a_tsid_ = MatrixXd(B, nv);
+                MatrixXd vnew(B, nv);
+                for (int i = 0; i < B; ++i)
+                    for (int j = 0; j < nv; ++j) {
+                        a_tsid_(i, j) = x_[(size_t)i * n + j];
+                        vnew(i, j) = dq(i, j) + dt_ * a_tsid_(i, j);
+                    }
+                MatrixXd qnew = q;
+                for (int i = 0; i < B; ++i) _integrate(q.row(i), vnew.row(i), qnew.row(i), q.cols, nv);
+                v_tsid_ = vnew;
+                q_tsid_ = qnew;
+                t_ += dt_;
+                activated_contacts_forces_.clear();
+                for (size_t c = 0; c < st.contacts().size(); ++c) {
+                    MatrixXd f(B, 12);
+                    for (int i = 0; i < B; ++i)
+                        for (int m = 0; m < 12; ++m) f(i, m) = x_[(size_t)i * n + nv + 12 * c + m];
+                    activated_contacts_forces_[st.contacts()[c].name] = f;
+                }
+            }
+
+            // semi-implicit Euler on SE(3) x R^na: what pinocchio::integrate does for a free-flyer + revolute joints
+            void _integrate(const double* q, const double* v, double* qout, int nq, int nv) const
+            {
+                if (!floating_base_) {
+                    for (int j = 0; j < nv; ++j) qout[j] = q[j] + dt_ * v[j];
+                    return;
+                }
+                // q = [p(3), quat(x,y,z,w), joints]; v = [v_lin (body frame), w (body frame), joint rates]
+                const double wx = v[3] * dt_, wy = v[4] * dt_, wz = v[5] * dt_;
+                const double vx = v[0] * dt_, vy = v[1] * dt_, vz = v[2] * dt_;
+                const double th2 = wx * wx + wy * wy + wz * wz, th = std::sqrt(th2);
+                // exp6: rotation increment (quaternion) and translation increment V(w) v
+                double a, b, c;
+                if (th < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0; }
+                else { a = std::sin(th) / th; b = (1.0 - std::cos(th)) / th2; c = (1.0 - a) / th2; }
+                const double cx = wy * vz - wz * vy, cy = wz * vx - wx * vz, cz = wx * vy - wy * vx;              // w x v
+                const double ccx = wy * cz - wz * cy, ccy = wz * cx - wx * cz, ccz = wx * cy - wy * cx;            // w x (w x v)
+                const double tx = vx + b * cx + c * ccx, ty = vy + b * cy + c * ccy, tz = vz + b * cz + c * ccz;
+                const double half = 0.5 * th, sh = (th < 1e-8) ? 0.5 - th2 / 48.0 : std::sin(half) / th;
+                const double dqx = wx * sh, dqy = wy * sh, dqz = wz * sh, dqw = std::cos(half);
+                const double qx = q[3], qy = q[4], qz = q[5], qw = q[6];
+                // p += R(q) t
+                const double r00 = 1 - 2 * (qy * qy + qz * qz), r01 = 2 * (qx * qy - qz * qw), r02 = 2 * (qx * qz + qy * qw);
+                const double r10 = 2 * (qx * qy + qz * qw), r11 = 1 - 2 * (qx * qx + qz * qz), r12 = 2 * (qy * qz - qx * qw);
+                const double r20 = 2 * (qx * qz - qy * qw), r21 = 2 * (qy * qz + qx * qw), r22 = 1 - 2 * (qx * qx + qy * qy);
+                qout[0] = q[0] + r00 * tx + r01 * ty + r02 * tz;
+                qout[1] = q[1] + r10 * tx + r11 * ty + r12 * tz;
+                qout[2] = q[2] + r20 * tx + r21 * ty + r22 * tz;
+                // quat = q * dq, renormalised
+                double nx = qw * dqx + qx * dqw + qy * dqz - qz * dqy;
+                double ny = qw * dqy - qx * dqz + qy * dqw + qz * dqx;
+                double nz = qw * dqz + qx * dqy - qy * dqx + qz * dqw;
+                double nw = qw * dqw - qx * dqx - qy * dqy - qz * dqz;
+                const double nn = std::sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+                qout[3] = nx / nn; qout[4] = ny / nn; qout[5] = nz / nn; qout[6] = nw / nn;
+                for (int j = 6; j < nv; ++j) qout[j + 1] = q[j + 1] + dt_ * v[j];
+                (void)nq;
+            }
+
+            bool verbose_ = false;
+            double t_ = 0.0, dt_ = 0.001;
+            bool floating_base_ = true;
+            bool closed_loop_ = false;
+            std::string base_path_, behavior_type_, solver_to_use_;
+            int batch_ = 0;
+
+            MatrixXd q_tsid_, v_tsid_, a_tsid_, tau_;
+            std::vector<double> x_, objective_;
+            VectorXi status_, iters_;
+            std::vector<std::string> activated_contacts_, all_contacts_;
+            std::unordered_map<std::string, MatrixXd> activated_contacts_forces_;
+
+            std::shared_ptr<ProblemSource> source_;
+            TickInputs in_;
+            wbcqp_handle* handle_ = nullptr; // the reference's solver_ (controller.hpp:224)
+        };
+
+        using Factory = utils::Factory<Controller, yaml::Node>;
+        template <typename T>
+        using Register = Factory::AutoRegister<T>;
+    } // namespace controllers
+} // namespace inria_wbc
+#endif

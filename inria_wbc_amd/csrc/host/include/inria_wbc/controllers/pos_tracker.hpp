@@ -1,0 +1,197 @@
+// Batched stand-in for inria_wbc::controllers::PosTracker (/root/reference/src/controllers/pos_tracker.cpp:40-326,
+// /root/reference/include/inria_wbc/controllers/pos_tracker.hpp:12-82): YAML task stack -> QP structure, the
+// `solver:` switch (a third value, "hip-batched", selects libwbcqp), reference setters, contact add/remove
+// (changes the QP dimension), task-weight updates.  Registered as "pos-tracker".
+#ifndef IWBC_HIP_POS_TRACKER_HPP
+#define IWBC_HIP_POS_TRACKER_HPP
+
+#include <iostream>
+#include <map>
+
+#include <inria_wbc/controllers/controller.hpp>
+
+namespace inria_wbc {
+    namespace controllers {
+        class PosTracker : public Controller {
+        public:
+            explicit PosTracker(const yaml::Node& config) : Controller(config)
+            {
+                yaml::Node c = IWBC_CHECK(config["CONTROLLER"]);
+                solver_to_use_ = IWBC_CHECK(c["solver"].as<std::string>());
+                // robot dimensions come from the URDF in the reference (controller.cpp:104-118); here from the config
+                const int nv = IWBC_CHECK(c["nv"].as<int>());
+                const int na = IWBC_CHECK(c["na"].as<int>());
+                IWBC_ASSERT(floating_base_ ? (nv == na + 6) : (nv == na), "nv / na do not match floating_base");
+                closed_loop_ = c["closed_loop"] ? c["closed_loop"].as<bool>() : false;
+
+                // qp solver to be used: the reference accepts 'eiquadprog' or 'qpmad' (pos_tracker.cpp:88-100)
+                if (solver_to_use_ == "hip-batched") {
+                    wbcqp_desc desc = {c["device"] ? c["device"].as<int>() : 0, WBCQP_F64, 0};
+                    int rc = wbcqp_create(&desc, &handle_);
+                    if (rc != WBCQP_OK) IWBC_ERROR("'hip-batched' solver is not available: ", wbcqp_last_error(nullptr));
+                }
+                else if (solver_to_use_ == "eiquadprog" || solver_to_use_ == "qpmad") {
+                    IWBC_ERROR("'", solver_to_use_, "' solver is not available: this build does not link tsid; use 'hip-batched'.");
+                }
+                else {
+                    IWBC_ERROR("solver in configuration file must be either 'eiquadprog', 'qpmad' or 'hip-batched'.");
+                }
+
+                auto task_file = IWBC_CHECK(c["tasks"].as<std::string>());
+                auto p = task_file.size() && task_file[0] == '/' ? task_file : base_path_ + "/" + task_file;
+                parse_tasks(p, nv, na);
+
+                if (verbose_) {
+                    std::cout << "--------- Solver size info ---------" << std::endl;
+                    std::cout << "Solver : " << solver_to_use_ << std::endl;
+                    std::cout << "total number of variable (acceleration + contact-force) : " << stack_.nVar() << std::endl;
+                    std::cout << "number of equality constraints : " << stack_.nEq() << std::endl;
+                    std::cout << "number of inequality constraints : " << stack_.nIn() << std::endl;
+                    std::cout << "--------- ------------- ---------" << std::endl;
+                }
+            }
+
+            // ---- reference setters / getters (pos_tracker.hpp:44-70); one sample drives every instance ----
+            void set_com_ref(const TrajectorySample& sample) { com_ref_ = sample; }
+            void set_se3_ref(const TrajectorySample& sample, const std::string& task_name)
+            {
+                IWBC_ASSERT(stack_.has_task(task_name), "Task [", task_name, "] not found");
+                se3_refs_[task_name] = sample;
+            }
+            const std::vector<double>& get_com_ref() const { return com_init_; }
+            double objective_value(int instance = 0) const { return objective_.at(instance); }
+            double cost(const std::string& task_name) const override
+            {
+                // |A ddq - b| of the first instance (controller.hpp:148-152)
+                const auto& t = stack_.task(task_name);
+                if (t.type == "posture" || in_.batch == 0) return 0.0;
+                const int nv = stack_.nv();
+                double s = 0.0;
+                for (int r = 0; r < t.rows; ++r) {
+                    double v = -in_.b1[t.first_row + r];
+                    for (int j = 0; j < nv; ++j) v += in_.A[(size_t)(t.first_row + r) * nv + j] * a_tsid_(0, j);
+                    s += v * v;
+                }
+                return std::sqrt(s);
+            }
+
+            // PosTracker::update_task_weights (pos_tracker.cpp:314-324)
+            void update_task_weights(const std::map<std::string, double>& new_weights)
+            {
+                for (const auto& kv : new_weights) {
+                    const auto& t = stack_.task(kv.first);
+                    IWBC_ASSERT(t.weight_index >= 0, "Task [", kv.first, "] carries no level-1 weight");
+                    weights_[t.weight_index] = kv.second;
+                }
+            }
+            // remove_contact / add_contact (pos_tracker.cpp:246-263): n, nEq, nIn change with the contact set
+            void remove_contact(const std::string& contact_name)
+            {
+                IWBC_ASSERT(stack_.contact_index(contact_name) >= 0, "Trying to remove an contact:", contact_name);
+                stack_ = stack_.without_contact(contact_name);
+                _install_stack();
+            }
+            void add_contact(const std::string& contact_name)
+            {
+                IWBC_ASSERT(full_stack_.contact_index(contact_name) >= 0, "Trying to add an unknown contact:", contact_name);
+                stack_ = full_stack_; // every shipped stack has two contacts: adding one back restores the full stack
+                _install_stack();
+            }
+            const tasks::TaskStack& stack() const { return stack_; }
+
+        protected:
+            void parse_tasks(const std::string& path, int nv, int na)
+            {
+                if (verbose_) std::cout << "parsing task file:" << path << std::endl;
+                yaml::Node task_list = IWBC_CHECK(yaml::LoadFile(path));
+                stack_ = tasks::TaskStack(task_list, nv, na);
+                full_stack_ = stack_;
+                _install_stack();
+                if (verbose_) std::cout << "Number of parsed tasks " << task_list.size() << std::endl;
+            }
+
+            void _install_stack()
+            {
+                wbcqp_structure s = stack_.c_struct();
+                // the analogue of solver_->resize(nVar, nEq, nIn) (pos_tracker.cpp:102)
+                int rc = wbcqp_set_structure(handle_, 0, &s);
+                if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_set_structure failed: ", wbcqp_last_error(handle_));
+                rc = wbcqp_layout_of(&s, &layout_);
+                if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_layout_of failed");
+                std::vector<double> w = stack_.default_weights();
+                if (!weights_.empty()) // keep user-updated weights across a contact switch, by name
+                    for (size_t i = 0; i < w.size(); ++i)
+                        for (size_t j = 0; j < weight_names_.size(); ++j)
+                            if (weight_names_[j] == stack_.weight_names()[i]) w[i] = weights_[j];
+                weights_ = w;
+                weight_names_ = stack_.weight_names();
+                activated_contacts_.clear();
+                for (const auto& c : stack_.contacts()) activated_contacts_.push_back(c.name);
+                if (all_contacts_.empty()) all_contacts_ = activated_contacts_;
+            }
+
+            void _reset() override
+            {
+                const int nv = stack_.nv(), nq = floating_base_ ? nv + 1 : nv;
+                q_tsid_ = MatrixXd(batch_, nq);
+                if (floating_base_)
+                    for (int i = 0; i < batch_; ++i) q_tsid_(i, 6) = 1.0; // unit quaternion
+                v_tsid_ = MatrixXd(batch_, nv);
+                a_tsid_ = MatrixXd(batch_, nv);
+                MatrixXd cp, cv;
+                source_->com(cp, cv);
+                com_init_.assign(3, 0.0);
+                if (cp.rows > 0)
+                    for (int d = 0; d < 3; ++d) com_init_[d] = cp(0, d);
+                com_ref_ = TrajectorySample(3);
+                com_ref_.pos = com_init_;
+                com_ref_set_ = false;
+            }
+
+            void _build_inputs(const MatrixXd& q, const MatrixXd& v) override
+            {
+                in_.resize(batch_, layout_);
+                source_->compute(t_, q, v, stack_, layout_, in_);
+                for (int i = 0; i < batch_; ++i)
+                    for (int k = 0; k < layout_.len_w; ++k) in_.w[(size_t)i * layout_.len_w + k] = weights_[k];
+                // CoM task PD law: b += Kp (x_ref - x) + Kd (v_ref - v) + a_ref on the masked axes (tsid TaskComEquality)
+                if (com_ref_set_ && stack_.has_task("com")) {
+                    const auto& t = stack_.task("com");
+                    MatrixXd cp, cv;
+                    source_->com(cp, cv);
+                    for (int i = 0; i < batch_; ++i) {
+                        int r = 0;
+                        for (int d = 0; d < 3; ++d) {
+                            if (t.mask[d] != '1') continue;
+                            in_.b1[(size_t)i * layout_.len_b1 + t.first_row + r] +=
+                                t.kp * (com_ref_.pos[d] - cp(i, d)) + t.kd * (com_ref_.vel[d] - cv(i, d)) + com_ref_.acc[d];
+                            ++r;
+                        }
+                    }
+                }
+            }
+            const tasks::TaskStack& _stack() const override { return stack_; }
+            int _slot() const override { return 0; }
+            const wbcqp_layout& _layout() const override { return layout_; }
+
+        public:
+            // set_com_ref with tracking enabled (MoveCom::update calls this every tick)
+            void set_com_ref_tracking(const TrajectorySample& sample)
+            {
+                com_ref_ = sample;
+                com_ref_set_ = true;
+            }
+
+        protected:
+            tasks::TaskStack stack_, full_stack_;
+            wbcqp_layout layout_{};
+            std::vector<double> weights_;
+            std::vector<std::string> weight_names_;
+            TrajectorySample com_ref_{3};
+            bool com_ref_set_ = false;
+            std::vector<double> com_init_;
+            std::map<std::string, TrajectorySample> se3_refs_;
+        };
+    } // namespace controllers
+} // namespace inria_wbc
+#endif

@@ -1,0 +1,14 @@
+// Static registrations under the reference's string keys (pos_tracker.cpp:38, move_com.cpp:6).
+#include <inria_wbc/behaviors/humanoid/move_com.hpp>
+#include <inria_wbc/controllers/pos_tracker.hpp>
+
+namespace inria_wbc {
+    namespace controllers {
+        static Register<PosTracker> __generic_pos_tracker("pos-tracker");
+    }
+    namespace behaviors {
+        namespace humanoid {
+            static Register<MoveCom> __talos_move_com("humanoid::move_com");
+        }
+    } // namespace behaviors
+} // namespace inria_wbc

@@ -1,0 +1,60 @@
+// Batched counterpart of the reference's solver timing harness (/root/reference/src/robot_dart/qp_timer_test.cpp:15-70):
+// builds a PosTracker from argv[1] and a behavior from argv[2], then loops behavior->update() with empty sensor data
+// (open loop) under the "solver" timer.  Differences: B robot instances per tick (from the batch file argv[3]), and the
+// last tick's torques can be written to argv[5] so that a test can compare them with the CPU oracle.
+//   qp_timer_test <controller.yaml> <behavior.yaml> <batch.bin> [n_ticks=10] [tau_out.bin] [first_tick=0]
+#include <csignal>
+#include <fstream>
+#include <iostream>
+
+#include <inria_wbc/behaviors/humanoid/move_com.hpp>
+#include <inria_wbc/controllers/file_source.hpp>
+#include <inria_wbc/utils/timer.hpp>
+
+static volatile sig_atomic_t stop = 0;
+static void stopsig(int) { stop = 1; }
+
+int main(int argc, char** argv)
+{
+    using namespace inria_wbc;
+    if (argc < 4) {
+        std::cerr << "usage: " << argv[0] << " <controller.yaml> <behavior.yaml> <batch.bin> [n_ticks] [tau_out.bin] [first_tick]" << std::endl;
+        return 2;
+    }
+    std::signal(SIGINT, stopsig);
+    try {
+        const std::string ctrl_path = argv[1];
+        yaml::Node c_config = IWBC_CHECK(yaml::LoadFile(ctrl_path));
+        c_config["CONTROLLER"].set("base_path", ctrl_path.substr(0, ctrl_path.find_last_of('/')));
+        auto controller_name = IWBC_CHECK(c_config["CONTROLLER"]["name"].as<std::string>());
+        auto controller = controllers::Factory::instance().create(controller_name, c_config);
+        controller->set_problem_source(std::make_shared<controllers::FileSource>(argv[3]));
+
+        yaml::Node b_config = IWBC_CHECK(yaml::LoadFile(argv[2]));
+        auto behavior_name = IWBC_CHECK(b_config["BEHAVIOR"]["name"].as<std::string>());
+        auto behavior = behaviors::Factory::instance().create(behavior_name, controller, b_config);
+        const int n_ticks = argc > 4 ? std::atoi(argv[4]) : 10;
+        if (argc > 6)
+            if (auto mc = std::dynamic_pointer_cast<behaviors::humanoid::MoveCom>(behavior)) mc->set_time(std::atoi(argv[6]));
+
+        utils::Timer timer;
+        int it = 0;
+        while (!stop && it < n_ticks) {
+            timer.begin("solver");
+            behavior->update();
+            timer.end("solver");
+            timer.report(std::cout, it++, 1);
+        }
+        std::cout << "instances per tick: " << controller->batch_size() << std::endl;
+        if (argc > 5) {
+            std::ofstream f(argv[5], std::ios::binary);
+            const auto& tau = controller->tau();
+            f.write(reinterpret_cast<const char*>(tau.data.data()), (std::streamsize)(tau.data.size() * sizeof(double)));
+        }
+    }
+    catch (std::exception& e) {
+        std::cerr << "Exception (solver):" << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,97 @@
+// CPU-only checks of the host facade, in the spirit of the reference's utest programs
+// (/root/reference/tests/utest.hpp:154-212, test_all_robots.cpp:135-229): factories, config parsing, task stacks,
+// error behaviour of the solver switch.  Exit code 0 = all checks passed.
+#include <cmath>
+#include <iostream>
+
+#include <inria_wbc/behaviors/humanoid/move_com.hpp>
+#include <inria_wbc/controllers/pos_tracker.hpp>
+#include <inria_wbc/utils/timer.hpp>
+
+static int failures = 0;
+#define UTEST_CHECK(cond)                                                              \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            ++failures;                                                                \
+            std::cerr << "CHECK FAILED " << __FILE__ << ":" << __LINE__ << " " #cond << std::endl; \
+        }                                                                              \
+    } while (0)
+#define UTEST_CHECK_EXCEPTION(expr, needle)                                            \
+    do {                                                                               \
+        bool thrown_ = false;                                                          \
+        try { expr; }                                                                  \
+        catch (const inria_wbc::Exception& e) { thrown_ = std::string(e.what()).find(needle) != std::string::npos; \
+            if (!thrown_) std::cerr << "unexpected message: " << e.what() << std::endl; } \
+        UTEST_CHECK(thrown_);                                                          \
+    } while (0)
+
+using namespace inria_wbc;
+
+int main(int argc, char** argv)
+{
+    const std::string cfg = argc > 1 ? argv[1] : "configs";
+    // ---- task stacks: sizes of SURVEY.md Appendix B ----
+    struct Exp { const char* robot; int nv, na, n, neq, nin, r1, dense; };
+    const Exp exps[] = {{"talos", 50, 44, 74, 18, 122, 97, 41}, {"icub", 38, 32, 62, 18, 66, 83, 39}, {"franka", 9, 9, 9, 0, 0, 15, 6}, {"tiago", 12, 12, 12, 0, 12, 25, 13}};
+    for (const auto& e : exps) {
+        yaml::Node tasks = yaml::LoadFile(cfg + "/" + e.robot + "/tasks.yaml");
+        tasks::TaskStack st(tasks, e.nv, e.na);
+        UTEST_CHECK(st.nVar() == e.n && st.nEq() == e.neq && st.nIn() == e.nin && st.level1_rows() == e.r1 && st.n_dense() == e.dense);
+        wbcqp_structure s = st.c_struct();
+        wbcqp_layout L;
+        UTEST_CHECK(wbcqp_layout_of(&s, &L) == WBCQP_OK);
+        UTEST_CHECK(L.n == e.n && L.neq == e.neq && L.nin == e.nin && L.nin2 == 2 * e.nin && L.r1 == e.r1);
+    }
+    {
+        yaml::Node tasks = yaml::LoadFile(cfg + "/talos/tasks.yaml");
+        tasks::TaskStack st(tasks, 50, 44);
+        UTEST_CHECK(st.task("com").kp == 30.0 && std::fabs(st.task("com").kd - 2.0 * std::sqrt(30.0)) < 1e-12);
+        UTEST_CHECK(st.task("self_collision-left").kd == 250.0 && st.task("posture").weight == 1.75);
+        // single support: n 62, nEq 12, nIn 105
+        tasks::TaskStack ss = st.without_contact("contact_lfoot");
+        UTEST_CHECK(ss.nVar() == 62 && ss.nEq() == 12 && ss.nIn() == 105 && ss.level1_rows() == 91);
+        UTEST_CHECK_EXCEPTION(st.task("nope"), "not found");
+    }
+    // ---- unknown task type is refused with its name ----
+    UTEST_CHECK_EXCEPTION(tasks::TaskStack(yaml::Load("t:\n  type: cop\n  weight: 1\n"), 9, 9), "not handled");
+    UTEST_CHECK_EXCEPTION(tasks::TaskStack(yaml::Load("t:\n  type: se3\n  weight: 1\n  mask: 11\n"), 9, 9), "mask");
+    // ---- yaml subset ----
+    {
+        yaml::Node n = yaml::Load("BEHAVIOR:\n  name: humanoid::move_com # comment\n  targets: [[0, 0, -0.2], [1, 2, 3]]\n  loop: true\n  mask: 001\n");
+        UTEST_CHECK(n["BEHAVIOR"]["name"].as<std::string>() == "humanoid::move_com");
+        auto t = n["BEHAVIOR"]["targets"].as<std::vector<std::vector<double>>>();
+        UTEST_CHECK(t.size() == 2 && t[0][2] == -0.2 && t[1][1] == 2.0);
+        UTEST_CHECK(n["BEHAVIOR"]["loop"].as<bool>() && n["BEHAVIOR"]["mask"].as<std::string>() == "001");
+        UTEST_CHECK(!n["BEHAVIOR"]["missing"]);
+        UTEST_CHECK_EXCEPTION(IWBC_CHECK(n["BEHAVIOR"]["missing"].as<double>()), "when calling");
+    }
+    // ---- factories: unknown name lists the known ones; known names are registered ----
+    UTEST_CHECK(controllers::Factory::instance().has("pos-tracker"));
+    UTEST_CHECK(behaviors::Factory::instance().has("humanoid::move_com"));
+    UTEST_CHECK_EXCEPTION(controllers::Factory::instance().create("no-such-controller", yaml::Node()), "is not in the factory");
+    // ---- solver switch (pos_tracker.cpp:88-100) ----
+    {
+        yaml::Node c = yaml::LoadFile(cfg + "/talos/pos_tracker.yaml");
+        c["CONTROLLER"].set("base_path", cfg + "/talos");
+        c["CONTROLLER"].set("solver", "banana");
+        UTEST_CHECK_EXCEPTION(controllers::Factory::instance().create("pos-tracker", c), "must be either");
+        c["CONTROLLER"].set("solver", "eiquadprog");
+        UTEST_CHECK_EXCEPTION(controllers::Factory::instance().create("pos-tracker", c), "not available");
+    }
+    // ---- min jerk ----
+    {
+        auto p = trajs::min_jerk_trajectory<trajs::d_order::ZERO>({0, 0, 0.9}, {0, 0, 0.7}, 1e-3, 2.0);
+        auto v = trajs::min_jerk_trajectory<trajs::d_order::FIRST>({0, 0, 0.9}, {0, 0, 0.7}, 1e-3, 2.0);
+        UTEST_CHECK(p.size() == 2000 && std::fabs(p[1000][2] - 0.8) < 1e-12 && p[0][2] == 0.9);
+        UTEST_CHECK(std::fabs(v[1000][2] - (-0.2 * 30.0 / 16.0 / 2.0)) < 1e-12);
+    }
+    // ---- timer ----
+    {
+        utils::Timer timer;
+        timer.begin("solver");
+        timer.end("solver");
+        UTEST_CHECK(timer["solver"].iterations == 1 && timer["solver"].min_time <= timer["solver"].max_time);
+    }
+    std::cout << (failures ? "FAILED" : "OK") << " (" << failures << " failures)" << std::endl;
+    return failures ? 1 : 0;
+}

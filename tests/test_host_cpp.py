@@ -1,0 +1,62 @@
+"""The C++ host facade (inria_wbc_amd/csrc/host): the reference's controller / behavior plugin surface over the C ABI."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host_build(built_lib):
+    from inria_wbc_amd import build
+    return build.build_host()
+
+
+def test_facade_cpu_checks(host_build):
+    """factories, YAML subset, task stacks (SURVEY App. B sizes), solver-switch errors, min-jerk -- no GPU needed."""
+    r = subprocess.run([host_build["test_facade"], os.path.join(ROOT, "configs")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK (0 failures)" in r.stdout
+
+
+def test_hip_batched_solver_refuses_without_gpu(host_build, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    sys.path.insert(0, ROOT)
+    from tools import dump_batch
+    from inria_wbc_amd import structure, synth
+    st = structure.talos_structure()
+    path = str(tmp_path / "b.bin")
+    dump_batch.dump(path, st, synth.generate(st, 2, synth.SEED_BASE["talos"]))
+    r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/talos/pos_tracker.yaml"),
+                        os.path.join(ROOT, "configs/talos/squat.yaml"), path, "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_qp_timer_test_squat_matches_oracle(host_build, oracle_mod, tmp_path):
+    """The reference's qp_timer_test loop (qp_timer_test.cpp:55-63) with PosTracker + humanoid::move_com on 48 Talos
+    instances; torques of the last tick against the oracle fed the same CoM reference (BASELINE config 4 stream)."""
+    from tools import dump_batch
+    from inria_wbc_amd import structure, synth
+    st = structure.talos_structure()
+    B, first_tick, n_ticks = 48, 700, 3
+    inputs = synth.generate(st, B, synth.SEED_BASE["talos_squat"])
+    path, tau_path = str(tmp_path / "b.bin"), str(tmp_path / "tau.bin")
+    dump_batch.dump(path, st, inputs)
+    r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/talos/pos_tracker.yaml"),
+                        os.path.join(ROOT, "configs/talos/squat.yaml"), path, str(n_ticks), tau_path, str(first_tick)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "solver:" in r.stdout and "instances per tick: 48" in r.stdout
+    tau = np.fromfile(tau_path, dtype=np.float64).reshape(B, st.na)
+    rows = np.where(st.dense_row_task == st.task_names.index("com"))[0]
+    ref_in = {k: v.copy() for k, v in inputs.items()}
+    ref_in["b1"][:, rows] += synth.squat_com_rhs(st, first_tick + n_ticks - 1, 30.0)
+    ref = oracle_mod.tick_batch(st, ref_in, nthreads=4)
+    assert (ref["status"] == 0).all()
+    assert np.abs(tau - ref["tau"]).max() <= 1e-8 * max(1.0, np.abs(ref["tau"]).max())

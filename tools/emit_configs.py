@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Writes configs/<robot>/*.yaml in the reference's own configuration schema (task stacks as in
+/root/reference/etc/<robot>/tasks.yaml, CONTROLLER / BEHAVIOR trees as in etc/talos/talos_pos_tracker.yaml and
+etc/talos/squat.yaml) from the constants below (the same numbers inria_wbc_amd/structure.py carries).
+The C++ facade parses these files."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+TALOS_CONTACT = dict(kp=30.0, lxp=0.1, lxn=0.11, lyp=0.069, lyn=0.069, lz=0.107, fmin=5.0, fmax=1500.0, mu=0.3, normal="[0, 0, 1]")
+# (name, type, fields) in task-stack order
+TALOS = [
+    ("head", "se3", dict(tracked="head_1_joint", weight=1.0, kp=1.0, mask="110000")),
+    ("head_pitch", "se3", dict(tracked="head_1_joint", weight=100.0, kp=30.0, mask="000010")),
+    ("head_yaw", "se3", dict(tracked="head_2_joint", weight=100.0, kp=30.0, mask="000001")),
+    ("lh", "se3", dict(tracked="gripper_left_joint", weight=10.0, kp=30.0, mask="111111")),
+    ("rh", "se3", dict(tracked="gripper_right_joint", weight=10.0, kp=30.0, mask="111111")),
+    ("torso", "se3", dict(tracked="torso_2_link", weight=10.0, kp=30.0, mask="000110")),
+    ("lf", "se3", dict(tracked="leg_left_6_joint", weight=1000.0, kp=30.0, mask="111111")),
+    ("rf", "se3", dict(tracked="leg_right_6_joint", weight=1000.0, kp=30.0, mask="111111")),
+    ("com", "com", dict(weight=1000.0, kp=30.0, mask="111")),
+    ("posture", "posture", dict(weight=1.75, kp=10.0, ref="inria_start")),
+    ("momentum", "momentum", dict(weight=1000.0, kp=30.0, mask="000110")),
+    ("bounds", "bounds", dict(weight=10000)),
+    ("actuation_bounds", "actuation-bounds", dict(weight=10000)),
+    ("contact_lfoot", "contact", dict(joint="leg_left_6_joint", **TALOS_CONTACT)),
+    ("contact_rfoot", "contact", dict(joint="leg_right_6_joint", **TALOS_CONTACT)),
+] + [(n, "self-collision", dict(tracked=t, radius=r, weight=w, kp=kp, kd=250.0, margin=0.02, m=0.2)) for n, t, r, w, kp in [
+    ("self_collision-left", "gripper_left_joint", 0.1, 2000, 50.0), ("self_collision-right", "gripper_right_joint", 0.1, 2000, 50.0),
+    ("self_collision-elbow-right", "arm_right_4_joint", 0.15, 1000, 50.0), ("self_collision-elbow-left", "arm_left_4_joint", 0.15, 1000, 150.0),
+    ("self_collision-wrist-right", "arm_right_5_joint", 0.10, 1000, 50.0), ("self_collision-wrist-left", "arm_left_5_joint", 0.10, 1000, 150.0)]]
+
+ICUB_CONTACT = dict(kp=30.0, lxp=0.14, lxn=0.06, lyp=0.045, lyn=0.045, lz=0.065, fmin=5.0, fmax=1500.0, mu=0.3, normal="[0, 0, -1]")
+ICUB = [
+    ("lh", "se3", dict(tracked="l_hand", weight=1.0, kp=30.0, mask="111111")),
+    ("rh", "se3", dict(tracked="r_hand", weight=1.0, kp=30.0, mask="111111")),
+    ("lf", "se3", dict(tracked="l_sole", weight=1000.0, kp=30.0, mask="111111")),
+    ("rf", "se3", dict(tracked="r_sole", weight=10.0, kp=30.0, mask="111111")),
+    ("com", "com", dict(weight=3000.0, kp=50.0, mask="111")),
+    ("momentum", "momentum", dict(weight=1000.0, kp=30.0, mask="000110")),
+    ("posture", "posture", dict(weight=0.05, kp=10.0, ref="start")),
+    ("torso", "se3", dict(tracked="chest", weight=1.0, kp=30.0, mask="000111")),
+    ("head", "se3", dict(tracked="head", weight=10.0, kp=30.0, mask="110111")),
+    ("bounds", "bounds", dict(weight=1000.0)),
+    ("contact_lfoot", "contact", dict(joint="l_sole", **ICUB_CONTACT)),
+    ("contact_rfoot", "contact", dict(joint="r_sole", **ICUB_CONTACT)),
+    ("self_collision-left", "self-collision", dict(tracked="l_hand", radius=0.05, weight=500, kp=50.0, kd=250.0, margin=0.02, m=0.2)),
+    ("self_collision-right", "self-collision", dict(tracked="r_hand", radius=0.05, weight=500, kp=50.0, kd=250.0, margin=0.02, m=0.2)),
+]
+FRANKA = [("ee", "se3", dict(tracked="panda_joint7", weight=100.0, kp=30.0, mask="111111")),
+          ("posture", "posture", dict(weight=0.75, kp=30.0, ref="start"))]
+TIAGO = [("ee", "se3", dict(tracked="gripper_link", weight=1500.0, kp=30.0, mask="111111")),
+         ("head", "se3", dict(tracked="head_2_link", weight=500.0, kp=30.0, mask="000111")),
+         ("posture", "posture", dict(weight=0.1, kp=10.0, ref="start")),
+         ("bounds", "bounds", dict(weight=10000))] + \
+        [(n, "self-collision", dict(tracked=n, radius=0.1, weight=1000, kp=50.0, kd=250.0, margin=0.02, m=0.2))
+         for n in ("sc-gripper", "sc-wrist", "sc-forearm", "sc-elbow")]
+
+ROBOTS = {"talos": (TALOS, 50, 44, True), "icub": (ICUB, 38, 32, True), "franka": (FRANKA, 9, 9, False), "tiago": (TIAGO, 12, 12, False)}
+
+
+def emit_tasks(tasks):
+    out = []
+    for name, typ, fields in tasks:
+        out.append("%s:" % name)
+        out.append("  type: %s" % typ)
+        for k, v in fields.items():
+            out.append("  %s: %s" % (k, v))
+    return "\n".join(out) + "\n"
+
+
+def main():
+    for robot, (tasks, nv, na, fb) in ROBOTS.items():
+        d = os.path.join(ROOT, "configs", robot)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "tasks.yaml"), "w") as f:
+            f.write("# task stack of %s in inria_wbc's tasks.yaml schema (generated by tools/emit_configs.py)\n" % robot)
+            f.write(emit_tasks(tasks))
+        with open(os.path.join(d, "pos_tracker.yaml"), "w") as f:
+            f.write("# CONTROLLER tree (schema of inria_wbc's <robot>_pos_tracker.yaml); nv / na replace the URDF lookup;\n")
+            f.write("# base_path is filled in by the harness (relative paths are resolved against it)\n")
+            f.write("CONTROLLER:\n  name: pos-tracker\n  solver: hip-batched\n  base_path: .\n  tasks: tasks.yaml\n")
+            f.write("  dt: 0.001\n  floating_base: %s\n  closed_loop: false\n  verbose: false\n  nv: %d\n  na: %d\n" % ("true" if fb else "false", nv, na))
+    with open(os.path.join(ROOT, "configs", "talos", "squat.yaml"), "w") as f:
+        f.write("# BEHAVIOR tree of the squat (schema of inria_wbc's etc/talos/squat.yaml)\n")
+        f.write("BEHAVIOR:\n  name: humanoid::move_com\n  trajectory_duration: 2\n  targets: [[0, 0, -0.2]]\n  mask: 001\n  absolute: false\n  loop: true\n")
+
+
+if __name__ == "__main__":
+    main()
