@@ -118,7 +118,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; }; // keep 16-byte alignment
     D.o_J = take(n * D.ldj);
     int rsize = n * (n + 3) / 2 + 2;
-    if (D.n_dense * nv + 8 > rsize) rsize = D.n_dense * nv + 8; // + 8: the 8-row H pass may read past the last row
+    if (D.n_dense * nv + 64 > rsize) rsize = D.n_dense * nv + 64; // + 64: the 4x4 H tiles may read past the last staged row
     D.o_R = take(rsize);
     D.o_M = take(nv * D.ldm);
     D.o_Jc = take(D.k * D.ldc);
@@ -133,6 +133,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     D.o_prm = take(4 * (n + 2));
     D.o_rdinv = take(n + 2); D.o_dinv = take(n + 2); D.o_g = take(n);
     D.o_w = take(D.n_tasks); D.o_b1 = take(D.r1); D.o_q = take(n + 2); D.o_wrow = take(D.n_dense);
+    D.o_red = take(32); D.o_part = take(4 * 128); D.o_stash = take(2 * 128);
     D.o_int = o;
     const int n_int = 2 * (n + 2) + 2 * D.nin2 + (n + 2);
     o += (n_int + 1) / 2 + 2;
@@ -217,7 +218,7 @@ int launch(wbcqp_handle* h, const GroupTable<TI>& tab, int total, int lds_bytes,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         h->max_lds = lds_bytes;
     }
-    hipLaunchKernelGGL(solve_kernel<TI>, dim3(total), dim3(kWave), lds_bytes, stream, tab);
+    hipLaunchKernelGGL(solve_kernel<TI>, dim3(total), dim3(kThreads), lds_bytes, stream, tab);
     HIP_TRY(h, hipGetLastError());
     return WBCQP_OK;
 }
