@@ -35,7 +35,7 @@ extern "C" {
 #define WBCQP_VERSION 100 /* 0.1.0 */
 #define WBCQP_MAX_STRUCTURES 16
 #define WBCQP_MAX_INEQ_BLOCKS 16
-#define WBCQP_MAX_VARS 128 /* n = nv + 12*nc must fit two 64-lane passes */
+#define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: two 64-lane row sets, n + 2 <= 128 */
 
 /* ---- return codes of the API itself ---- */
 typedef enum {

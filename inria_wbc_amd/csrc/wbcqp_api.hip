@@ -77,6 +77,8 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     std::memset(&D, 0, sizeof(D));
     D.nv = st->nv; D.na = st->na; D.nc = st->nc; D.k = 12 * st->nc; D.n = D.nv + D.k; D.nu = D.nv - D.na;
     if (D.n > WBCQP_MAX_VARS) { why = "n = nv + 12 nc exceeds WBCQP_MAX_VARS"; return WBCQP_ERR_UNSUPPORTED; }
+    if (D.nv > 64) { why = "nv exceeds 64 (the dv block is factorised on a 64 x 64 register grid)"; return WBCQP_ERR_UNSUPPORTED; }
+    if (st->n_tasks > kSlot || st->n_dense > kSlot || st->n_bound > kSlot || 6 * st->nc > kSlot) { why = "a per-QP vector exceeds 128 entries"; return WBCQP_ERR_UNSUPPORTED; }
     D.n_dense = st->n_dense; D.n_tasks = st->n_tasks; D.n_sel = st->n_sel; D.n_bound = st->n_bound;
     D.act_bounds = st->act_bounds ? 1 : 0;
     D.neq = D.nu + 6 * D.nc;
@@ -99,6 +101,8 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     }
     if (has_act != (D.act_bounds != 0)) { why = "act_bounds flag and inequality blocks disagree"; return WBCQP_ERR_INVALID; }
     D.nin2 = off;
+    if (D.nin2 > 4 * kSlot) { why = "more than 512 one-sided inequality rows"; return WBCQP_ERR_UNSUPPORTED; }
+    if (D.r1 > 2 * kSlot) { why = "more than 256 level-1 rows"; return WBCQP_ERR_UNSUPPORTED; }
     if (D.neq > D.n) { why = "more equalities than variables"; return WBCQP_ERR_INVALID; }
     for (int r = 0; r < D.n_dense; ++r)
         if (st->dense_row_task[r] < 0 || st->dense_row_task[r] >= D.n_tasks) { why = "dense_row_task out of range"; return WBCQP_ERR_INVALID; }
@@ -113,30 +117,22 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
 
     // ---- LDS layout (doubles) ----
     const int n = D.n, nv = D.nv;
-    D.ldj = odd(n); D.ldm = odd(nv); D.ldc = odd(nv);
+    D.ldj = odd(n); D.ldm = odd(nv); D.ldc = odd(nv); D.ldb = odd(D.neq) + 2; // + 2: 8-wide column groups may read past m
     int o = 0;
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; }; // keep 16-byte alignment
     D.o_J = take(n * D.ldj);
     int rsize = n * (n + 3) / 2 + 2;
-    if (D.n_dense * nv + 64 > rsize) rsize = D.n_dense * nv + 64; // + 64: the 4x4 H tiles may read past the last staged row
+    if (D.n_dense * nv + 64 > rsize) rsize = D.n_dense * nv + 64;
+    if (D.neq > 0 && 256 + (n + 1) * D.ldb + 8 > rsize) rsize = 256 + (n + 1) * D.ldb + 8; // B of the blocked equality phase // + 64: the 4x4 H tiles may read past the last staged row
     D.o_R = take(rsize);
     D.o_M = take(nv * D.ldm);
     D.o_Jc = take(D.k * D.ldc);
     D.o_Ac = take(D.nc * 6 * nv);
-    D.o_h = take(nv);
-    D.o_x = take(n); D.o_np = take(n); D.o_d = take(n); D.o_z = take(n); D.o_xold = take(n);
-    D.o_r = take(n + 2); D.o_u = take(n + 2); D.o_uold = take(n + 2);
-    D.o_s = take(D.nin2);
-    D.o_blb = take(D.n_bound); D.o_bub = take(D.n_bound);
-    D.o_tl = take(D.na); D.o_tu = take(D.na);
-    D.o_bc = take(6 * D.nc);
-    D.o_prm = take(4 * (n + 2));
-    D.o_rdinv = take(n + 2); D.o_dinv = take(n + 2); D.o_g = take(n);
-    D.o_w = take(D.n_tasks); D.o_b1 = take(D.r1); D.o_q = take(n + 2); D.o_wrow = take(D.n_dense);
-    D.o_red = take(32); D.o_part = take(4 * 128); D.o_stash = take(2 * 128);
+    D.o_vec = take(V_COUNT * kSlot);
+    D.o_eqw = take(D.neq > 0 ? (n + 1) * D.ldb + 8 : 0);
+    D.o_eqt = take(D.neq > 0 ? D.neq * (D.neq + 1) + 4 * D.neq + 16 : 0);
     D.o_int = o;
-    const int n_int = 2 * (n + 2) + 2 * D.nin2 + (n + 2);
-    o += (n_int + 1) / 2 + 2;
+    o += kIntCount / 2 + 2;
     D.lds_doubles = o;
 
     std::memset(&L, 0, sizeof(L));

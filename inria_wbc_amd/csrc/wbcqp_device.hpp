@@ -26,6 +26,23 @@ constexpr int kWaves = kThreads / kWave;
 constexpr int kMaxBlocks = 16;
 constexpr int kMaxGroups = 8;
 
+// All small per-QP vectors live at FIXED offsets (multiples of kSlot doubles) from one LDS base, so that the compiler
+// addresses them with immediates instead of keeping ~40 wave-uniform pointers alive in SGPRs (they spilled).
+// Limits that make this legal are checked on the host: n <= 126, n_tasks, n_dense, n_bound, na, 6 nc <= 128,
+// level-1 rows <= 256, one-sided inequality rows <= 512.
+constexpr int kSlot = 128;
+enum VecSlot {
+    V_H = 0, V_X, V_NP, V_D, V_Z, V_XOLD, V_R, V_U, V_UOLD, V_Q, V_G, V_W, V_WROW, V_BLB, V_BUB, V_TL, V_TU, V_BC,
+    V_RDINV, V_DINV, V_RED,
+    V_PRM,              // 2 slots
+    V_B1 = V_PRM + 2,   // 2 slots
+    V_S = V_B1 + 2,     // 4 slots
+    V_STASH = V_S + 4,  // 2 slots
+    V_PART = V_STASH + 2, // 5 slots
+    V_COUNT = V_PART + 5
+};
+constexpr int kIntA = 0, kIntAold = 128, kIntGskip = 256, kIntIai = 384, kIntIaexcl = 896, kIntCount = 1408;
+
 enum { INEQ_BOUNDS = 0, INEQ_ACTUATION = 1, INEQ_FORCE = 2 };
 enum { HQP_UNKNOWN = -1, HQP_OPTIMAL = 0, HQP_INFEASIBLE = 1, HQP_UNBOUNDED = 2, HQP_MAX_ITER = 3, HQP_ERROR = 4 };
 
@@ -44,10 +61,9 @@ struct DevStruct {
     const double *ft;        // [nc][12][6]   F'
     const double *fric_mat, *fric_lb, *fric_ub;
     // LDS layout: leading dimensions and element offsets (in doubles)
-    int ldj, ldm, ldc;
-    int o_J, o_R, o_M, o_Jc, o_Ac, o_h, o_x, o_np, o_d, o_z, o_xold, o_r, o_u, o_uold, o_s;
-    int o_blb, o_bub, o_tl, o_tu, o_bc, o_prm, o_rdinv, o_dinv, o_g, o_w, o_b1, o_q, o_wrow, o_red, o_part, o_stash;
-    int o_int; // int area: A[n+2], Aold[n+2], iai[nin2], iaexcl[nin2], gskip[n+2]
+    int ldj, ldm, ldc, ldb;
+    int o_J, o_R, o_M, o_Jc, o_Ac, o_vec, o_eqw, o_eqt;
+    int o_int; // int area (fixed slots, see kInt*)
     int lds_doubles;
 };
 
@@ -187,19 +203,32 @@ __device__ __forceinline__ double gi_distance(double a, double b)
     return a1 * sqrt(2.0);
 }
 
+// In-kernel phase stamps (diagnostic build only: -DWBCQP_STAMPS). Never compiled into the product library.
+#ifdef WBCQP_STAMPS
+constexpr int kStamps = 20;
+#define STAMP_DECL c.st_prev_ = clock64(); for (int i_ = 0; i_ < kStamps; ++i_) c.st_acc_[i_] = 0;
+#define STAMP(i) { long long now_ = clock64(); c.st_acc_[i] += now_ - c.st_prev_; c.st_prev_ = now_; }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // per-workgroup context: LDS pointers + sizes (all uniform across the 256 threads)
 // ------------------------------------------------------------------------------------------------
 struct Ctx {
     const DevStruct* S;
     int tid, lane, wave;
-    int nv, na, nc, k, n, nu, neq, nin2, ldj, ldm, ldc;
+    int nv, na, nc, k, n, nu, neq, nin2, ldj, ldm, ldc, ldb;
     double *J, *R, *M, *Jc, *Ac, *h, *x, *np, *d, *z, *xold, *r, *u, *uold, *s;
-    double *blb, *bub, *tl, *tu, *bc, *prm, *rdinv, *dinv, *g, *w, *b1, *q, *wrow, *red, *part, *stash;
+    double *blb, *bub, *tl, *tu, *bc, *prm, *rdinv, *dinv, *g, *w, *b1, *q, *wrow, *red, *part, *stash, *eqw, *eqt;
     int *A, *Aold, *iai, *iaexcl, *gskip;
     int iq;
     int rslot; // alternating slot of the block-reduction scratch
     double R_norm;
+#ifdef WBCQP_STAMPS
+    long long st_prev_, st_acc_[kStamps];
+#endif
 };
 
 // ---- workgroup-wide reductions: wave-level DPP reduce, four partials through LDS, one barrier ----
@@ -260,6 +289,9 @@ __device__ __forceinline__ int block_max_int(Ctx& c, int v)
 
 // packed upper-triangular R with one spare slot per column (column j holds rows 0..j+1):
 __device__ __forceinline__ int roff(int j) { return (j * (j + 3)) >> 1; }
+// first structurally non-zero column / one past the last of row i: H is block diagonal (dv block, one 12x12 block per contact)
+__device__ __forceinline__ int blk_begin(int i, int nv) { return (i < nv) ? 0 : nv + 12 * ((i - nv) / 12); }
+__device__ __forceinline__ int blk_end(int i, int nv) { return (i < nv) ? nv : nv + 12 * ((i - nv) / 12) + 12; }
 
 // d = J' np over the support [k0, k1) of np (eiquadprog compute_d).
 // threads 0..127 own column idx for the first half of the support, threads 128..255 for the second half;
@@ -712,15 +744,6 @@ __device__ __forceinline__ void copy_in(const TI* __restrict__ src, double* dst,
     for (; e < len; e += kThreads) dst[e] = (double)src[e];
 }
 
-// In-kernel phase stamps (diagnostic build only: -DWBCQP_STAMPS). Never compiled into the product library.
-#ifdef WBCQP_STAMPS
-constexpr int kStamps = 20;
-#define STAMP_DECL long long st_prev_ = clock64(); long long st_acc_[kStamps] = {};
-#define STAMP(i) { long long now_ = clock64(); st_acc_[i] += now_ - st_prev_; st_prev_ = now_; }
-#else
-#define STAMP_DECL
-#define STAMP(i)
-#endif
 
 // One right-looking Cholesky step on a 16 x 16 thread grid, NB x NB positions per thread: reads the pivot, forms
 // inv = 1/sqrt(pivot) while the other loads are in flight, then T(a,e) -= inv^2 row[a] row[e] for e >= a.
@@ -778,9 +801,363 @@ __device__ __forceinline__ void inv_step(double* T, int ld, const double* fcol, 
         }
 }
 
-// first structurally non-zero column / one past the last of row i: H is block diagonal (dv block, one 12x12 block per contact)
-__device__ __forceinline__ int blk_begin(int i, int nv) { return (i < nv) ? 0 : nv + 12 * ((i - nv) / 12); }
-__device__ __forceinline__ int blk_end(int i, int nv) { return (i < nv) ? nv : nv + 12 * ((i - nv) / 12) + 12; }
+// row sum over the 16 lanes of a DPP row (every lane of the row gets the total)
+__device__ __forceinline__ double row16_sum(double v)
+{
+    WBCQP_ROW_REDUCE(v, op_add)
+    return v;
+}
+
+// One Householder step of the QR of B (n x m, leading dimension c.ldb) on column j.  Thread (column e = j+1+(tid>>4),
+// rows kk = j + (tid&15) + 16 t, t < NT).  The squared norm of column j's tail was left in nrm2[j&1] by the previous
+// step; this step leaves the next one.  Returns false when the column is (numerically) dependent.
+template <int NT>
+__device__ __forceinline__ bool qr_step(Ctx& c, double* Bm, double* tau, double* rdiag, double* nrm2, int j, double v0_prev,
+                                        double& alpha, double& v0)
+{
+    const int n = c.n, m = c.neq, ldb = c.ldb, tid = c.tid;
+    const int kc = tid & 15;
+    const int e = j + 1 + (tid >> 4);
+    const bool ev = e < m;
+    const int es = ev ? e : j;
+    // loads first: the pivot data and this thread's elements of column j and column e
+    const double nrm = nrm2[j & 1];
+    const double x0 = Bm[j * ldb + j];
+    double vk[NT], bk[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int kk = min(j + kc + 16 * t, n - 1);
+        vk[t] = Bm[kk * ldb + j];
+        bk[t] = Bm[kk * ldb + es];
+    }
+    const double inx = rsqrt(nrm);
+    const double nx = (nrm > 0.0) ? nrm * inx : 0.0; // exactly dependent column: alpha = 0 -> reported as redundant
+    alpha = (x0 >= 0.0) ? -nx : nx;
+    v0 = x0 - alpha;
+    const double tj = inx / (nx + fabs(x0));
+    if (kc == 0) vk[0] = v0;
+    double dot = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (j + kc + 16 * t < n) dot = fma(vk[t], bk[t], dot);
+    dot = row16_sum(dot) * tj;
+    double sq = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int kk = j + kc + 16 * t;
+        const double nb_ = fma(-dot, vk[t], bk[t]);
+        if (ev && kk < n) {
+            Bm[kk * ldb + e] = nb_;
+            if (kk > j) sq = fma(nb_, nb_, sq);
+        }
+    }
+    sq = row16_sum(sq);
+    // columns beyond the first 16 (m - j - 1 > 16): generic pass
+    for (int eb = j + 17; eb < m; eb += 16) {
+        const int e2 = eb + (tid >> 4);
+        double d2 = 0.0;
+        if (e2 < m)
+            for (int kk = j + kc; kk < n; kk += 16) d2 = fma((kk == j) ? v0 : Bm[kk * ldb + j], Bm[kk * ldb + e2], d2);
+        d2 = row16_sum(d2) * tj;
+        if (e2 < m)
+            for (int kk = j + kc; kk < n; kk += 16) Bm[kk * ldb + e2] = fma(-d2, (kk == j) ? v0 : Bm[kk * ldb + j], Bm[kk * ldb + e2]);
+    }
+    if (tid == 0) {
+        nrm2[(j + 1) & 1] = sq; // threads 0..15 own column j+1
+        rdiag[j] = alpha;
+        tau[j] = tj;
+        if (j > 0) Bm[(j - 1) * ldb + (j - 1)] = v0_prev; // nobody reads B(j-1,j-1) any more
+    }
+    if (fabs(alpha) <= 2.220446049250313e-16 * c.R_norm) return false;
+    c.R_norm = fmax(c.R_norm, fabs(alpha));
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Equality phase, blocked.  eiquadprog adds the neq equalities one by one (d = J'n, Givens sweep over J, ...): 18
+// full passes over J for Talos.  The same state (J, R, x, u, f) is reached in one go: with N = CE' (n x m) and
+// B = J0' N, a Householder QR  Q' B = [R; 0]  gives J = J0 Q (applied as one rank-m update through the compact WY
+// form Q = I - V T V'), and the equality-constrained minimiser follows from R' y = -(CE x0 + ce0):
+// x = x0 + J[:, :m] y,  u = R^-1 y,  f = f0 + y'y / 2.  J' H J = I and J' N = [R; 0] hold exactly as after m
+// add_constraint calls (R's diagonal signs and the null-space basis differ, which the later steps never see).
+// Returns false on (numerically) redundant equalities -- upstream's REDUNDANT_EQUALITIES.
+// Requires n <= 85, 1 <= m <= 24.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
+{
+    const int n = c.n, m = c.neq, nv = c.nv, nu = c.nu, ldj = c.ldj, ldb = c.ldb, tid = c.tid;
+    double* Nm = c.eqw;        // N = CE' (n x m), later W = J0 V
+    double* Bm = c.R + 256;    // B -> V (lower trapezoid) / R (strict upper), in the unused tail of the R region
+    double* Tm = c.eqt;        // T (m x (m+1))
+    double* tau = Tm + m * (m + 1);
+    double* rdiag = tau + m;
+    double* rhs = rdiag + m;   // later y
+    double* nrm2 = rhs + m;    // [2]
+    const double eps = 2.220446049250313e-16;
+
+    // ---- N = CE': base dynamics rows [M_u | -J_u'], then the contact motion rows [A_c | 0]
+    for (int e2 = tid; e2 < n * m; e2 += kThreads) {
+        const int kk = e2 / m, e = e2 - kk * m;
+        double v;
+        if (e < nu) v = (kk < nv) ? c.M[kk * c.ldm + e] : -c.Jc[(kk - nv) * c.ldc + e];
+        else v = (kk < nv) ? c.Ac[(e - nu) * nv + kk] : 0.0;
+        Nm[kk * ldb + e] = v;
+    }
+    bsync();
+    // ---- rhs_e = -(N(:,e)'x0 + ce0_e): 16 lanes (one DPP row) per equality
+    for (int e0 = 0; e0 < m; e0 += 16) {
+        const int e = e0 + (tid >> 4), kc = tid & 15;
+        double acc = 0.0;
+        if (e < m)
+            for (int kk = kc; kk < n; kk += 16) acc = fma(Nm[kk * ldb + e], c.x[kk], acc);
+        acc = row16_sum(acc);
+        if (e < m && kc == 0) {
+            const double ce0 = (e < nu) ? c.h[e] : -c.bc[e - nu];
+            rhs[e] = -(acc + ce0);
+        }
+    }
+    // ---- B = J0' N: thread (column cidx, group of 8 equalities); J0 is upper triangular and block diagonal
+    {
+        const int eg = tid / 85, cidx = tid - 85 * eg;
+        const int e0 = 8 * eg;
+        if (eg < 3 && cidx < n && e0 < m) {
+            double acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+            const double* Jc0 = c.J + cidx;
+            for (int kk = blk_begin(cidx, nv); kk <= cidx; ++kk) {
+                const double jv = Jc0[kk * ldj];
+                const double* Nr = Nm + kk * ldb + e0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = fma(jv, Nr[q], acc[q]); // reads past m stay inside the row padding / next row
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (e0 + q < m) Bm[cidx * ldb + e0 + q] = acc[q];
+        }
+    }
+    bsync();
+    STAMP(5)
+    // squared norm of column 0
+    {
+        double sq = 0.0;
+        if (tid < n) {
+            const double v = Bm[tid * ldb];
+            sq = v * v;
+        }
+        sq = block_sum(c, sq);
+        if (tid == 0) nrm2[0] = sq;
+        bsync();
+    }
+    // ---- Householder QR of B, one barrier per column. Thread (column e = j+1+(tid>>4), rows k = j + (tid&15) + 16 t).
+    double v0_prev = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const int nt = (n - j + 15) >> 4;
+        double alpha, v0;
+        bool ok;
+        switch (nt) {
+        case 1: ok = qr_step<1>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
+        case 2: ok = qr_step<2>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
+        case 3: ok = qr_step<3>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
+        case 4: ok = qr_step<4>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
+        case 5: ok = qr_step<5>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
+        default: ok = qr_step<6>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break; // n <= 85 -> nt <= 6
+        }
+        if (!ok) return false; // redundant equalities
+        v0_prev = v0;
+        bsync();
+    }
+    if (tid == 0) Bm[(m - 1) * ldb + (m - 1)] = v0_prev;
+    STAMP(6)
+    // ---- R (packed, the active-set factor) from the strict upper part of B and the Householder alphas; then clear
+    //      that part so that B is exactly V
+    for (int e2 = tid; e2 < m * m; e2 += kThreads) {
+        const int i = e2 / m, jj = e2 - i * m;
+        if (i < jj) {
+            c.R[roff(jj) + i] = Bm[i * ldb + jj];
+        }
+        else if (i == jj) {
+            const double a = rdiag[jj];
+            c.R[roff(jj) + jj] = a;
+            c.rdinv[jj] = 1.0 / a;
+        }
+    }
+    bsync();
+    for (int e2 = tid; e2 < m * m; e2 += kThreads) {
+        const int i = e2 / m, jj = e2 - i * m;
+        if (i < jj) Bm[i * ldb + jj] = 0.0;
+    }
+    bsync();
+    const double* Vm = Bm;
+    // ---- G = V'V (upper) into T's storage (one thread per pair), then T by the forward recurrence
+    //      T(0:j,j) = -tau_j T(0:j,0:j) G(0:j,j), T(j,j) = tau_j  (wave 0, lane = row); meanwhile W = J0 V on the others
+    {
+        const int npair = m * (m + 1) / 2;
+        if (tid < npair) {
+            int bb = (int)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
+            while (bb * (bb + 1) / 2 > tid) --bb;
+            while ((bb + 1) * (bb + 2) / 2 <= tid) ++bb;
+            const int aa = tid - bb * (bb + 1) / 2; // aa <= bb
+            double a0 = 0.0, a1 = 0.0;
+            int kk = bb;
+            for (; kk + 2 <= n; kk += 2) {
+                a0 = fma(Vm[kk * ldb + aa], Vm[kk * ldb + bb], a0);
+                a1 = fma(Vm[(kk + 1) * ldb + aa], Vm[(kk + 1) * ldb + bb], a1);
+            }
+            for (; kk < n; ++kk) a0 = fma(Vm[kk * ldb + aa], Vm[kk * ldb + bb], a0);
+            c.part[aa * m + bb] = a0 + a1; // G(aa,bb), m*m <= 576 > part? guarded by the caller: m <= 22
+        }
+    }
+    bsync();
+    STAMP(7)
+    if (c.wave == 0) {
+        // lane = row i of T; the row stays in registers (static indices, guarded by the uniform bound m), G comes from LDS
+        const int i = c.lane;
+        constexpr int MM = 22;
+        double trow[MM];
+#pragma unroll
+        for (int j = 0; j < MM; ++j) {
+            if (j < m) {
+                double acc = 0.0;
+#pragma unroll
+                for (int l = 0; l < j; ++l) acc = fma((l >= i) ? trow[l] : 0.0, c.part[l * m + j], acc);
+                const double tj = tau[j];
+                trow[j] = (i == j) ? tj : ((i < j) ? -tj * acc : 0.0);
+                if (i < m) Tm[i * (m + 1) + j] = trow[j];
+            }
+        }
+    }
+    else {
+        // W = J0 V on waves 1..3: thread (row kidx, group of 8 columns)
+        const int t3 = tid - kWave;      // 0..191
+        const int eg = t3 / 64;          // 0..2
+        const int e0 = 8 * eg;
+        if (e0 < m)
+            for (int kidx = t3 - 64 * eg; kidx < n; kidx += 64) {
+                double acc[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+                const double* Jr = c.J + kidx * ldj;
+                const int cend = blk_end(kidx, nv);
+                for (int cc = kidx; cc < cend; ++cc) {
+                    const double jv = Jr[cc];
+                    const double* Vr = Vm + cc * ldb + e0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = fma(jv, Vr[q], acc[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (e0 + q < m) Nm[kidx * ldb + e0 + q] = acc[q];
+            }
+    }
+    bsync();
+    STAMP(18)
+    // ---- W <- W T (in place: every thread first forms its outputs from the untouched row, then all write)
+    {
+        const int eg = tid / 85, kidx = tid - 85 * eg;
+        const int e0 = 8 * eg;
+        double out[8];
+        const bool act = eg < 3 && kidx < n && e0 < m;
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[q] = 0.0;
+            const double* Wr = Nm + kidx * ldb;
+            for (int l = 0; l < min(m, e0 + 8); ++l) {
+                const double wv = Wr[l];
+                const double* Tr = Tm + l * (m + 1) + e0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) out[q] = fma(wv, Tr[q], out[q]); // T is upper triangular: T(l,e) = 0 for e < l
+            }
+        }
+        bsync();
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (e0 + q < m) Nm[kidx * ldb + e0 + q] = out[q];
+        }
+    }
+    bsync();
+    STAMP(19)
+    // ---- J <- J - (W T) V' in 4 x 4 tiles on waves 1..3, while wave 0 solves y = R'^-1 rhs (forward) and u = R^-1 y
+    //      (backward): lane = index, pivots by readlane
+    if (c.wave == 0) {
+        const int lane = c.lane;
+        double yv = (lane < m) ? rhs[lane] : 0.0;
+        for (int j = 0; j < m; ++j) {
+            const double yj = bcast_lane(yv, j) * c.rdinv[j];
+            if (lane == j) yv = yj;
+            // column j of R' below the diagonal = row j of R right of the diagonal: R(j, lane) = R[roff(lane) + j]
+            if (lane > j && lane < m) yv = fma(-yj, c.R[roff(lane) + j], yv);
+        }
+        if (lane < m) rhs[lane] = yv; // y
+        double uv = yv;
+        for (int j = m - 1; j >= 0; --j) {
+            const double uj = bcast_lane(uv, j) * c.rdinv[j];
+            if (lane == j) uv = uj;
+            if (lane < j) uv = fma(-uj, c.R[roff(j) + lane], uv);
+        }
+        if (lane < m) {
+            c.u[lane] = uv;
+            c.A[lane] = -lane - 1;
+        }
+    }
+    else {
+        const int nt = (n + 3) >> 2;
+        for (int t = tid - kWave; t < nt * nt; t += kThreads - kWave) {
+            const int tk = t / nt, tc = t - tk * nt;
+            const int k0 = 4 * tk, c0 = 4 * tc;
+            const double* wp[4];
+            const double* vp[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                wp[a] = Nm + min(k0 + a, n - 1) * ldb;
+                vp[a] = Vm + min(c0 + a, n - 1) * ldb;
+            }
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+            for (int e = 0; e < m; ++e) {
+                double wk[4], vc[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    wk[a] = wp[a][e];
+                    vc[a] = vp[a][e];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(wk[a], vc[b], acc[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (k0 + a < n && c0 + b < n) c.J[(k0 + a) * ldj + c0 + b] -= acc[a][b];
+        }
+    }
+    bsync();
+    STAMP(13)
+    // ---- x = x0 + J[:, :m] y ; f += y'y / 2
+    {
+        double yy = 0.0;
+        if (tid < m) yy = rhs[tid] * rhs[tid];
+        if (tid >= 128 && tid - 128 < n) {
+            const int kk = tid - 128;
+            const double* Jr = c.J + kk * ldj;
+            double acc = 0.0;
+            for (int e = 0; e < m; ++e) acc = fma(Jr[e], rhs[e], acc);
+            c.x[kk] += acc;
+        }
+        yy = block_sum(c, yy);
+        f_value += 0.5 * yy;
+    }
+    c.iq = m;
+    bsync();
+    return true;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // one QP on one workgroup of 256 threads
@@ -798,16 +1175,21 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     c.nv = S.nv; c.na = S.na; c.nc = S.nc; c.k = S.k; c.n = S.n; c.nu = S.nu;
     c.neq = S.neq; c.nin2 = S.nin2; c.ldj = S.ldj; c.ldm = S.ldm; c.ldc = S.ldc;
     c.J = lds + S.o_J; c.R = lds + S.o_R; c.M = lds + S.o_M; c.Jc = lds + S.o_Jc; c.Ac = lds + S.o_Ac;
-    c.h = lds + S.o_h; c.x = lds + S.o_x; c.np = lds + S.o_np; c.d = lds + S.o_d; c.z = lds + S.o_z;
-    c.xold = lds + S.o_xold; c.r = lds + S.o_r; c.u = lds + S.o_u; c.uold = lds + S.o_uold; c.s = lds + S.o_s;
-    c.blb = lds + S.o_blb; c.bub = lds + S.o_bub; c.tl = lds + S.o_tl; c.tu = lds + S.o_tu; c.bc = lds + S.o_bc;
-    c.prm = lds + S.o_prm; c.rdinv = lds + S.o_rdinv;
-    c.dinv = lds + S.o_dinv; c.g = lds + S.o_g; c.w = lds + S.o_w; c.b1 = lds + S.o_b1; c.q = lds + S.o_q;
-    c.wrow = lds + S.o_wrow; c.red = lds + S.o_red; c.part = lds + S.o_part; c.stash = lds + S.o_stash;
+    {
+        double* vec = lds + S.o_vec;
+        c.h = vec + V_H * kSlot; c.x = vec + V_X * kSlot; c.np = vec + V_NP * kSlot; c.d = vec + V_D * kSlot;
+        c.z = vec + V_Z * kSlot; c.xold = vec + V_XOLD * kSlot; c.r = vec + V_R * kSlot; c.u = vec + V_U * kSlot;
+        c.uold = vec + V_UOLD * kSlot; c.q = vec + V_Q * kSlot; c.g = vec + V_G * kSlot; c.w = vec + V_W * kSlot;
+        c.wrow = vec + V_WROW * kSlot; c.blb = vec + V_BLB * kSlot; c.bub = vec + V_BUB * kSlot; c.tl = vec + V_TL * kSlot;
+        c.tu = vec + V_TU * kSlot; c.bc = vec + V_BC * kSlot; c.rdinv = vec + V_RDINV * kSlot; c.dinv = vec + V_DINV * kSlot;
+        c.red = vec + V_RED * kSlot; c.prm = vec + V_PRM * kSlot; c.b1 = vec + V_B1 * kSlot; c.s = vec + V_S * kSlot;
+        c.stash = vec + V_STASH * kSlot; c.part = vec + V_PART * kSlot;
+    }
+    c.eqw = lds + S.o_eqw; c.eqt = lds + S.o_eqt; c.ldb = S.ldb;
     int* ia = reinterpret_cast<int*>(lds + S.o_int);
     const int n = c.n, nv = c.nv, na = c.na, nc = c.nc, k = c.k, nu = c.nu, neq = c.neq, nin2 = c.nin2;
     const int ldj = c.ldj, ldm = c.ldm, ldc = c.ldc;
-    c.A = ia; c.Aold = ia + (n + 2); c.iai = ia + 2 * (n + 2); c.iaexcl = c.iai + nin2; c.gskip = c.iaexcl + nin2;
+    c.A = ia + kIntA; c.Aold = ia + kIntAold; c.gskip = ia + kIntGskip; c.iai = ia + kIntIai; c.iaexcl = ia + kIntIaexcl;
     c.iq = 0;
     c.R_norm = 1.0;
 
@@ -872,40 +1254,12 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     bsync();
     STAMP(0)
 
-    // ---------------- phase 1: H = sum_r w_r a_r a_r' (+ selection, force-reg, reg), g ----------------
-    // 16 x 16 thread grid, each thread a 4 x 4 tile of the upper triangle of H_vv (tiles strictly below the
-    // diagonal are skipped: only the upper triangle is factorised); the column operand carries the row weight
-    for (int ti0 = 0; ti0 < nv; ti0 += 64) {
-        for (int tj0 = ti0; tj0 < nv; tj0 += 64) {
-            const int ti = ti0 + 4 * (tid >> 4), tj = tj0 + 4 * (tid & 15);
-            if (ti < nv && tj < nv && tj + 3 >= ti) {
-                double acc[4][4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[a][e] = 0.0;
-                for (int r = 0; r < n_dense; ++r) {
-                    const double* Ar = As + r * nv;
-                    const double wr = c.wrow[r];
-                    double ai[4], aj[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        ai[a] = Ar[ti + a]; // reads past nv stay inside the (padded) staging area and are discarded
-                        aj[a] = Ar[tj + a] * wr;
-                    }
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[a][e] = fma(ai[a], aj[e], acc[a][e]);
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (ti + a < nv && tj + e < nv && tj + e >= ti + a) c.J[(ti + a) * ldj + tj + e] = acc[a][e];
-            }
-        }
-    }
+    // ---------------- phases 1-2b in registers: H assembly, Cholesky H = U'U, J = U^-1 ----------------
+    // Thread (ta, te) of a 16 x 16 grid OWNS the strided positions (ta + 16u, te + 16w) of the upper triangle of the
+    // dv block for the whole pipeline: H is accumulated, factorised and inverted in its registers.  Only what another
+    // thread must see travels through LDS: the pivot row of each Cholesky step (written once, final), the pivot column of
+    // each inversion step.  One barrier per step, no element reloads, no masks (the zeros of the strict lower triangle
+    // and of the off-diagonal blocks make dead positions inert).
     // g_j = - sum_r w_r A(r,j) b(r)
     for (int j = tid; j < nv; j += kThreads) {
         const double* Aj = As + j;
@@ -917,6 +1271,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         }
         for (; r < n_dense; ++r) g0 = fma(Aj[r * nv] * c.wrow[r], c.b1[r], g0);
         c.g[j] = -(g0 + g1);
+        c.z[j] = 0.0; // diagonal additions of the selection rows
     }
     for (int m = tid; m < k; m += kThreads) c.g[nv + m] = 0.0;
     bsync();
@@ -924,19 +1279,13 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     for (int sidx = tid; sidx < n_sel; sidx += kThreads) {
         const int col = S.sel_col[sidx];
         const double wt = c.w[S.sel_task[sidx]];
-        c.J[col * ldj + col] += wt;
+        c.z[col] += wt; // distinct columns
         c.g[col] -= wt * c.b1[n_dense + sidx];
     }
-    // force regularisation blocks: H_ff += w F'F (upper triangle), g_f -= w F' b
     for (int ct = 0; ct < nc; ++ct) {
         const double wt = c.w[S.forcereg_task[ct]];
-        const double* FtF = S.ftf + ct * 144;
         const double* Ft = S.ft + ct * 72;
         const double* bb = c.b1 + n_dense + n_sel + 6 * ct;
-        for (int e = tid; e < 144; e += kThreads) {
-            const int a = e / 12, bcol = e % 12;
-            if (bcol >= a) c.J[(nv + 12 * ct + a) * ldj + nv + 12 * ct + bcol] = wt * FtF[e];
-        }
         if (tid < 12) {
             double sacc = 0.0;
 #pragma unroll
@@ -945,104 +1294,217 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         }
     }
     bsync();
-    double c1;
-    {
-        double tr = 0.0;
-        for (int i = tid; i < n; i += kThreads) {
-            double v = c.J[i * ldj + i] + S.hessian_reg;
-            c.J[i * ldj + i] = v;
-            tr += v;
-        }
-        c1 = block_sum(c, tr);
-    }
-    STAMP(1)
-
-    // ---------------- phase 2: Cholesky H = U'U on the upper triangle, right-looking, one barrier per row.
-    // Row j is left UNSCALED (U(j,c) = A(j,c) * dinv[j] is formed on the fly by its consumers): the trailing update
-    // A(i,c) -= A(j,i) A(j,c) dinv[j]^2 needs no second barrier. Only 1/U(j,j) is ever formed. ----------------
-    {
-        double* dummy = c.red + 31;
-        for (int j = 0; j < n; ++j) {
-            const int m = blk_end(j, nv) - j - 1; // trailing size
-            const double* pivp = c.J + j * ldj + j;
-            const double* Aj = pivp + 1;
-            double* At = c.J + (j + 1) * ldj + j + 1;
-            const int nb = (m + 15) >> 4;
-            double inv;
-            if (nb <= 0) inv = rsqrt(*pivp);
-            else if (nb == 1) inv = chol_step<1>(pivp, At, ldj, Aj, m, tid, dummy);
-            else if (nb == 2) inv = chol_step<2>(pivp, At, ldj, Aj, m, tid, dummy);
-            else if (nb == 3) inv = chol_step<3>(pivp, At, ldj, Aj, m, tid, dummy);
-            else if (nb == 4) inv = chol_step<4>(pivp, At, ldj, Aj, m, tid, dummy);
-            else {
-                inv = rsqrt(*pivp);
-                const double inv2 = inv * inv;
-                for (int a = (tid >> 4); a < m; a += 16) {
-                    const double f = Aj[a] * inv2;
-                    for (int e = (tid & 15); e < m; e += 16)
-                        if (e >= a) At[a * ldj + e] = fma(-f, Aj[e], At[a * ldj + e]);
+    double c1, c2;
+    { // nv <= 64 is checked on the host
+        const int ta = tid >> 4, te = tid & 15;
+        double h[4][4];
+        double trace = 0.0;
+        {
+            int ri[4], ci[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ri[u] = min(ta + 16 * u, nv - 1);
+                ci[u] = min(te + 16 * u, nv - 1);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) h[u][w] = 0.0;
+            }
+            for (int r = 0; r < n_dense; ++r) {
+                const double* Ar = As + r * nv;
+                const double wr = c.wrow[r];
+                double ai[4], aj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ai[u] = Ar[ri[u]];
+                    aj[u] = Ar[ci[u]] * wr;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int w = u; w < 4; ++w) h[u][w] = fma(ai[u], aj[w], h[u][w]);
+            }
+            if (ta == te) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = ta + 16 * u;
+                    if (i < nv) {
+                        h[u][u] += c.z[i] + S.hessian_reg;
+                        trace += h[u][u];
+                    }
                 }
             }
-            if (tid == 0) c.dinv[j] = inv;
-            bsync();
         }
-    }
-    STAMP(2)
-
-    // ---------------- phase 2b: J = U^-1 in place on the upper triangle (U = rows of the buffer times dinv).
-    // Step p: every (c,i) with c < p < i in p's block gets Y(c,i) -= U(p,i) J(c,p), and (p,i) becomes -U(p,i) dinv[p];
-    // row p is stashed one step ahead so that its readers never race with that overwrite. Columns stay unscaled until
-    // the end: J(c,p) = Y(c,p) dinv[p]. ----------------
-    {
-        if (tid > 0 && tid < blk_end(0, nv)) c.stash[tid] = c.J[tid] * c.dinv[0];
-        bsync();
-        for (int p = 0; p < n; ++p) {
-            const int bs = blk_begin(p, nv), bend = blk_end(p, nv);
-            const double dp = c.dinv[p];
-            const double* Up = c.stash + (p & 1) * 128;
-            const int nrow = p - bs;      // rows c in [bs, p)
-            const int ni = bend - p - 1;  // columns i in (p, bend)
-            {
-                // Y(c,i) -= (Y(c,p) dp) U(p,i): column p of the block (stride ldj) times the stashed row p
-                double* Yt = c.J + bs * ldj + p + 1;
-                const double* fcol = c.J + bs * ldj + p; // element a at fcol[a * ldj]
-                double* dummy = c.red + 31;
-                const int nb = (max(nrow, ni) + 15) >> 4;
-                if (nb == 1) inv_step<1>(Yt, ldj, fcol, Up + p + 1, dp, nrow, ni, tid, dummy);
-                else if (nb == 2) inv_step<2>(Yt, ldj, fcol, Up + p + 1, dp, nrow, ni, tid, dummy);
-                else if (nb == 3) inv_step<3>(Yt, ldj, fcol, Up + p + 1, dp, nrow, ni, tid, dummy);
-                else if (nb == 4) inv_step<4>(Yt, ldj, fcol, Up + p + 1, dp, nrow, ni, tid, dummy);
-                else
-                    for (int a = (tid >> 4); a < nrow; a += 16) {
-                        const double f = fcol[a * ldj] * dp;
-                        for (int e = (tid & 15); e < ni; e += 16) Yt[a * ldj + e] = fma(-f, Up[p + 1 + e], Yt[a * ldj + e]);
+        STAMP(1)
+        // publishes row jn (final after step jn-1): strict upper part into the J buffer, the pivot into q[jn]
+        auto publish_row = [&](int jn) {
+            if (ta == (jn & 15)) {
+                const int us = jn >> 4;
+                double* Jr = c.J + jn * ldj;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u == us) {
+#pragma unroll
+                        for (int w = u; w < 4; ++w) {
+                            const int cc = te + 16 * w;
+                            if (cc > jn && cc < nv) Jr[cc] = h[u][w];
+                            else if (cc == jn) c.q[jn] = h[u][w];
+                        }
                     }
             }
-            // row p itself: (p,i) := -U(p,i) dp
-            if (tid < ni) c.J[(size_t)p * ldj + p + 1 + tid] = -Up[p + 1 + tid] * dp;
-            // stash row p+1 for the next step (rows > p are still untouched Cholesky rows)
-            if (p + 1 < n && tid >= 128) {
-                const int i2 = p + 2 + (tid - 128);
-                if (i2 < blk_end(p + 1, nv)) c.stash[((p + 1) & 1) * 128 + i2] = c.J[(size_t)(p + 1) * ldj + i2] * c.dinv[p + 1];
+        };
+        publish_row(0);
+        for (int j = 0; j < nv; ++j) {
+            bsync();
+            const double* Jr = c.J + j * ldj;
+            const double piv = c.q[j];
+            double fa[4], fe[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                fa[u] = Jr[ta + 16 * u]; // columns <= j of row j are zero (diagonal kept in q[]): rows <= j are never touched again
+                fe[u] = Jr[te + 16 * u];
+            }
+            const double inv = rsqrt(piv);
+            const double inv2 = inv * inv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double f = fa[u] * inv2;
+#pragma unroll
+                for (int w = u; w < 4; ++w) h[u][w] = fma(-f, fe[w], h[u][w]);
+            }
+            if (tid == 0) c.dinv[j] = inv;
+            if (j + 1 < nv) publish_row(j + 1);
+        }
+        STAMP(2)
+        // ---- J = U^-1: step p updates Y(r,q) -= U(p,q) J(r,p) for r < p < q; row p itself restarts from zero with the
+        //      unit pivot (Y(p,q) = -U(p,q) dinv[p]).  colb = column p as the readers need it: Y(r,p) (r < p), 1 (r = p), 0 (r > p)
+        auto publish_col = [&](int pn) {
+            if (te == (pn & 15)) {
+                const int ws = pn >> 4;
+                double* colb = c.stash + (pn & 1) * 128;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (w == ws) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int r = ta + 16 * u;
+                            double v = 0.0;
+                            if (u <= w && r < pn) v = h[u][w];
+                            if (r == pn) v = 1.0;
+                            colb[r] = v;
+                        }
+                    }
+            }
+        };
+        publish_col(0);
+        for (int p = 0; p < nv; ++p) {
+            bsync();
+            const double dp = c.dinv[p];
+            const double dp2 = dp * dp;
+            const double* Jr = c.J + p * ldj;
+            const double* colb = c.stash + (p & 1) * 128;
+            double fr[4], fq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                fr[u] = colb[ta + 16 * u] * dp2;
+                fq[u] = Jr[te + 16 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool isp = (ta + 16 * u == p);
+#pragma unroll
+                for (int w = u; w < 4; ++w) h[u][w] = fma(-fr[u], fq[w], isp ? 0.0 : h[u][w]);
+            }
+            if (p + 1 < nv) publish_col(p + 1);
+        }
+        bsync();
+        // final: J(r,q) = Y(r,q) dinv[q], J(r,r) = dinv[r]
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = u; w < 4; ++w) {
+                const int r = ta + 16 * u, q = te + 16 * w;
+                if (q < nv && r < q) c.J[r * ldj + q] = h[u][w] * c.dinv[q];
+                else if (r == q && r < nv) c.J[r * ldj + r] = c.dinv[r];
+            }
+        // ---- the 12 x 12 force-regularisation blocks, two contacts at a time, same scheme with one position per thread
+        for (int ct0 = 0; ct0 < nc; ct0 += 2) {
+            double hf[2];
+            int fb[2];
+            bool cv[2];
+            const bool mine = ta < 12 && te < 12 && te >= ta;
+#pragma unroll
+            for (int z2 = 0; z2 < 2; ++z2) {
+                const int ct = ct0 + z2;
+                cv[z2] = ct < nc;
+                const int cs = cv[z2] ? ct : ct0;
+                fb[z2] = nv + 12 * cs;
+                const double wt = c.w[S.forcereg_task[cs]];
+                hf[z2] = mine ? wt * S.ftf[cs * 144 + ta * 12 + te] : 0.0;
+                if (mine && ta == te) {
+                    hf[z2] += S.hessian_reg;
+                    if (cv[z2]) trace += hf[z2];
+                }
+            }
+            auto pub_row = [&](int sn) {
+                if (mine && ta == sn) {
+#pragma unroll
+                    for (int z2 = 0; z2 < 2; ++z2)
+                        if (cv[z2]) {
+                            if (te > sn) c.J[(fb[z2] + sn) * ldj + fb[z2] + te] = hf[z2];
+                            else c.q[fb[z2] + sn] = hf[z2];
+                        }
+                }
+            };
+            pub_row(0);
+            for (int sidx = 0; sidx < 12; ++sidx) {
+                bsync();
+#pragma unroll
+                for (int z2 = 0; z2 < 2; ++z2) {
+                    const double* Jr = c.J + (fb[z2] + sidx) * ldj + fb[z2];
+                    const double piv = c.q[fb[z2] + sidx];
+                    const double fa_ = Jr[min(ta, 11)], fe_ = Jr[min(te, 11)];
+                    const double inv = rsqrt(piv);
+                    hf[z2] = fma(-(fa_ * inv * inv), fe_, hf[z2]);
+                    if (tid == 0 && cv[z2]) c.dinv[fb[z2] + sidx] = inv;
+                }
+                if (sidx + 1 < 12) pub_row(sidx + 1);
+            }
+            auto pub_col = [&](int pn) {
+                if (te == pn && ta < 12) {
+#pragma unroll
+                    for (int z2 = 0; z2 < 2; ++z2) {
+                        double v = 0.0;
+                        if (ta < pn) v = hf[z2];
+                        if (ta == pn) v = 1.0;
+                        c.stash[(pn & 1) * 128 + 16 * z2 + ta] = v;
+                    }
+                }
+            };
+            pub_col(0);
+            for (int p = 0; p < 12; ++p) {
+                bsync();
+#pragma unroll
+                for (int z2 = 0; z2 < 2; ++z2) {
+                    const double dp = c.dinv[fb[z2] + p];
+                    const double fr_ = c.stash[(p & 1) * 128 + 16 * z2 + min(ta, 11)] * dp * dp;
+                    const double fq_ = c.J[(fb[z2] + p) * ldj + fb[z2] + min(te, 11)];
+                    hf[z2] = fma(-fr_, fq_, (ta == p) ? 0.0 : hf[z2]);
+                }
+                if (p + 1 < 12) pub_col(p + 1);
             }
             bsync();
-        }
-        // finalise: scale columns, set the diagonal (the strict lower triangle was never written: still zero)
-        for (int e = tid; e < n * n; e += kThreads) {
-            const int i = e / n, cc = e - i * n;
-            double* pj = c.J + (size_t)i * ldj + cc;
-            if (cc > i) {
-                if (cc < blk_end(i, nv)) *pj = *pj * c.dinv[cc];
+            if (mine) {
+#pragma unroll
+                for (int z2 = 0; z2 < 2; ++z2)
+                    if (cv[z2]) {
+                        const int r = fb[z2] + ta, q = fb[z2] + te;
+                        c.J[r * ldj + q] = (ta == te) ? c.dinv[r] : hf[z2] * c.dinv[q];
+                    }
             }
-            else if (cc == i)
-                *pj = c.dinv[i];
         }
-    }
-    double c2;
-    {
-        double tr = 0.0;
-        for (int i = tid; i < n; i += kThreads) tr += c.dinv[i];
-        c2 = block_sum(c, tr);
+        c1 = block_sum(c, trace);
+        double tr2 = 0.0;
+        for (int i = tid; i < n; i += kThreads) tr2 += c.dinv[i];
+        c2 = block_sum(c, tr2);
     }
     STAMP(3)
 
@@ -1074,7 +1536,12 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     int iter = 0;
 
     // ---------------- phase 3: equality constraints ----------------
-    for (int i = 0; i < neq && status == -2; ++i) {
+    const bool blocked_eq = (neq >= 1 && neq <= 22 && n <= 85);
+    if (blocked_eq) {
+        if (!equality_phase_blocked(c, f_value)) status = HQP_ERROR; // redundant equalities
+        STAMP(8)
+    }
+    for (int i = 0; i < neq && status == -2 && !blocked_eq; ++i) {
         int k0, k1;
         double ce0;
         build_eq_row(c, i, k0, k1, ce0);
@@ -1295,7 +1762,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
 #ifdef WBCQP_STAMPS
     STAMP(17)
     if (tid == 0 && ga.dbg)
-        for (int i = 0; i < kStamps; ++i) ga.dbg[qp * kStamps + i] = st_acc_[i];
+        for (int i = 0; i < kStamps; ++i) ga.dbg[qp * kStamps + i] = c.st_acc_[i];
 #endif
 }
 
