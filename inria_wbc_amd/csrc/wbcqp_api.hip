@@ -78,6 +78,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     D.nv = st->nv; D.na = st->na; D.nc = st->nc; D.k = 12 * st->nc; D.n = D.nv + D.k; D.nu = D.nv - D.na;
     if (D.n > WBCQP_MAX_VARS) { why = "n = nv + 12 nc exceeds WBCQP_MAX_VARS"; return WBCQP_ERR_UNSUPPORTED; }
     if (D.nv > 64) { why = "nv exceeds 64 (the dv block is factorised on a 64 x 64 register grid)"; return WBCQP_ERR_UNSUPPORTED; }
+    if (st->nc > 15) { why = "more than 15 contacts"; return WBCQP_ERR_UNSUPPORTED; }
     if (st->n_tasks > kSlot || st->n_dense > kSlot || st->n_bound > kSlot || 6 * st->nc > kSlot) { why = "a per-QP vector exceeds 128 entries"; return WBCQP_ERR_UNSUPPORTED; }
     D.n_dense = st->n_dense; D.n_tasks = st->n_tasks; D.n_sel = st->n_sel; D.n_bound = st->n_bound;
     D.act_bounds = st->act_bounds ? 1 : 0;
@@ -325,6 +326,19 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     UP(fric_mat, st->fric_mat, nc * 17 * 12);
     UP(fric_lb, st->fric_lb, nc * 17);
     UP(fric_ub, st->fric_ub, nc * 17);
+    {
+        std::vector<int> meta((size_t)D.nin2 + 1, 0);
+        for (int b = 0; b < D.n_blocks; ++b) {
+            const int rows = D.blk_rows[b], off = D.blk_off[b], kind = D.blk_kind[b];
+            for (int r = 0; r < rows; ++r) {
+                const int col = (kind == WBCQP_INEQ_BOUNDS) ? st->bound_col[r] : 0;
+                const int ct = (kind == WBCQP_INEQ_FORCE) ? D.blk_arg[b] : 0;
+                meta[off + r] = row_meta_pack(kind, 0, r, ct, col);
+                meta[off + rows + r] = row_meta_pack(kind, 1, r, ct, col);
+            }
+        }
+        UP(rowmeta, meta.data(), D.nin2);
+    }
 #undef UP
     void* dv = nullptr;
     HIP_TRY(h, hipMalloc(&dv, sizeof(DevStruct)));

@@ -41,7 +41,9 @@ enum VecSlot {
     V_PART = V_STASH + 2, // 5 slots
     V_COUNT = V_PART + 5
 };
-constexpr int kIntA = 0, kIntAold = 128, kIntGskip = 256, kIntIai = 384, kIntIaexcl = 896, kIntCount = 1408;
+constexpr int kIntA = 0, kIntAold = 128, kIntGskip = 256, kIntIai = 384, kIntIaexcl = 896, kIntMeta = 1408, kIntCount = 1920;
+// packed row descriptor: bits 0-1 kind, bit 2 negated copy (-A row), bits 3-10 local row, bits 11-14 contact, bits 15-22 column
+__host__ __device__ inline int row_meta_pack(int kind, int neg, int rr, int ct, int col) { return kind | (neg << 2) | (rr << 3) | (ct << 11) | (col << 15); }
 
 enum { INEQ_BOUNDS = 0, INEQ_ACTUATION = 1, INEQ_FORCE = 2 };
 enum { HQP_UNKNOWN = -1, HQP_OPTIMAL = 0, HQP_INFEASIBLE = 1, HQP_UNBOUNDED = 2, HQP_MAX_ITER = 3, HQP_ERROR = 4 };
@@ -60,6 +62,7 @@ struct DevStruct {
     const double *ftf;       // [nc][12][12]  F'F,  F = diag(w_f) T
     const double *ft;        // [nc][12][6]   F'
     const double *fric_mat, *fric_lb, *fric_ub;
+    const int* rowmeta;      // [nin2] packed descriptor of every one-sided inequality row (see row_meta_*)
     // LDS layout: leading dimensions and element offsets (in doubles)
     int ldj, ldm, ldc, ldb;
     int o_J, o_R, o_M, o_Jc, o_Ac, o_vec, o_eqw, o_eqt;
@@ -222,7 +225,7 @@ struct Ctx {
     int nv, na, nc, k, n, nu, neq, nin2, ldj, ldm, ldc, ldb;
     double *J, *R, *M, *Jc, *Ac, *h, *x, *np, *d, *z, *xold, *r, *u, *uold, *s;
     double *blb, *bub, *tl, *tu, *bc, *prm, *rdinv, *dinv, *g, *w, *b1, *q, *wrow, *red, *part, *stash, *eqw, *eqt;
-    int *A, *Aold, *iai, *iaexcl, *gskip;
+    int *A, *Aold, *iai, *iaexcl, *gskip, *meta;
     int iq;
     int rslot; // alternating slot of the block-reduction scratch
     double R_norm;
@@ -242,21 +245,24 @@ __device__ __forceinline__ double block_sum(Ctx& c, double v)
     c.rslot ^= 1;
     return t;
 }
-__device__ __forceinline__ void block_sum3(Ctx& c, double& a, double& b, double& e)
+__device__ __forceinline__ void block_sum4(Ctx& c, double& a, double& b, double& e, double& f)
 {
     a = wave_sum(a);
     b = wave_sum(b);
     e = wave_sum(e);
+    f = wave_sum(f);
     double* slot = c.red + c.rslot * 16;
     if (c.lane == 0) {
         slot[c.wave] = a;
         slot[4 + c.wave] = b;
         slot[8 + c.wave] = e;
+        slot[12 + c.wave] = f;
     }
     bsync();
     a = (slot[0] + slot[1]) + (slot[2] + slot[3]);
     b = (slot[4] + slot[5]) + (slot[6] + slot[7]);
     e = (slot[8] + slot[9]) + (slot[10] + slot[11]);
+    f = (slot[12] + slot[13]) + (slot[14] + slot[15]);
     c.rslot ^= 1;
 }
 __device__ __forceinline__ ValIdx block_argmin(Ctx& c, ValIdx a)
@@ -285,6 +291,13 @@ __device__ __forceinline__ int block_max_int(Ctx& c, int v)
     for (int w = 1; w < kWaves; ++w) r = max(r, __double2loint(slot[w]));
     c.rslot ^= 1;
     return r;
+}
+
+// row sum over the 16 lanes of a DPP row (every lane of the row gets the total)
+__device__ __forceinline__ double row16_sum(double v)
+{
+    WBCQP_ROW_REDUCE(v, op_add)
+    return v;
 }
 
 // packed upper-triangular R with one spare slot per column (column j holds rows 0..j+1):
@@ -330,9 +343,10 @@ __device__ __forceinline__ void compute_d_unit(Ctx& c, int row, double sign)
 
 // z = J[:, iq:] d[iq:] (update_z) on waves 0..2 (each a third of the columns, both row sets), and
 // r = R[:iq,:iq]^-1 d[:iq] (update_r) on wave 3: column-oriented back substitution, the pivot travels by
-// readlane, 1/R(j,j) and the column entries of four steps are fetched ahead of the dependent chain.
-// Ends with barriers: z and r are visible to every thread on return.
-__device__ __forceinline__ void update_z_r(Ctx& c)
+// readlane, 1/R(j,j) and the column entries of four steps are fetched ahead of the dependent chain.  Only r[rlo:iq] is
+// formed: the inequality loop passes rlo = neq, because r of the equality rows only feeds the equality multipliers,
+// which are neither an output nor an input of any decision.  Ends with barriers: z and r are visible on return.
+__device__ __forceinline__ void update_z_r(Ctx& c, int rlo)
 {
     const int n = c.n, ldj = c.ldj, lane = c.lane, iq = c.iq;
     if (c.wave < 3) {
@@ -367,7 +381,7 @@ __device__ __forceinline__ void update_z_r(Ctx& c)
             if (has1) c.part[c.wave * 128 + k1] = a1 + b1;
         }
     }
-    else if (iq > 0) {
+    else if (iq > rlo) {
         double v0 = (lane < iq) ? c.d[lane] : 0.0;
         double v1 = (lane + kWave < iq) ? c.d[lane + kWave] : 0.0;
         auto step = [&](int j, double rd, double ra, double rb) {
@@ -378,7 +392,7 @@ __device__ __forceinline__ void update_z_r(Ctx& c)
             if (lane + kWave < j) v1 = fma(-rj, rb, v1);
         };
         int j = iq - 1;
-        for (; j >= 3; j -= 4) {
+        for (; j >= rlo + 3; j -= 4) {
             double rd[4], ra[4], rb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -391,7 +405,7 @@ __device__ __forceinline__ void update_z_r(Ctx& c)
 #pragma unroll
             for (int u = 0; u < 4; ++u) step(j - u, rd[u], ra[u], rb[u]);
         }
-        for (; j >= 0; --j) {
+        for (; j >= rlo; --j) {
             const double* Rc = c.R + roff(j);
             step(j, c.rdinv[j], Rc[min(lane, j)], Rc[min(lane + kWave, j)]);
         }
@@ -496,6 +510,60 @@ __device__ __forceinline__ bool add_constraint(Ctx& c)
     bsync();
     if (fabs(diq) <= 2.220446049250313e-16 * c.R_norm) return false; // degenerate
     c.R_norm = fmax(c.R_norm, fabs(diq));
+    return true;
+}
+
+// add_constraint, Householder form.  eiquadprog zeroes d[iq+1:] with a chain of n-iq-1 Givens rotations of J's columns (a
+// sequential sweep); one reflector H = I - tau v v' (v = d[iq:] - alpha e_0) spans the same subspaces, and its product
+// with J needs no new matvec: J[:, iq:] v = z - alpha J[:, iq] with z = J[:, iq:] d[iq:] from update_z.  dn2 = |d[iq:]|^2.
+// The new column of R is [d[:iq]; alpha].  Returns false when the constraint is (numerically) dependent.
+__device__ __forceinline__ bool add_constraint_hh(Ctx& c, double dn2)
+{
+    const int n = c.n, ldj = c.ldj, iq = c.iq, tid = c.tid;
+    const double diq = c.d[iq];
+    double alpha = diq;
+    if (iq + 1 < n && dn2 > 0.0) {
+        const double inx = rsqrt(dn2);
+        const double nx = dn2 * inx;
+        alpha = (diq >= 0.0) ? -nx : nx;
+        const double v0 = diq - alpha;
+        const double tau = inx / (nx + fabs(diq));
+        // w_k = tau (z_k - alpha J(k,iq)) for every row, published before anybody touches column iq
+        if (tid < n) c.part[tid] = tau * (c.z[tid] - alpha * c.J[tid * ldj + iq]);
+        bsync();
+        // J(k,c) -= w_k v_c: thread (row k = tid & 127, half of the columns)
+        const int k = tid & 127, half = tid >> 7;
+        if (k < n) {
+            const int span = n - iq;
+            const int ca = iq + half * ((span + 1) >> 1), cb = half ? n : iq + ((span + 1) >> 1);
+            double* Jk = c.J + k * ldj;
+            const double wk = c.part[k];
+            int cc = ca;
+            if (cc == iq && cc < cb) {
+                Jk[cc] = fma(-wk, v0, Jk[cc]);
+                ++cc;
+            }
+            for (; cc + 4 <= cb; cc += 4) {
+                const double d0 = c.d[cc], d1 = c.d[cc + 1], d2 = c.d[cc + 2], d3 = c.d[cc + 3];
+                const double j0 = Jk[cc], j1 = Jk[cc + 1], j2 = Jk[cc + 2], j3 = Jk[cc + 3];
+                Jk[cc] = fma(-wk, d0, j0);
+                Jk[cc + 1] = fma(-wk, d1, j1);
+                Jk[cc + 2] = fma(-wk, d2, j2);
+                Jk[cc + 3] = fma(-wk, d3, j3);
+            }
+            for (; cc < cb; ++cc) Jk[cc] = fma(-wk, c.d[cc], Jk[cc]);
+        }
+    }
+    double* Rc = c.R + roff(iq);
+    for (int i = tid; i < iq; i += kThreads) Rc[i] = c.d[i];
+    if (tid == kThreads - 1) {
+        Rc[iq] = alpha;
+        c.rdinv[iq] = 1.0 / alpha;
+    }
+    c.iq = iq + 1;
+    bsync();
+    if (fabs(alpha) <= 2.220446049250313e-16 * c.R_norm) return false; // degenerate
+    c.R_norm = fmax(c.R_norm, fabs(alpha));
     return true;
 }
 
@@ -629,22 +697,19 @@ __device__ __forceinline__ void build_eq_row(Ctx& c, int i, int& k0, int& k1, do
     }
 }
 
-// Decodes CI row ip: builds np in LDS, returns support, ci0, and for bound rows the column (unit_col < 0 if not a unit row)
+// Decodes CI row ip from its packed descriptor: builds np in LDS, returns support, ci0, and for bound rows the column
+// (unit_col < 0 if not a unit row)
 __device__ __forceinline__ void build_ineq_row(Ctx& c, int ip, int& k0, int& k1, double& ci0, int& unit_col, double& unit_sign)
 {
     const DevStruct& S = *c.S;
     const int nv = c.nv, k = c.k, nu = c.nu, tid = c.tid;
-    int b = 0;
-    while (b + 1 < S.n_blocks && ip >= S.blk_off[b] + 2 * S.blk_rows[b]) ++b;
-    const int rows = S.blk_rows[b], local = ip - S.blk_off[b];
-    const bool neg = local >= rows;
-    const int rr = neg ? local - rows : local;
+    const int mt = c.meta[ip];
+    const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
+    const bool neg = (mt >> 2) & 1;
     const double sg = neg ? -1.0 : 1.0;
-    const int kind = S.blk_kind[b];
     unit_col = -1;
     unit_sign = sg;
     if (kind == INEQ_BOUNDS) {
-        const int col = S.bound_col[rr];
         if (tid == 0) c.np[col] = sg;
         k0 = col;
         k1 = col + 1;
@@ -660,13 +725,92 @@ __device__ __forceinline__ void build_ineq_row(Ctx& c, int ip, int& k0, int& k1,
         ci0 = neg ? c.tu[rr] : -c.tl[rr];
     }
     else {
-        const int ct = S.blk_arg[b];
-        const double* B = S.fric_mat + ((size_t)ct * 17 + rr) * 12;
+        const double* B = S.fric_mat + (ct * 17 + rr) * 12;
         if (tid < 12) c.np[nv + 12 * ct + tid] = sg * B[tid];
         k0 = nv + 12 * ct;
         k1 = k0 + 12;
         ci0 = neg ? S.fric_ub[ct * 17 + rr] : -S.fric_lb[ct * 17 + rr];
     }
+}
+
+// What one thread keeps about the (at most two) rows of s it owns: rows tid and tid + 256
+struct OwnRows {
+    int meta[2];
+    double ci0[2];
+    double coef[2][12]; // friction rows only
+};
+__device__ __forceinline__ void own_rows_init(Ctx& c, OwnRows& o)
+{
+    const DevStruct& S = *c.S;
+#pragma unroll
+    for (int z2 = 0; z2 < 2; ++z2) {
+        const int i = c.tid + z2 * kThreads;
+        o.meta[z2] = -1;
+        o.ci0[z2] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 12; ++m) o.coef[z2][m] = 0.0;
+        if (i < c.nin2) {
+            const int mt = c.meta[i];
+            const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15;
+            const bool neg = (mt >> 2) & 1;
+            o.meta[z2] = mt;
+            if (kind == INEQ_BOUNDS) o.ci0[z2] = neg ? c.bub[rr] : -c.blb[rr];
+            else if (kind == INEQ_ACTUATION) o.ci0[z2] = neg ? c.tu[rr] : -c.tl[rr];
+            else {
+                o.ci0[z2] = neg ? S.fric_ub[ct * 17 + rr] : -S.fric_lb[ct * 17 + rr];
+                const double* B = S.fric_mat + (ct * 17 + rr) * 12;
+#pragma unroll
+                for (int m = 0; m < 12; ++m) o.coef[z2][m] = neg ? -B[m] : B[m];
+            }
+        }
+    }
+}
+
+// tau' = M_a dv - J_a' f into c.part[0..na): 16 lanes (one DPP row) per actuated row, partial sums meet inside the row
+__device__ __forceinline__ void actuation_product(Ctx& c)
+{
+    const int nv = c.nv, nu = c.nu, n = c.n, na = c.na;
+    const int kc = c.tid & 15;
+    for (int r0 = 0; r0 < na; r0 += 16) {
+        const int rr = r0 + (c.tid >> 4);
+        const int row = nu + min(rr, na - 1);
+        const double* Mr = c.M + row * c.ldm;
+        double acc = 0.0;
+        for (int j = kc; j < nv; j += 16) acc = fma(Mr[j], c.x[j], acc);
+        for (int j = nv + ((kc - nv) & 15); j < n; j += 16) acc = fma(-c.Jc[(j - nv) * c.ldc + row], c.x[j], acc);
+        acc = row16_sum(acc);
+        if (kc == 0 && rr < na) c.part[rr] = acc;
+    }
+}
+
+// s = CI x + ci0 for the rows this thread owns (needs actuation_product + barrier first). Returns sum of min(s, 0).
+__device__ __forceinline__ double compute_s_owned(Ctx& c, const OwnRows& o)
+{
+    double psi = 0.0;
+#pragma unroll
+    for (int z2 = 0; z2 < 2; ++z2) {
+        const int mt = o.meta[z2];
+        if (mt >= 0) {
+            const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
+            const bool neg = (mt >> 2) & 1;
+            double v;
+            if (kind == INEQ_BOUNDS) v = neg ? -c.x[col] : c.x[col];
+            else if (kind == INEQ_ACTUATION) v = neg ? -c.part[rr] : c.part[rr];
+            else {
+                const double* f = c.x + c.nv + 12 * ct;
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < 12; ++m) a = fma(o.coef[z2][m], f[m], a);
+                v = a;
+            }
+            v += o.ci0[z2];
+            const int i = c.tid + z2 * kThreads;
+            c.s[i] = v;
+            c.iaexcl[i] = 1;
+            psi += fmin(0.0, v);
+        }
+    }
+    return psi;
 }
 
 // s = CI x + ci0 for every one-sided row, from the structure of each block. Ends with a barrier.
@@ -799,13 +943,6 @@ __device__ __forceinline__ void inv_step(double* T, int ld, const double* fcol, 
             double* dst = (a < na && e < ne) ? (T + a * ld + e) : dummy;
             *dst = fma(-(fa[u] * dp), fe[w], v[u][w]);
         }
-}
-
-// row sum over the 16 lanes of a DPP row (every lane of the row gets the total)
-__device__ __forceinline__ double row16_sum(double v)
-{
-    WBCQP_ROW_REDUCE(v, op_add)
-    return v;
 }
 
 // One Householder step of the QR of B (n x m, leading dimension c.ldb) on column j.  Thread (column e = j+1+(tid>>4),
@@ -1190,6 +1327,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     const int n = c.n, nv = c.nv, na = c.na, nc = c.nc, k = c.k, nu = c.nu, neq = c.neq, nin2 = c.nin2;
     const int ldj = c.ldj, ldm = c.ldm, ldc = c.ldc;
     c.A = ia + kIntA; c.Aold = ia + kIntAold; c.gskip = ia + kIntGskip; c.iai = ia + kIntIai; c.iaexcl = ia + kIntIaexcl;
+    c.meta = ia + kIntMeta;
     c.iq = 0;
     c.R_norm = 1.0;
 
@@ -1238,6 +1376,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         }
     }
     for (int r = tid; r < n_dense; r += kThreads) c.wrow[r] = c.w[S.dense_row_task[r]];
+    for (int i = tid; i < nin2; i += kThreads) c.meta[i] = S.rowmeta[i];
     // Jc = T' A_c  (12 x nv per contact)
     for (int e = tid; e < k * nv; e += kThreads) {
         const int m = e / nv, j = e - m * nv;
@@ -1334,86 +1473,104 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
             }
         }
         STAMP(1)
-        // publishes row jn (final after step jn-1): strict upper part into the J buffer, the pivot into q[jn]
-        auto publish_row = [&](int jn) {
+        // publishes row jn (final after step jn-1): strict upper part into the J buffer; the owner of the diagonal turns
+        // the pivot into 1/U(jn,jn) (dinv) and 1/U(jn,jn)^2 (q[]) so that nobody else needs the rsqrt
+        auto publish_row = [&](int jn) __attribute__((always_inline)) {
             if (ta == (jn & 15)) {
-                const int us = jn >> 4;
                 double* Jr = c.J + jn * ldj;
+                double rowv[4] = {0.0, 0.0, 0.0, 0.0};
+                double dg;
+                switch (jn >> 4) {
+                case 0: rowv[0] = h[0][0]; rowv[1] = h[0][1]; rowv[2] = h[0][2]; rowv[3] = h[0][3]; dg = h[0][0]; break;
+                case 1: rowv[1] = h[1][1]; rowv[2] = h[1][2]; rowv[3] = h[1][3]; dg = h[1][1]; break;
+                case 2: rowv[2] = h[2][2]; rowv[3] = h[2][3]; dg = h[2][2]; break;
+                default: rowv[3] = h[3][3]; dg = h[3][3]; break;
+                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (u == us) {
-#pragma unroll
-                        for (int w = u; w < 4; ++w) {
-                            const int cc = te + 16 * w;
-                            if (cc > jn && cc < nv) Jr[cc] = h[u][w];
-                            else if (cc == jn) c.q[jn] = h[u][w];
-                        }
-                    }
+                for (int w = 0; w < 4; ++w) {
+                    const int cc = te + 16 * w;
+                    if (cc > jn && cc < nv) Jr[cc] = rowv[w];
+                }
+                if (te == ta) { // the one owner of the diagonal
+                    const double inv = rsqrt(dg);
+                    c.dinv[jn] = inv;
+                    c.q[jn] = inv * inv;
+                }
             }
         };
         publish_row(0);
         for (int j = 0; j < nv; ++j) {
             bsync();
             const double* Jr = c.J + j * ldj;
-            const double piv = c.q[j];
+            const double inv2 = c.q[j];
             double fa[4], fe[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                fa[u] = Jr[ta + 16 * u]; // columns <= j of row j are zero (diagonal kept in q[]): rows <= j are never touched again
+                fa[u] = Jr[ta + 16 * u]; // columns <= j of row j are zero (the diagonal never enters the buffer): rows <= j stay untouched
                 fe[u] = Jr[te + 16 * u];
             }
-            const double inv = rsqrt(piv);
-            const double inv2 = inv * inv;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const double f = fa[u] * inv2;
 #pragma unroll
                 for (int w = u; w < 4; ++w) h[u][w] = fma(-f, fe[w], h[u][w]);
             }
-            if (tid == 0) c.dinv[j] = inv;
             if (j + 1 < nv) publish_row(j + 1);
         }
         STAMP(2)
         // ---- J = U^-1: step p updates Y(r,q) -= U(p,q) J(r,p) for r < p < q; row p itself restarts from zero with the
-        //      unit pivot (Y(p,q) = -U(p,q) dinv[p]).  colb = column p as the readers need it: Y(r,p) (r < p), 1 (r = p), 0 (r > p)
-        auto publish_col = [&](int pn) {
+        //      unit pivot (Y(p,q) = -U(p,q) dinv[p]).  The published column p (already times dinv[p]^2, both scalings of the
+        //      update) holds Y(r,p) for r < p and 1 for r = p; rows r > p are never written and stay zero (the two column
+        //      buffers start zeroed and each publication covers every row the previous one in that buffer touched).
+        if (tid < 256) c.stash[tid] = 0.0;
+        bsync();
+        auto publish_col = [&](int pn, double dn) __attribute__((always_inline)) {
+            if (ta == (pn & 15)) {
+                // the owners of row pn restart it from zero (a multiply by 0/1 keeps the indices static: explicit zero
+                // stores under a switch get merged into a variable-offset memset that pushes h[][] out of registers)
+                const int us = pn >> 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double keep = (u == us) ? 0.0 : 1.0;
+#pragma unroll
+                    for (int w = u; w < 4; ++w) h[u][w] *= keep;
+                }
+            }
             if (te == (pn & 15)) {
-                const int ws = pn >> 4;
                 double* colb = c.stash + (pn & 1) * 128;
+                const double dn2 = dn * dn;
+                double colv[4] = {0.0, 0.0, 0.0, 0.0};
+                switch (pn >> 4) {
+                case 0: colv[0] = h[0][0]; break;
+                case 1: colv[0] = h[0][1]; colv[1] = h[1][1]; break;
+                case 2: colv[0] = h[0][2]; colv[1] = h[1][2]; colv[2] = h[2][2]; break;
+                default: colv[0] = h[0][3]; colv[1] = h[1][3]; colv[2] = h[2][3]; colv[3] = h[3][3]; break;
+                }
 #pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    if (w == ws) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int r = ta + 16 * u;
-                            double v = 0.0;
-                            if (u <= w && r < pn) v = h[u][w];
-                            if (r == pn) v = 1.0;
-                            colb[r] = v;
-                        }
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const int r = ta + 16 * u;
+                    if (r < pn) colb[r] = colv[u] * dn2;
+                    else if (r == pn) colb[r] = dn2;
+                }
             }
         };
-        publish_col(0);
+        publish_col(0, c.dinv[0]);
         for (int p = 0; p < nv; ++p) {
             bsync();
-            const double dp = c.dinv[p];
-            const double dp2 = dp * dp;
             const double* Jr = c.J + p * ldj;
             const double* colb = c.stash + (p & 1) * 128;
+            const double dnext = c.dinv[min(p + 1, nv - 1)];
             double fr[4], fq[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                fr[u] = colb[ta + 16 * u] * dp2;
+                fr[u] = colb[ta + 16 * u];
                 fq[u] = Jr[te + 16 * u];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool isp = (ta + 16 * u == p);
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int w = u; w < 4; ++w) h[u][w] = fma(-fr[u], fq[w], isp ? 0.0 : h[u][w]);
-            }
-            if (p + 1 < nv) publish_col(p + 1);
+                for (int w = u; w < 4; ++w) h[u][w] = fma(-fr[u], fq[w], h[u][w]);
+            if (p + 1 < nv) publish_col(p + 1, dnext);
         }
         bsync();
         // final: J(r,q) = Y(r,q) dinv[q], J(r,r) = dinv[r]
@@ -1444,7 +1601,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                     if (cv[z2]) trace += hf[z2];
                 }
             }
-            auto pub_row = [&](int sn) {
+            auto pub_row = [&](int sn) __attribute__((always_inline)) {
                 if (mine && ta == sn) {
 #pragma unroll
                     for (int z2 = 0; z2 < 2; ++z2)
@@ -1468,7 +1625,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                 }
                 if (sidx + 1 < 12) pub_row(sidx + 1);
             }
-            auto pub_col = [&](int pn) {
+            auto pub_col = [&](int pn) __attribute__((always_inline)) {
                 if (te == pn && ta < 12) {
 #pragma unroll
                     for (int z2 = 0; z2 < 2; ++z2) {
@@ -1513,7 +1670,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     bsync();
     compute_d(c, 0, n); // d = J' g
     c.iq = 0;
-    update_z_r(c); // z = J d
+    update_z_r(c, 0); // z = J d
     double f_value;
     {
         double part = 0.0;
@@ -1548,19 +1705,20 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         bsync();
         compute_d(c, k0, k1);
         STAMP(5)
-        update_z_r(c);
+        update_z_r(c, 0);
         STAMP(6)
-        double zz = 0.0, znp = 0.0, npx = 0.0;
+        double zz = 0.0, znp = 0.0, npx = 0.0, dn2 = 0.0;
         if (tid < n) {
             const double zv = c.z[tid];
             zz = zv * zv;
+            if (tid >= c.iq) dn2 = c.d[tid] * c.d[tid];
             if (tid >= k0 && tid < k1) {
                 const double nv_ = c.np[tid];
                 znp = zv * nv_;
                 npx = nv_ * c.x[tid];
             }
         }
-        block_sum3(c, zz, znp, npx);
+        block_sum4(c, zz, znp, npx, dn2);
         double t2 = 0.0;
         if (fabs(zz) > eps) t2 = (-npx - ce0) / znp;
         const int iq = c.iq;
@@ -1572,13 +1730,15 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         }
         f_value += 0.5 * (t2 * t2) * znp;
         STAMP(7)
-        if (!add_constraint(c)) status = HQP_ERROR; // redundant equalities
+        if (!add_constraint_hh(c, dn2)) status = HQP_ERROR; // redundant equalities
         STAMP(8)
     }
 
     // ---------------- phase 4: inequality loop (GI steps 1, 2, 2a-2c) ----------------
     if (status == -2) {
         for (int i = tid; i < nin2; i += kThreads) c.iai[i] = i;
+        OwnRows own;
+        own_rows_init(c, own);
         bsync();
         const double psi_tol = (double)nin2 * eps * c1 * c2 * 100.0;
         while (status == -2) {
@@ -1589,17 +1749,14 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                 break;
             }
             for (int i = neq + tid; i < c.iq; i += kThreads) c.iai[c.A[i]] = -1;
-            compute_s(c);
-            double psi = 0.0;
-            for (int i = tid; i < nin2; i += kThreads) {
-                c.iaexcl[i] = 1;
-                psi += fmin(0.0, c.s[i]);
-            }
+            actuation_product(c);
             for (int i = tid; i < c.iq; i += kThreads) {
                 c.uold[i] = c.u[i];
                 c.Aold[i] = c.A[i];
             }
             for (int i = tid; i < n; i += kThreads) c.xold[i] = c.x[i];
+            bsync();
+            double psi = compute_s_owned(c, own);
             psi = block_sum(c, psi);
             if (fabs(psi) <= psi_tol) {
                 status = HQP_OPTIMAL;
@@ -1639,7 +1796,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                     else
                         compute_d(c, k0, k1);
                     STAMP(11)
-                    update_z_r(c);
+                    update_z_r(c, neq);
                     STAMP(12)
                     const int iq = c.iq;
                     // step 2b: partial step length t1 (dual feasibility) and full step length t2
@@ -1652,13 +1809,14 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                     const double t1 = bt.v;
                     const int lpos = bt.i;
                     const int l = (t1 < inf) ? c.A[lpos] : 0;
-                    double zz = 0.0, znp = 0.0, dummy = 0.0;
+                    double zz = 0.0, znp = 0.0, dn2 = 0.0, dummy = 0.0;
                     if (tid < n) {
                         const double zv = c.z[tid];
                         zz = zv * zv;
+                        if (tid >= iq) dn2 = c.d[tid] * c.d[tid];
                         if (tid >= k0 && tid < k1) znp = zv * c.np[tid];
                     }
-                    block_sum3(c, zz, znp, dummy);
+                    block_sum4(c, zz, znp, dn2, dummy);
                     const double sip = c.s[ip];
                     const double uiq = c.u[iq];
                     const double t2 = (fabs(zz) > eps) ? (-sip / znp) : inf;
@@ -1670,7 +1828,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                     bsync(); // everyone has read s[ip], u[iq], A[lpos] before they change
                     if (t2 >= inf) {
                         // (ii) dual step only, drop l
-                        for (int j = tid; j < iq; j += kThreads) c.u[j] = fma(-t, c.r[j], c.u[j]);
+                        for (int j = neq + tid; j < iq; j += kThreads) c.u[j] = fma(-t, c.r[j], c.u[j]);
                         if (tid == kThreads - 1) {
                             c.u[iq] = uiq + t;
                             c.iai[l] = l;
@@ -1684,13 +1842,13 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                     // (iii) primal + dual step
                     if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
                     f_value += t * znp * (0.5 * t + uiq);
-                    if (tid >= 128 && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                    if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
                     if (tid == kThreads - 1) c.u[iq] = uiq + t;
                     bsync();
                     STAMP(13)
                     if (t == t2) {
                         // full step: add ip to the active set
-                        const bool added_ = add_constraint(c);
+                        const bool added_ = add_constraint_hh(c, dn2);
                         STAMP(14)
                         if (!added_) {
                             if (tid == 0) c.iaexcl[ip] = 0;
