@@ -1519,58 +1519,45 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         }
         STAMP(2)
         // ---- J = U^-1: step p updates Y(r,q) -= U(p,q) J(r,p) for r < p < q; row p itself restarts from zero with the
-        //      unit pivot (Y(p,q) = -U(p,q) dinv[p]).  The published column p (already times dinv[p]^2, both scalings of the
-        //      update) holds Y(r,p) for r < p and 1 for r = p; rows r > p are never written and stay zero (the two column
-        //      buffers start zeroed and each publication covers every row the previous one in that buffer touched).
-        if (tid < 256) c.stash[tid] = 0.0;
-        bsync();
-        auto publish_col = [&](int pn, double dn) __attribute__((always_inline)) {
-            if (ta == (pn & 15)) {
-                // the owners of row pn restart it from zero (a multiply by 0/1 keeps the indices static: explicit zero
-                // stores under a switch get merged into a variable-offset memset that pushes h[][] out of registers)
-                const int us = pn >> 4;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double keep = (u == us) ? 0.0 : 1.0;
-#pragma unroll
-                    for (int w = u; w < 4; ++w) h[u][w] *= keep;
-                }
-            }
+        //      unit pivot (Y(p,q) = -U(p,q) dinv[p]).  colb = column p as the readers need it: Y(r,p) (r < p), 1 (r = p), 0 (r > p)
+        auto publish_col = [&](int pn) __attribute__((always_inline)) {
             if (te == (pn & 15)) {
+                const int ws = pn >> 4;
                 double* colb = c.stash + (pn & 1) * 128;
-                const double dn2 = dn * dn;
-                double colv[4] = {0.0, 0.0, 0.0, 0.0};
-                switch (pn >> 4) {
-                case 0: colv[0] = h[0][0]; break;
-                case 1: colv[0] = h[0][1]; colv[1] = h[1][1]; break;
-                case 2: colv[0] = h[0][2]; colv[1] = h[1][2]; colv[2] = h[2][2]; break;
-                default: colv[0] = h[0][3]; colv[1] = h[1][3]; colv[2] = h[2][3]; colv[3] = h[3][3]; break;
-                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = ta + 16 * u;
-                    if (r < pn) colb[r] = colv[u] * dn2;
-                    else if (r == pn) colb[r] = dn2;
-                }
+                for (int w = 0; w < 4; ++w)
+                    if (w == ws) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int r = ta + 16 * u;
+                            double v = 0.0;
+                            if (u <= w && r < pn) v = h[u][w];
+                            if (r == pn) v = 1.0;
+                            colb[r] = v;
+                        }
+                    }
             }
         };
-        publish_col(0, c.dinv[0]);
+        publish_col(0);
         for (int p = 0; p < nv; ++p) {
             bsync();
+            const double dp = c.dinv[p];
+            const double dp2 = dp * dp;
             const double* Jr = c.J + p * ldj;
             const double* colb = c.stash + (p & 1) * 128;
-            const double dnext = c.dinv[min(p + 1, nv - 1)];
             double fr[4], fq[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                fr[u] = colb[ta + 16 * u];
+                fr[u] = colb[ta + 16 * u] * dp2;
                 fq[u] = Jr[te + 16 * u];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+                const bool isp = (ta + 16 * u == p);
 #pragma unroll
-                for (int w = u; w < 4; ++w) h[u][w] = fma(-fr[u], fq[w], h[u][w]);
-            if (p + 1 < nv) publish_col(p + 1, dnext);
+                for (int w = u; w < 4; ++w) h[u][w] = fma(-fr[u], fq[w], isp ? 0.0 : h[u][w]);
+            }
+            if (p + 1 < nv) publish_col(p + 1);
         }
         bsync();
         // final: J(r,q) = Y(r,q) dinv[q], J(r,r) = dinv[r]
