@@ -124,7 +124,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     D.o_J = take(n * D.ldj);
     int rsize = n * (n + 3) / 2 + 2;
     if (D.n_dense * nv + 64 > rsize) rsize = D.n_dense * nv + 64;
-    if (D.neq > 0 && 256 + (n + 1) * D.ldb + 8 > rsize) rsize = 256 + (n + 1) * D.ldb + 8; // B of the blocked equality phase // + 64: the 4x4 H tiles may read past the last staged row
+    if (D.neq > 0 && 256 + (n + 17) * D.ldb + 8 > rsize) rsize = 256 + (n + 17) * D.ldb + 8; // B of the blocked equality phase + 16 zero rows // + 64: the 4x4 H tiles may read past the last staged row
     D.o_R = take(rsize);
     D.o_M = take(nv * D.ldm);
     D.o_Jc = take(D.k * D.ldc);

@@ -208,7 +208,7 @@ __device__ __forceinline__ double gi_distance(double a, double b)
 
 // In-kernel phase stamps (diagnostic build only: -DWBCQP_STAMPS). Never compiled into the product library.
 #ifdef WBCQP_STAMPS
-constexpr int kStamps = 20;
+constexpr int kStamps = 24;
 #define STAMP_DECL c.st_prev_ = clock64(); for (int i_ = 0; i_ < kStamps; ++i_) c.st_acc_[i_] = 0;
 #define STAMP(i) { long long now_ = clock64(); c.st_acc_[i] += now_ - c.st_prev_; c.st_prev_ = now_; }
 #else
@@ -946,13 +946,14 @@ __device__ __forceinline__ void inv_step(double* T, int ld, const double* fcol, 
 }
 
 // One Householder step of the QR of B (n x m, leading dimension c.ldb) on column j.  Thread (column e = j+1+(tid>>4),
-// rows kk = j + (tid&15) + 16 t, t < NT).  The squared norm of column j's tail was left in nrm2[j&1] by the previous
-// step; this step leaves the next one.  Returns false when the column is (numerically) dependent.
+// rows kk = j + (tid&15) + 16 t, t < NT = ceil((n-j)/16)).  B carries 16 zero rows below row n-1, so rows past the end need no
+// mask: they contribute nothing and stay zero.  The squared norm of column j's tail was left in nrm2[j&1] by the
+// previous step; this step leaves the next one.  Returns false when the column is (numerically) dependent.
 template <int NT>
 __device__ __forceinline__ bool qr_step(Ctx& c, double* Bm, double* tau, double* rdiag, double* nrm2, int j, double v0_prev,
                                         double& alpha, double& v0)
 {
-    const int n = c.n, m = c.neq, ldb = c.ldb, tid = c.tid;
+    const int m = c.neq, ldb = c.ldb, tid = c.tid;
     const int kc = tid & 15;
     const int e = j + 1 + (tid >> 4);
     const bool ev = e < m;
@@ -960,12 +961,13 @@ __device__ __forceinline__ bool qr_step(Ctx& c, double* Bm, double* tau, double*
     // loads first: the pivot data and this thread's elements of column j and column e
     const double nrm = nrm2[j & 1];
     const double x0 = Bm[j * ldb + j];
+    const double* colj = Bm + (j + kc) * ldb + j;
+    double* cole = Bm + (j + kc) * ldb + es;
     double vk[NT], bk[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int kk = min(j + kc + 16 * t, n - 1);
-        vk[t] = Bm[kk * ldb + j];
-        bk[t] = Bm[kk * ldb + es];
+        vk[t] = colj[16 * t * ldb];
+        bk[t] = cole[16 * t * ldb];
     }
     const double inx = rsqrt(nrm);
     const double nx = (nrm > 0.0) ? nrm * inx : 0.0; // exactly dependent column: alpha = 0 -> reported as redundant
@@ -975,29 +977,31 @@ __device__ __forceinline__ bool qr_step(Ctx& c, double* Bm, double* tau, double*
     if (kc == 0) vk[0] = v0;
     double dot = 0.0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-        if (j + kc + 16 * t < n) dot = fma(vk[t], bk[t], dot);
+    for (int t = 0; t < NT; ++t) dot = fma(vk[t], bk[t], dot);
     dot = row16_sum(dot) * tj;
     double sq = 0.0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int kk = j + kc + 16 * t;
         const double nb_ = fma(-dot, vk[t], bk[t]);
-        if (ev && kk < n) {
-            Bm[kk * ldb + e] = nb_;
-            if (kk > j) sq = fma(nb_, nb_, sq);
-        }
+        if (ev) cole[16 * t * ldb] = nb_;
+        if (t > 0 || kc > 0) sq = fma(nb_, nb_, sq);
     }
     sq = row16_sum(sq);
     // columns beyond the first 16 (m - j - 1 > 16): generic pass
     for (int eb = j + 17; eb < m; eb += 16) {
         const int e2 = eb + (tid >> 4);
+        const int e2s = (e2 < m) ? e2 : j;
         double d2 = 0.0;
-        if (e2 < m)
-            for (int kk = j + kc; kk < n; kk += 16) d2 = fma((kk == j) ? v0 : Bm[kk * ldb + j], Bm[kk * ldb + e2], d2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) d2 = fma((t == 0 && kc == 0) ? v0 : colj[16 * t * ldb], Bm[(j + kc + 16 * t) * ldb + e2s], d2);
         d2 = row16_sum(d2) * tj;
-        if (e2 < m)
-            for (int kk = j + kc; kk < n; kk += 16) Bm[kk * ldb + e2] = fma(-d2, (kk == j) ? v0 : Bm[kk * ldb + j], Bm[kk * ldb + e2]);
+        if (e2 < m) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double* pe = Bm + (j + kc + 16 * t) * ldb + e2;
+                *pe = fma(-d2, (t == 0 && kc == 0) ? v0 : colj[16 * t * ldb], *pe);
+            }
+        }
     }
     if (tid == 0) {
         nrm2[(j + 1) & 1] = sq; // threads 0..15 own column j+1
@@ -1073,6 +1077,7 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
                 if (e0 + q < m) Bm[cidx * ldb + e0 + q] = acc[q];
         }
     }
+    for (int e2 = tid; e2 < 16 * ldb; e2 += kThreads) Bm[n * ldb + e2] = 0.0; // zero rows below B for the maskless QR steps
     bsync();
     STAMP(5)
     // squared norm of column 0
@@ -1089,16 +1094,15 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     // ---- Householder QR of B, one barrier per column. Thread (column e = j+1+(tid>>4), rows k = j + (tid&15) + 16 t).
     double v0_prev = 0.0;
     for (int j = 0; j < m; ++j) {
-        const int nt = (n - j + 15) >> 4;
         double alpha, v0;
         bool ok;
-        switch (nt) {
+        switch ((n - j + 15) >> 4) {
         case 1: ok = qr_step<1>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
         case 2: ok = qr_step<2>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
         case 3: ok = qr_step<3>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
         case 4: ok = qr_step<4>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
         case 5: ok = qr_step<5>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
-        default: ok = qr_step<6>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break; // n <= 85 -> nt <= 6
+        default: ok = qr_step<6>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break; // n <= 85
         }
         if (!ok) return false; // redundant equalities
         v0_prev = v0;
@@ -1498,67 +1502,66 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                 }
             }
         };
+        // ---- fused loop: step j applies BOTH the Cholesky update of the trailing matrix (h) and the update of the
+        //      inverse (y, from zero): Y(r,q) -= U(j,q) J(r,j) for r < j < q, unit pivot for r = j.  Row j of U is read once
+        //      for both.  The published column j is raw (Y(r,j), r < j; 1 at r = j; rows r > j never written, both buffers
+        //      start zeroed and each publication covers every row the previous one in that buffer touched); readers scale
+        //      it by dinv[j]^2 (= q[j]).  One barrier per step.
+        double y[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) y[u][w] = 0.0;
+        c.stash[tid] = 0.0;
+        auto publish_col = [&](int pn) __attribute__((always_inline)) {
+            if (te == (pn & 15)) {
+                double* colb = c.stash + (pn & 1) * 128;
+                double colv[4] = {0.0, 0.0, 0.0, 0.0};
+                switch (pn >> 4) {
+                case 0: colv[0] = y[0][0]; break;
+                case 1: colv[0] = y[0][1]; colv[1] = y[1][1]; break;
+                case 2: colv[0] = y[0][2]; colv[1] = y[1][2]; colv[2] = y[2][2]; break;
+                default: colv[0] = y[0][3]; colv[1] = y[1][3]; colv[2] = y[2][3]; colv[3] = y[3][3]; break;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = ta + 16 * u;
+                    if (r < pn) colb[r] = colv[u];
+                    else if (r == pn) colb[r] = 1.0;
+                }
+            }
+        };
+        bsync();
         publish_row(0);
+        publish_col(0);
         for (int j = 0; j < nv; ++j) {
             bsync();
             const double* Jr = c.J + j * ldj;
+            const double* colb = c.stash + (j & 1) * 128;
             const double inv2 = c.q[j];
-            double fa[4], fe[4];
+            double fa[4], fe[4], fr[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 fa[u] = Jr[ta + 16 * u]; // columns <= j of row j are zero (the diagonal never enters the buffer): rows <= j stay untouched
                 fe[u] = Jr[te + 16 * u];
+                fr[u] = colb[ta + 16 * u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const double f = fa[u] * inv2;
+                const double g2 = fr[u] * inv2;
 #pragma unroll
-                for (int w = u; w < 4; ++w) h[u][w] = fma(-f, fe[w], h[u][w]);
+                for (int w = u; w < 4; ++w) {
+                    h[u][w] = fma(-f, fe[w], h[u][w]);
+                    y[u][w] = fma(-g2, fe[w], y[u][w]);
+                }
             }
-            if (j + 1 < nv) publish_row(j + 1);
+            if (j + 1 < nv) {
+                publish_row(j + 1);
+                publish_col(j + 1);
+            }
         }
         STAMP(2)
-        // ---- J = U^-1: step p updates Y(r,q) -= U(p,q) J(r,p) for r < p < q; row p itself restarts from zero with the
-        //      unit pivot (Y(p,q) = -U(p,q) dinv[p]).  colb = column p as the readers need it: Y(r,p) (r < p), 1 (r = p), 0 (r > p)
-        auto publish_col = [&](int pn) __attribute__((always_inline)) {
-            if (te == (pn & 15)) {
-                const int ws = pn >> 4;
-                double* colb = c.stash + (pn & 1) * 128;
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    if (w == ws) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int r = ta + 16 * u;
-                            double v = 0.0;
-                            if (u <= w && r < pn) v = h[u][w];
-                            if (r == pn) v = 1.0;
-                            colb[r] = v;
-                        }
-                    }
-            }
-        };
-        publish_col(0);
-        for (int p = 0; p < nv; ++p) {
-            bsync();
-            const double dp = c.dinv[p];
-            const double dp2 = dp * dp;
-            const double* Jr = c.J + p * ldj;
-            const double* colb = c.stash + (p & 1) * 128;
-            double fr[4], fq[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                fr[u] = colb[ta + 16 * u] * dp2;
-                fq[u] = Jr[te + 16 * u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool isp = (ta + 16 * u == p);
-#pragma unroll
-                for (int w = u; w < 4; ++w) h[u][w] = fma(-fr[u], fq[w], isp ? 0.0 : h[u][w]);
-            }
-            if (p + 1 < nv) publish_col(p + 1);
-        }
         bsync();
         // final: J(r,q) = Y(r,q) dinv[q], J(r,r) = dinv[r]
 #pragma unroll
@@ -1566,12 +1569,12 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
 #pragma unroll
             for (int w = u; w < 4; ++w) {
                 const int r = ta + 16 * u, q = te + 16 * w;
-                if (q < nv && r < q) c.J[r * ldj + q] = h[u][w] * c.dinv[q];
+                if (q < nv && r < q) c.J[r * ldj + q] = y[u][w] * c.dinv[q];
                 else if (r == q && r < nv) c.J[r * ldj + r] = c.dinv[r];
             }
-        // ---- the 12 x 12 force-regularisation blocks, two contacts at a time, same scheme with one position per thread
+        // ---- the 12 x 12 force-regularisation blocks, two contacts at a time, same fused scheme with one position per thread
         for (int ct0 = 0; ct0 < nc; ct0 += 2) {
-            double hf[2];
+            double hf[2], yf[2];
             int fb[2];
             bool cv[2];
             const bool mine = ta < 12 && te < 12 && te >= ta;
@@ -1583,57 +1586,49 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                 fb[z2] = nv + 12 * cs;
                 const double wt = c.w[S.forcereg_task[cs]];
                 hf[z2] = mine ? wt * S.ftf[cs * 144 + ta * 12 + te] : 0.0;
+                yf[z2] = 0.0;
                 if (mine && ta == te) {
                     hf[z2] += S.hessian_reg;
                     if (cv[z2]) trace += hf[z2];
                 }
             }
-            auto pub_row = [&](int sn) __attribute__((always_inline)) {
+            bsync();
+            if (tid < 64) c.stash[(tid >> 5) * 128 + (tid & 31)] = 0.0;
+            bsync();
+            auto pub = [&](int sn) __attribute__((always_inline)) {
                 if (mine && ta == sn) {
 #pragma unroll
                     for (int z2 = 0; z2 < 2; ++z2)
                         if (cv[z2]) {
                             if (te > sn) c.J[(fb[z2] + sn) * ldj + fb[z2] + te] = hf[z2];
-                            else c.q[fb[z2] + sn] = hf[z2];
+                            else {
+                                const double inv = rsqrt(hf[z2]);
+                                c.dinv[fb[z2] + sn] = inv;
+                                c.q[fb[z2] + sn] = inv * inv;
+                            }
                         }
                 }
+                if (te == sn && ta < 12) {
+#pragma unroll
+                    for (int z2 = 0; z2 < 2; ++z2) {
+                        if (ta < sn) c.stash[(sn & 1) * 128 + 16 * z2 + ta] = yf[z2];
+                        else if (ta == sn) c.stash[(sn & 1) * 128 + 16 * z2 + ta] = 1.0;
+                    }
+                }
             };
-            pub_row(0);
+            pub(0);
             for (int sidx = 0; sidx < 12; ++sidx) {
                 bsync();
 #pragma unroll
                 for (int z2 = 0; z2 < 2; ++z2) {
                     const double* Jr = c.J + (fb[z2] + sidx) * ldj + fb[z2];
-                    const double piv = c.q[fb[z2] + sidx];
+                    const double inv2 = c.q[fb[z2] + sidx];
                     const double fa_ = Jr[min(ta, 11)], fe_ = Jr[min(te, 11)];
-                    const double inv = rsqrt(piv);
-                    hf[z2] = fma(-(fa_ * inv * inv), fe_, hf[z2]);
-                    if (tid == 0 && cv[z2]) c.dinv[fb[z2] + sidx] = inv;
+                    const double fr_ = c.stash[(sidx & 1) * 128 + 16 * z2 + min(ta, 11)];
+                    hf[z2] = fma(-(fa_ * inv2), fe_, hf[z2]);
+                    yf[z2] = fma(-(fr_ * inv2), fe_, yf[z2]);
                 }
-                if (sidx + 1 < 12) pub_row(sidx + 1);
-            }
-            auto pub_col = [&](int pn) __attribute__((always_inline)) {
-                if (te == pn && ta < 12) {
-#pragma unroll
-                    for (int z2 = 0; z2 < 2; ++z2) {
-                        double v = 0.0;
-                        if (ta < pn) v = hf[z2];
-                        if (ta == pn) v = 1.0;
-                        c.stash[(pn & 1) * 128 + 16 * z2 + ta] = v;
-                    }
-                }
-            };
-            pub_col(0);
-            for (int p = 0; p < 12; ++p) {
-                bsync();
-#pragma unroll
-                for (int z2 = 0; z2 < 2; ++z2) {
-                    const double dp = c.dinv[fb[z2] + p];
-                    const double fr_ = c.stash[(p & 1) * 128 + 16 * z2 + min(ta, 11)] * dp * dp;
-                    const double fq_ = c.J[(fb[z2] + p) * ldj + fb[z2] + min(te, 11)];
-                    hf[z2] = fma(-fr_, fq_, (ta == p) ? 0.0 : hf[z2]);
-                }
-                if (p + 1 < 12) pub_col(p + 1);
+                if (sidx + 1 < 12) pub(sidx + 1);
             }
             bsync();
             if (mine) {
@@ -1641,7 +1636,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                 for (int z2 = 0; z2 < 2; ++z2)
                     if (cv[z2]) {
                         const int r = fb[z2] + ta, q = fb[z2] + te;
-                        c.J[r * ldj + q] = (ta == te) ? c.dinv[r] : hf[z2] * c.dinv[q];
+                        c.J[r * ldj + q] = (ta == te) ? c.dinv[r] : yf[z2] * c.dinv[q];
                     }
             }
         }

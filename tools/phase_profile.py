@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 NAMES = ["load", "assemble_Hg", "cholesky", "J=U^-1", "x0", "eq:N,rhs,B=J0'N", "eq:QR", "eq:R,G", "eq:solve x,u (+Givens path)",
          "in:s+psi+save", "in:argmin+build", "in:d", "in:z+r", "in:steplen+step | eq:J update", "in:add", "in:delete",
-         "loop-exit", "decode+store", "eq:T || W=J0V", "eq:W<-WT"]
+         "loop-exit", "decode+store", "eq:T || W=J0V", "eq:W<-WT", "f:pubcol->loop top", "f:barrier", "f:loads+fma", "f:publish_row"]
 
 
 def main():
@@ -39,7 +39,7 @@ def main():
     d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
     d_out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
                  status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
-    dbg = torch.zeros(B, 20, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(B, 24, dtype=torch.int64, device=dev)
     h = capi.Handle(0, capi.F64)
     h.set_structure(0, st)
     lib.wbcqp_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
