@@ -149,7 +149,7 @@ def main():
             "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s_pos_tracker%s_b%d_fp64_one_wave_per_qp" % (args.robot, "_squat" if args.squat else "", B),
+            "config": {"workload": "%s_pos_tracker%s_b%d_fp64_one_workgroup_per_qp" % (args.robot, "_squat" if args.squat else "", B),
                        "batch_per_gpu": B, "n": st.n, "neq": st.neq, "nin": st.nin, "level1_rows": st.r1,
                        "parallelism": "batch-shard x%d" % world,
                        "allgather_tau": bool(gather_state["ok"]), "lds_bytes_per_qp": layout["lds_bytes"],

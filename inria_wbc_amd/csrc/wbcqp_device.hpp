@@ -172,25 +172,6 @@ __device__ __forceinline__ int wave_max_int(int v)
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts; identity 0.0)
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_shift0(double v)
-{
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_prefix_sum(double v)
-{
-    v += dpp_shift0<0x111, 0xf>(v); // row_shr:1
-    v += dpp_shift0<0x112, 0xf>(v); // row_shr:2
-    v += dpp_shift0<0x114, 0xf>(v); // row_shr:4
-    v += dpp_shift0<0x118, 0xf>(v); // row_shr:8
-    v += dpp_shift0<0x142, 0xa>(v); // row_bcast:15 into rows 1,3
-    v += dpp_shift0<0x143, 0xc>(v); // row_bcast:31 into rows 2,3
-    return v;
-}
-
 // overflow-safe hypot exactly as eiquadprog utils::distance
 __device__ __forceinline__ double gi_distance(double a, double b)
 {
@@ -413,104 +394,6 @@ __device__ __forceinline__ void update_z_r(Ctx& c, int rlo)
     bsync();
     if (c.tid < n) c.z[c.tid] = (c.part[c.tid] + c.part[128 + c.tid]) + c.part[256 + c.tid];
     bsync();
-}
-
-// add_constraint (eiquadprog): Givens sweep that zeroes d[iq+1:], updates J, appends a column to R.
-// Rotation parameters come from suffix sums of d^2 (closed form of the upstream hypot chain; one DPP scan on
-// wave 0).  The reflection is applied as (cc ss; ss -cc) directly (algebraically what upstream's xny form
-// evaluates).  Sweep: wave 0 owns rows 0..63, wave 1 rows 64..127, running element in a register.
-__device__ __forceinline__ bool add_constraint(Ctx& c)
-{
-    const int n = c.n, ldj = c.ldj, lane = c.lane, iq = c.iq;
-    if (c.wave == 0) {
-        // lane l owns element 63-l (and 127-l): a prefix scan over lanes is a suffix scan over indices
-        const int e0 = kWave - 1 - lane, e1 = 2 * kWave - 1 - lane;
-        const double v1 = (e1 < n) ? c.d[e1] : 0.0;
-        const double q1 = wave_prefix_sum(v1 * v1);
-        const double hi_total = bcast_lane(q1, kWave - 1);
-        const double v0 = (e0 < n) ? c.d[e0] : 0.0;
-        const double q0 = wave_prefix_sum(v0 * v0) + hi_total;
-        int last_nz = -1;
-        if (e0 < n) {
-            c.q[e0] = q0;
-            if (q0 > 0.0) last_nz = e0;
-        }
-        if (e1 < n) {
-            c.q[e1] = q1;
-            if (q1 > 0.0) last_nz = e1;
-        }
-        last_nz = wave_max_int(last_nz);
-        if (lane == 0) c.q[n] = __hiloint2double(0, last_nz);
-    }
-    bsync();
-    const int last_nz = __double2loint(c.q[n]);
-    const int jstart = min(n - 1, last_nz + 1); // steps j > jstart have h == 0 and are skipped upstream
-    const bool any = jstart >= iq + 1;
-    if (any) {
-        for (int j = iq + 1 + c.tid; j <= jstart; j += kThreads) {
-            const int i = j - 1;
-            const double qi = c.q[i], qj = c.q[j], di = c.d[i], dj = c.d[j];
-            const double rh = 1.0 / sqrt(qi);
-            const double ej = (dj < 0.0 ? -1.0 : 1.0) * sqrt(qj);
-            double cc = di * rh, ss = ej * rh;
-            if (cc < 0.0) {
-                cc = -cc;
-                ss = -ss;
-            }
-            c.prm[2 * j] = cc;
-            c.prm[2 * j + 1] = ss;
-        }
-        bsync();
-        if (c.wave < 2) {
-            const int k = lane + c.wave * kWave;
-            if (k < n) {
-                double* Jk = c.J + (size_t)k * ldj;
-                const double* prm = c.prm;
-                double t2 = Jk[jstart];
-                int j = jstart;
-                for (; j - 3 > iq; j -= 4) {
-                    double t1[4], pc[4], ps[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        t1[u] = Jk[j - u - 1];
-                        pc[u] = prm[2 * (j - u)];
-                        ps[u] = prm[2 * (j - u) + 1];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double nw = fma(t2, ps[u], t1[u] * pc[u]);
-                        Jk[j - u] = fma(t1[u], ps[u], -(t2 * pc[u]));
-                        t2 = nw;
-                    }
-                }
-                for (; j > iq; --j) {
-                    const double pc = prm[2 * j], ps = prm[2 * j + 1];
-                    const double t1 = Jk[j - 1];
-                    const double nw = fma(t2, ps, t1 * pc);
-                    Jk[j] = fma(t1, ps, -(t2 * pc));
-                    t2 = nw;
-                }
-                Jk[iq] = t2;
-            }
-        }
-    }
-    // new column of R = d[0..iq] with d[iq] replaced by the accumulated norm
-    double diq;
-    if (any)
-        diq = (c.d[iq] < 0.0 ? -1.0 : 1.0) * sqrt(c.q[iq]);
-    else
-        diq = c.d[iq];
-    double* Rc = c.R + roff(iq);
-    for (int i = c.tid; i < iq; i += kThreads) Rc[i] = c.d[i];
-    if (c.tid == kThreads - 1) {
-        Rc[iq] = diq;
-        c.rdinv[iq] = 1.0 / diq;
-    }
-    c.iq = iq + 1;
-    bsync();
-    if (fabs(diq) <= 2.220446049250313e-16 * c.R_norm) return false; // degenerate
-    c.R_norm = fmax(c.R_norm, fabs(diq));
-    return true;
 }
 
 // add_constraint, Householder form.  eiquadprog zeroes d[iq+1:] with a chain of n-iq-1 Givens rotations of J's columns (a
@@ -813,66 +696,6 @@ __device__ __forceinline__ double compute_s_owned(Ctx& c, const OwnRows& o)
     return psi;
 }
 
-// s = CI x + ci0 for every one-sided row, from the structure of each block. Ends with a barrier.
-__device__ __forceinline__ void compute_s(Ctx& c)
-{
-    const DevStruct& S = *c.S;
-    const int nv = c.nv, nu = c.nu, tid = c.tid, n = c.n;
-    bool has_act = false;
-    for (int b = 0; b < S.n_blocks; ++b) {
-        const int kind = S.blk_kind[b], rows = S.blk_rows[b], off = S.blk_off[b];
-        if (kind == INEQ_BOUNDS) {
-            for (int rr = tid; rr < rows; rr += kThreads) {
-                double xv = c.x[S.bound_col[rr]];
-                c.s[off + rr] = xv - c.blb[rr];
-                c.s[off + rows + rr] = -xv + c.bub[rr];
-            }
-        }
-        else if (kind == INEQ_ACTUATION) {
-            // thread (row = lane [+64], quarter of the columns = wave); partials meet in LDS
-            has_act = true;
-            const int quarter = c.wave;
-            const int chunk = (n + 3) >> 2;
-            const int ja = quarter * chunk, jb = min(n, ja + chunk);
-            for (int rr = c.lane; rr < rows; rr += kWave) {
-                const int row = nu + rr;
-                const double* Mr = c.M + row * c.ldm;
-                const double* Jcr = c.Jc + row;
-                const double* x = c.x;
-                const int ldc = c.ldc;
-                double a0 = 0.0, a1 = 0.0;
-                for (int j = ja; j < min(jb, nv); ++j) a0 = fma(Mr[j], x[j], a0);
-                for (int m = max(ja, nv) - nv; m < jb - nv; ++m) a1 = fma(Jcr[m * ldc], x[nv + m], a1);
-                c.part[quarter * 128 + rr] = a0 - a1;
-            }
-        }
-        else {
-            const int ct = S.blk_arg[b];
-            if (tid < 17) {
-                const double* B = S.fric_mat + ((size_t)ct * 17 + tid) * 12;
-                double a = 0.0;
-#pragma unroll
-                for (int m = 0; m < 12; ++m) a = fma(B[m], c.x[nv + 12 * ct + m], a);
-                c.s[off + tid] = a - S.fric_lb[ct * 17 + tid];
-                c.s[off + 17 + tid] = -a + S.fric_ub[ct * 17 + tid];
-            }
-        }
-    }
-    bsync();
-    if (has_act) {
-        for (int b = 0; b < S.n_blocks; ++b) {
-            if (S.blk_kind[b] != INEQ_ACTUATION) continue;
-            const int rows = S.blk_rows[b], off = S.blk_off[b];
-            for (int rr = tid; rr < rows; rr += kThreads) {
-                const double t = (c.part[rr] + c.part[128 + rr]) + (c.part[256 + rr] + c.part[384 + rr]);
-                c.s[off + rr] = t - c.tl[rr];
-                c.s[off + rows + rr] = -t + c.tu[rr];
-            }
-        }
-        bsync();
-    }
-}
-
 // global -> LDS copy, all 256 threads, 4 loads in flight per thread
 template <typename TI>
 __device__ __forceinline__ void copy_in(const TI* __restrict__ src, double* dst, int len, int tid)
@@ -888,62 +711,6 @@ __device__ __forceinline__ void copy_in(const TI* __restrict__ src, double* dst,
     for (; e < len; e += kThreads) dst[e] = (double)src[e];
 }
 
-
-// One right-looking Cholesky step on a 16 x 16 thread grid, NB x NB positions per thread: reads the pivot, forms
-// inv = 1/sqrt(pivot) while the other loads are in flight, then T(a,e) -= inv^2 row[a] row[e] for e >= a.
-// Invalid positions store to a dummy slot instead of branching. Returns inv.
-template <int NB>
-__device__ __forceinline__ double chol_step(const double* pivp, double* T, int ld, const double* row, int m, int tid, double* dummy)
-{
-    const int ta = tid >> 4, te = tid & 15;
-    const double piv = *pivp;
-    double fa[NB], fe[NB], v[NB][NB];
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-        fa[u] = row[min(ta + 16 * u, m - 1)];
-        fe[u] = row[min(te + 16 * u, m - 1)];
-    }
-#pragma unroll
-    for (int u = 0; u < NB; ++u)
-#pragma unroll
-        for (int w = 0; w < NB; ++w) v[u][w] = T[min(ta + 16 * u, m - 1) * ld + min(te + 16 * w, m - 1)];
-    const double inv = rsqrt(piv);
-    const double inv2 = inv * inv;
-#pragma unroll
-    for (int u = 0; u < NB; ++u)
-#pragma unroll
-        for (int w = 0; w < NB; ++w) {
-            const int a = ta + 16 * u, e = te + 16 * w;
-            double* dst = (a < m && e < m && e >= a) ? (T + a * ld + e) : dummy;
-            *dst = fma(-(fa[u] * inv2), fe[w], v[u][w]);
-        }
-    return inv;
-}
-// One step of the in-place triangular inverse: T(a,e) -= (fcol[a] dp) up[e], rows a < na read down a column (stride ld)
-template <int NB>
-__device__ __forceinline__ void inv_step(double* T, int ld, const double* fcol, const double* up, double dp, int na, int ne, int tid, double* dummy)
-{
-    if (na <= 0 || ne <= 0) return;
-    const int ta = tid >> 4, te = tid & 15;
-    double fa[NB], fe[NB], v[NB][NB];
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-        fa[u] = fcol[min(ta + 16 * u, na - 1) * ld];
-        fe[u] = up[min(te + 16 * u, ne - 1)];
-    }
-#pragma unroll
-    for (int u = 0; u < NB; ++u)
-#pragma unroll
-        for (int w = 0; w < NB; ++w) v[u][w] = T[min(ta + 16 * u, na - 1) * ld + min(te + 16 * w, ne - 1)];
-#pragma unroll
-    for (int u = 0; u < NB; ++u)
-#pragma unroll
-        for (int w = 0; w < NB; ++w) {
-            const int a = ta + 16 * u, e = te + 16 * w;
-            double* dst = (a < na && e < ne) ? (T + a * ld + e) : dummy;
-            *dst = fma(-(fa[u] * dp), fe[w], v[u][w]);
-        }
-}
 
 // One Householder step of the QR of B (n x m, leading dimension c.ldb) on column j.  Thread (column e = j+1+(tid>>4),
 // rows kk = j + (tid&15) + 16 t, t < NT = ceil((n-j)/16)).  B carries 16 zero rows below row n-1, so rows past the end need no

@@ -299,10 +299,25 @@ def tiago_structure(nv: int = 12) -> Structure:
     return _mk("tiago", nv, nv, [], dense, None, sc, True, False, [(INEQ_BOUNDS, 0)])
 
 
+def three_contact_structure(nv: int = 36, na: int = 30) -> Structure:
+    """Not a shipped inria_wbc stack: a floating-base robot with THREE 6-D contacts (two feet and a hand), odd contact
+    count and 24 equalities. Exercises the code paths the shipped stacks do not reach (sequential equality phase,
+    unpaired contact block)."""
+    pts = contact6d_points(lxn=0.06, lyn=0.045, lxp=0.14, lyp=0.045, lz=0.065)
+    contacts = [Contact("contact_lfoot", pts, (0.0, 0.0, 1.0), 0.4, 5.0, 1200.0),
+                Contact("contact_rfoot", pts, (0.0, 0.0, 1.0), 0.4, 5.0, 1200.0),
+                Contact("contact_lhand", pts, (0.0, 0.0, 1.0), 0.5, 1.0, 500.0)]
+    dense = [("lh", 6, 10.0), ("rh", 6, 10.0), ("lf", 6, 1000.0), ("rf", 6, 1000.0), ("com", 3, 1000.0),
+             ("__posture__", "posture", 0.5), ("momentum", 2, 100.0), ("__contacts__",)]
+    level0 = [(INEQ_BOUNDS, 0), (INEQ_ACTUATION, 0), (INEQ_FORCE, 0), (INEQ_FORCE, 1), (INEQ_FORCE, 2)]
+    return _mk("three_contact", nv, na, contacts, dense, None, [], True, True, level0)
+
+
 STRUCTURES = {
     "talos": talos_structure,
     "talos_single_support": lambda: talos_structure(single_support=True),
     "icub": icub_structure,
     "franka": franka_structure,
     "tiago": tiago_structure,
+    "three_contact": three_contact_structure,
 }

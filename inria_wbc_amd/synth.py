@@ -21,7 +21,7 @@ from .trajs import move_com_stream
 FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
 
 SEED_BASE = {"franka": 1_000_000, "talos": 2_000_000, "icub": 3_000_000, "talos_squat": 4_000_000, "ragged": 5_000_000,
-             "tiago": 6_000_000, "talos_single_support": 7_000_000}
+             "tiago": 6_000_000, "talos_single_support": 7_000_000, "three_contact": 8_000_000}
 
 
 def _spd_mass(rng, nv: int, nu: int) -> np.ndarray:

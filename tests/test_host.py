@@ -51,7 +51,7 @@ def test_layout_without_gpu(built_lib):
     from inria_wbc_amd import capi
     for name, mk in structure.STRUCTURES.items():
         st = mk()
-        L = capi.layout_of(st)
+        L = capi.layout_of(st)  # includes the synthetic three-contact stack
         assert (L["n"], L["neq"], L["nin"], L["nin2"], L["r1"]) == (st.n, st.neq, st.nin, st.nin2, st.r1)
         fl = st.field_lengths()
         for k in capi.FIELDS:
