@@ -35,7 +35,7 @@ extern "C" {
 #define WBCQP_VERSION 100 /* 0.1.0 */
 #define WBCQP_MAX_STRUCTURES 16
 #define WBCQP_MAX_INEQ_BLOCKS 16
-#define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: two 64-lane row sets, n + 2 <= 128 */
+#define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: every per-QP vector fits one 128-entry LDS slot, n + 2 <= 128 */
 
 /* ---- return codes of the API itself ---- */
 typedef enum {
@@ -111,14 +111,14 @@ typedef struct {
     int32_t r1;   /* level-1 rows = n_dense + n_sel + 6 nc */
     /* element counts of the per-QP input arrays below */
     int32_t len_M, len_h, len_A, len_b1, len_Ac, len_bc, len_blb, len_bub, len_tlb, len_tub, len_w;
-    int32_t lds_bytes;         /* dynamic LDS one wavefront needs */
-    int32_t waves_per_cu;      /* resident QPs per CU that LDS admits */
+    int32_t lds_bytes;         /* dynamic LDS one QP (one 256-thread workgroup) needs */
+    int32_t waves_per_cu;      /* resident QPs (workgroups) per CU that LDS admits */
     int64_t algorithmic_bytes; /* compact in+out bytes per QP at WBCQP_F64 */
 } wbcqp_layout;
 
 /*
  * Per-QP inputs, each a contiguous [batch][len] row-major array of the handle's dtype.
- * One wavefront reads one QP's rows, so consecutive lanes read consecutive addresses.
+ * One workgroup reads one QP's rows, so consecutive lanes read consecutive addresses.
  */
 typedef struct {
     const void* M;   /* [batch][nv(nv+1)/2] inertia matrix, packed lower triangle (i>=j at i(i+1)/2+j)      */

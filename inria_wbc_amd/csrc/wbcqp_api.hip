@@ -118,7 +118,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
 
     // ---- LDS layout (doubles) ----
     const int n = D.n, nv = D.nv;
-    D.ldj = odd(n); D.ldm = odd(nv); D.ldc = odd(nv); D.ldb = odd(D.neq) + 2; // + 2: 8-wide column groups may read past m
+    D.ldj = odd(n); D.ldm = odd(nv); D.ldc = odd(nv); D.ldb = 2 * odd((4 * ((D.neq + 3) / 4) + 1) / 2); // twice an odd number: rows stay 16-byte aligned for the 4-wide column groups (which may read past m) and 16 rows still hit 16 distinct bank groups
     int o = 0;
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; }; // keep 16-byte alignment
     D.o_J = take(n * D.ldj);
