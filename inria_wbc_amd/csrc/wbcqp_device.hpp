@@ -279,6 +279,15 @@ __device__ __forceinline__ int block_max_int(Ctx& c, int v)
 // LDS table) -- it matters in the loops that are LDS-bound.  opaque() hides how a pointer was derived, so the load/store
 // optimizer cannot pair its accesses with a neighbour's; ld2() is the 16-byte-aligned pair read.
 typedef double double2v __attribute__((ext_vector_type(2)));
+// 1/x to full precision without the IEEE division's scaling and fix-up: v_rcp_f64 and two Newton steps
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ double2v ld2(const double* p) { return *reinterpret_cast<const double2v*>(__builtin_assume_aligned(p, 16)); }
 __device__ __forceinline__ int wave_min_int(int v) { return -wave_max_int(-v); }
@@ -1384,92 +1393,136 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
             }
         }
         STAMP(1)
-        // publishes row jn (final after step jn-1): strict upper part into the J buffer; the owner of the diagonal turns
-        // the pivot into 1/U(jn,jn) (dinv) and 1/U(jn,jn)^2 (q[]) so that nobody else needs the rsqrt.  UU = jn >> 4 is a
-        // compile-time constant: register indices stay static and the loop below only touches live positions.
-        auto publish_row = [&](auto UUc, int jn) __attribute__((always_inline)) {
-            constexpr int UU = decltype(UUc)::value;
-            if (ta == (jn & 15)) {
-                double* Jr = c.J + jn * ldj;
+        // positions past nv: identity, so that the pivots of the padded last panel are inert
 #pragma unroll
-                for (int w = UU; w < 4; ++w) {
-                    const int cc = te + 16 * w;
-                    if (cc > jn && cc < nv) Jr[cc] = h[UU][w];
-                }
-                if (te == ta) { // the one owner of the diagonal
-                    const double inv = rsqrt(h[UU][UU]);
-                    c.dinv[jn] = inv;
-                    c.q[jn] = inv * inv;
-                }
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = u; w < 4; ++w) {
+                const int r = ta + 16 * u, q = te + 16 * w;
+                if (r >= nv || q >= nv) h[u][w] = (r == q) ? 1.0 : 0.0;
             }
-        };
-        // ---- fused loop: step j applies BOTH the Cholesky update of the trailing matrix (h) and the update of the
-        //      inverse (y, from zero): Y(r,q) -= U(j,q) J(r,j) for r < j < q, unit pivot for r = j.  Row j of U is read once
-        //      for both.  The published column j is raw (Y(r,j), r < j; 1 at r = j; rows r > j never written, both buffers
-        //      start zeroed and each publication covers every row the previous one in that buffer touched); readers scale
-        //      it by dinv[j]^2 (= q[j]).  One barrier per step.  Within the block of 16 steps JB only h[u >= JB][.] and
-        //      y[u <= JB][w >= JB] can change: 14 / 12 / 9 / 5 FMAs per step instead of 20.
+        // ---- blocked elimination, four pivots per barrier.  S = [H; Y] (Y from the identity) is reduced by column
+        //      operations: with P the four pivot columns, S(:,k) -= S(:,P) H_PP^-1 H_Pk for every later column k.  What the
+        //      sequential form publishes one row / one column at a time travels once per panel, RAW: the four pivot rows of
+        //      H (rb[column][p]) and the four pivot columns of Y (yb[row][p]).  Every thread factors the 4 x 4 pivot block
+        //      itself (H_PP = U~' D U~, U~ unit upper triangular, four chained reciprocals) and brings its own slices of
+        //      the rows / columns to the state the sequential elimination would have published (x' = U~^-T x).
+        //      J = U^-1 then is Y scaled by 1/sqrt(pivot) as before.  JB = panel start >> 4 is a compile-time constant per
+        //      block of four panels: only h[u >= JB][.] and y[u <= JB][w >= JB] can change.
         double y[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int w = 0; w < 4; ++w) y[u][w] = 0.0;
-        c.stash[tid] = 0.0;
-        auto publish_col = [&](auto UUc, int pn) __attribute__((always_inline)) {
+        double* RB = c.s;      // [2][64][4]
+        double* YB = c.stash;  // [2][64][4] (stash + the first two slots of part)
+        auto publish = [&](auto UUc, int j0n) __attribute__((always_inline)) {
             constexpr int UU = decltype(UUc)::value;
-            if (te == (pn & 15)) {
-                double* colb = c.stash + (pn & 1) * 128;
+            const int par = (j0n >> 2) & 1;
+            const int grp = (j0n & 15) >> 2;
+            if ((ta >> 2) == grp) { // rows j0n + p, p = ta & 3: one whole wave
+                double* dst = RB + par * 256 + (ta & 3);
 #pragma unroll
-                for (int u = 0; u < UU; ++u) colb[ta + 16 * u] = y[u][UU];
+                for (int w = UU; w < 4; ++w) dst[(te + 16 * w) * 4] = h[UU][w];
+            }
+            if ((te >> 2) == grp) { // columns j0n + p of Y, p = te & 3
+                const int pp = te & 3;
+                double* dst = YB + par * 256 + pp;
+#pragma unroll
+                for (int u = 0; u < UU; ++u) dst[(ta + 16 * u) * 4] = y[u][UU];
                 const int r = ta + 16 * UU;
-                if (r < pn) colb[r] = y[UU][UU];
-                else if (r == pn) colb[r] = 1.0;
+                dst[r * 4] = (r < j0n) ? y[UU][UU] : ((r == j0n + pp) ? 1.0 : 0.0);
             }
         };
         auto factor_block = [&](auto JBc) __attribute__((always_inline)) {
             constexpr int JB = decltype(JBc)::value;
             constexpr int JN = (JB < 3) ? JB + 1 : 3;
-            const int jend = min(16 * JB + 16, nv);
-            for (int j = 16 * JB; j < jend; ++j) {
+            const int nvp = (nv + 3) & ~3;
+            const int jend = min(16 * JB + 16, nvp);
+            for (int j0 = 16 * JB; j0 < jend; j0 += 4) {
                 bsync();
-                const double* Jr = c.J + j * ldj;
-                const double* colb = c.stash + (j & 1) * 128;
-                const double inv2 = c.q[j];
-                double fa[4], fe[4], fr[4];
+                const int par = (j0 >> 2) & 1;
+                const double* rb = RB + par * 256;
+                const double* yb = YB + par * 256;
+                // operands: pivot block, this thread's row-role and column-role slices, its rows of Y
+                double2v hq[4][2], fa[4][2], fe[4][2], fr[4][2];
 #pragma unroll
-                for (int u = JB; u < 4; ++u) {
-                    fa[u] = Jr[ta + 16 * u]; // columns <= j of row j are zero (the diagonal never enters the buffer)
-                    fe[u] = Jr[te + 16 * u];
+                for (int q = 0; q < 4; ++q) {
+                    hq[q][0] = ld2(rb + (j0 + q) * 4);
+                    hq[q][1] = ld2(rb + (j0 + q) * 4 + 2);
                 }
 #pragma unroll
-                for (int u = 0; u <= JB; ++u) fr[u] = colb[ta + 16 * u];
-#pragma unroll
                 for (int u = JB; u < 4; ++u) {
-                    const double f = fa[u] * inv2;
-#pragma unroll
-                    for (int w = u; w < 4; ++w) h[u][w] = fma(-f, fe[w], h[u][w]);
+                    fe[u][0] = ld2(rb + (te + 16 * u) * 4);
+                    fe[u][1] = ld2(rb + (te + 16 * u) * 4 + 2);
+                    fa[u][0] = ld2(rb + (ta + 16 * u) * 4);
+                    fa[u][1] = ld2(rb + (ta + 16 * u) * 4 + 2);
                 }
 #pragma unroll
                 for (int u = 0; u <= JB; ++u) {
-                    const double g2 = fr[u] * inv2;
-#pragma unroll
-                    for (int w = JB; w < 4; ++w) y[u][w] = fma(-g2, fe[w], y[u][w]);
+                    fr[u][0] = ld2(yb + (ta + 16 * u) * 4);
+                    fr[u][1] = ld2(yb + (ta + 16 * u) * 4 + 2);
                 }
-                if (j + 1 < nv) {
-                    if (j + 1 < 16 * JB + 16) {
-                        publish_row(std::integral_constant<int, JB>{}, j + 1);
-                        publish_col(std::integral_constant<int, JB>{}, j + 1);
+                // H_PP = U~' D U~ : H(p,q) = hq[q][p>>1][p&1] for p <= q
+                const double a0 = hq[0][0].x, i0 = fast_rcp(a0);
+                const double u01 = hq[1][0].x * i0, u02 = hq[2][0].x * i0, u03 = hq[3][0].x * i0;
+                const double a1 = fma(-u01, hq[1][0].x, hq[1][0].y), i1 = fast_rcp(a1);
+                const double t12 = fma(-u01, hq[2][0].x, hq[2][0].y), t13 = fma(-u01, hq[3][0].x, hq[3][0].y);
+                const double u12 = t12 * i1, u13 = t13 * i1;
+                const double a2 = fma(-u12, t12, fma(-u02, hq[2][0].x, hq[2][1].x)), i2 = fast_rcp(a2);
+                const double t23 = fma(-u12, t13, fma(-u02, hq[3][0].x, hq[3][1].x));
+                const double u23 = t23 * i2;
+                const double a3 = fma(-u23, t23, fma(-u13, t13, fma(-u03, hq[3][0].x, hq[3][1].y))), i3 = fast_rcp(a3);
+                auto xform = [&](double2v (&x)[2]) __attribute__((always_inline)) { // x' = U~^-T x (also g' = g U~^-1)
+                    x[0].y = fma(-u01, x[0].x, x[0].y);
+                    x[1].x = fma(-u12, x[0].y, fma(-u02, x[0].x, x[1].x));
+                    x[1].y = fma(-u23, x[1].x, fma(-u13, x[0].y, fma(-u03, x[0].x, x[1].y)));
+                };
+#pragma unroll
+                for (int u = JB; u < 4; ++u) {
+                    xform(fa[u]);
+                    xform(fe[u]);
+                    fe[u][0].x *= i0; fe[u][0].y *= i1; fe[u][1].x *= i2; fe[u][1].y *= i3;
+                }
+                if (te + 16 * JB < j0 + 4) { // columns up to the end of the panel take no update
+                    fe[JB][0].x = 0.0; fe[JB][0].y = 0.0; fe[JB][1].x = 0.0; fe[JB][1].y = 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u <= JB; ++u) xform(fr[u]);
+#pragma unroll
+                for (int u = JB; u < 4; ++u)
+#pragma unroll
+                    for (int w = u; w < 4; ++w)
+                        h[u][w] = fma(-fa[u][1].y, fe[w][1].y, fma(-fa[u][1].x, fe[w][1].x,
+                                  fma(-fa[u][0].y, fe[w][0].y, fma(-fa[u][0].x, fe[w][0].x, h[u][w]))));
+#pragma unroll
+                for (int u = 0; u <= JB; ++u)
+#pragma unroll
+                    for (int w = JB; w < 4; ++w)
+                        y[u][w] = fma(-fr[u][1].y, fe[w][1].y, fma(-fr[u][1].x, fe[w][1].x,
+                                  fma(-fr[u][0].y, fe[w][0].y, fma(-fr[u][0].x, fe[w][0].x, y[u][w]))));
+                // the pivot columns of Y themselves are final now
+                if ((te >> 2) == ((j0 & 15) >> 2)) {
+                    const int pp = te & 3;
+#pragma unroll
+                    for (int u = 0; u <= JB; ++u) {
+                        const double lo = (pp & 1) ? fr[u][0].y : fr[u][0].x;
+                        const double hi = (pp & 1) ? fr[u][1].y : fr[u][1].x;
+                        y[u][JB] = (pp & 2) ? hi : lo;
                     }
-                    else {
-                        publish_row(std::integral_constant<int, JN>{}, j + 1);
-                        publish_col(std::integral_constant<int, JN>{}, j + 1);
-                    }
+                }
+                if (tid >= 128 && tid < 132) { // 1/sqrt(pivot), off the publishing wave's path
+                    const int pp = tid & 3;
+                    const double lo = (pp & 1) ? a1 : a0, hi = (pp & 1) ? a3 : a2;
+                    c.dinv[j0 + pp] = rsqrt((pp & 2) ? hi : lo);
+                }
+                if (j0 + 4 < nvp) {
+                    if (j0 + 4 < 16 * JB + 16) publish(std::integral_constant<int, JB>{}, j0 + 4);
+                    else publish(std::integral_constant<int, JN>{}, j0 + 4);
                 }
             }
         };
-        bsync();
-        publish_row(std::integral_constant<int, 0>{}, 0);
-        publish_col(std::integral_constant<int, 0>{}, 0);
+        publish(std::integral_constant<int, 0>{}, 0);
         factor_block(std::integral_constant<int, 0>{});
         if (nv > 16) factor_block(std::integral_constant<int, 1>{});
         if (nv > 32) factor_block(std::integral_constant<int, 2>{});
