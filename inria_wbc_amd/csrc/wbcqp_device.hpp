@@ -1173,6 +1173,134 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
 
 
 // ------------------------------------------------------------------------------------------------
+// Blocked elimination H -> (pivots, Y) with J = U^-1 = Y diag(1/sqrt(pivot)), four pivots per synchronisation.
+// Ownership: a G x G thread grid (G = 1 << LG); thread (ta, te) keeps positions (ta + G u, te + G w), u <= w < NU, of H
+// (h) and of Y (y, from zero) in registers for the whole factorisation.  S = [H; Y] (Y from the identity) is reduced by
+// column operations: with P the four pivot columns, S(:,k) -= S(:,P) H_PP^-1 H_Pk for every later column k.  Only the
+// four pivot rows of H (rb[column][p]) and the four pivot columns of Y (yb[row][p]) travel through LDS, RAW, once per
+// panel; every thread factors the 4 x 4 pivot block itself (H_PP = U~' D U~, U~ unit upper triangular, four chained
+// reciprocals) and brings its own slices to the state a pivot-by-pivot elimination would have published
+// (x' = U~^-T x).  JB = panel start / G is a compile-time constant: only h[u >= JB][.] and y[u <= JB][w >= JB] change.
+// WLOCAL: the grid is one wavefront -- LDS operations of a wave execute in order, no workgroup barrier is needed and
+// one buffer suffices; otherwise one barrier per panel and two buffers.  Positions past the matrix must hold the identity.
+// ------------------------------------------------------------------------------------------------
+template <int LG, int NU, bool WLOCAL, int UU>
+__device__ __forceinline__ void publish_panel(Ctx& c, double (&h)[NU][NU], double (&y)[NU][NU], int ta, int te, int j0n,
+                                              double* RB, double* YB)
+{
+    constexpr int G = 1 << LG, PS = NU * G * 4;
+    const int par = WLOCAL ? 0 : ((j0n >> 2) & 1);
+    const int grp = (j0n & (G - 1)) >> 2;
+    if ((ta >> 2) == grp) { // rows j0n + p, p = ta & 3
+        double* dst = RB + par * PS + (ta & 3);
+#pragma unroll
+        for (int w = UU; w < NU; ++w) dst[(te + G * w) * 4] = h[UU][w];
+    }
+    if ((te >> 2) == grp) { // columns j0n + p of Y, p = te & 3
+        const int pp = te & 3;
+        double* dst = YB + par * PS + pp;
+#pragma unroll
+        for (int u = 0; u < UU; ++u) dst[(ta + G * u) * 4] = y[u][UU];
+        const int r = ta + G * UU;
+        dst[r * 4] = (r < j0n) ? y[UU][UU] : ((r == j0n + pp) ? 1.0 : 0.0);
+    }
+}
+
+template <int LG, int NU, bool WLOCAL, int JB>
+__device__ __forceinline__ void eliminate_block(Ctx& c, double (&h)[NU][NU], double (&y)[NU][NU], int ta, int te, int npad,
+                                                double* RB, double* YB, double* dinv, bool dwriter, int dp)
+{
+    constexpr int G = 1 << LG, PS = NU * G * 4;
+    constexpr int JN = (JB + 1 < NU) ? JB + 1 : JB;
+    const int jend = min(G * JB + G, npad);
+    for (int j0 = G * JB; j0 < jend; j0 += 4) {
+        if (WLOCAL) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+        const int par = WLOCAL ? 0 : ((j0 >> 2) & 1);
+        const double* rb = RB + par * PS;
+        const double* yb = YB + par * PS;
+        // operands: pivot block, this thread's row-role and column-role slices, its rows of Y
+        double2v hq[4][2], fa[NU][2], fe[NU][2], fr[NU][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            hq[q][0] = ld2(rb + (j0 + q) * 4);
+            hq[q][1] = ld2(rb + (j0 + q) * 4 + 2);
+        }
+#pragma unroll
+        for (int u = JB; u < NU; ++u) {
+            fe[u][0] = ld2(rb + (te + G * u) * 4);
+            fe[u][1] = ld2(rb + (te + G * u) * 4 + 2);
+            fa[u][0] = ld2(rb + (ta + G * u) * 4);
+            fa[u][1] = ld2(rb + (ta + G * u) * 4 + 2);
+        }
+#pragma unroll
+        for (int u = 0; u <= JB; ++u) {
+            fr[u][0] = ld2(yb + (ta + G * u) * 4);
+            fr[u][1] = ld2(yb + (ta + G * u) * 4 + 2);
+        }
+        // H_PP = U~' D U~ : H(p,q) = hq[q][p>>1][p&1] for p <= q
+        const double a0 = hq[0][0].x, i0 = fast_rcp(a0);
+        const double u01 = hq[1][0].x * i0, u02 = hq[2][0].x * i0, u03 = hq[3][0].x * i0;
+        const double a1 = fma(-u01, hq[1][0].x, hq[1][0].y), i1 = fast_rcp(a1);
+        const double t12 = fma(-u01, hq[2][0].x, hq[2][0].y), t13 = fma(-u01, hq[3][0].x, hq[3][0].y);
+        const double u12 = t12 * i1, u13 = t13 * i1;
+        const double a2 = fma(-u12, t12, fma(-u02, hq[2][0].x, hq[2][1].x)), i2 = fast_rcp(a2);
+        const double t23 = fma(-u12, t13, fma(-u02, hq[3][0].x, hq[3][1].x));
+        const double u23 = t23 * i2;
+        const double a3 = fma(-u23, t23, fma(-u13, t13, fma(-u03, hq[3][0].x, hq[3][1].y))), i3 = fast_rcp(a3);
+        auto xform = [&](double2v (&x)[2]) __attribute__((always_inline)) { // x' = U~^-T x (also g' = g U~^-1)
+            x[0].y = fma(-u01, x[0].x, x[0].y);
+            x[1].x = fma(-u12, x[0].y, fma(-u02, x[0].x, x[1].x));
+            x[1].y = fma(-u23, x[1].x, fma(-u13, x[0].y, fma(-u03, x[0].x, x[1].y)));
+        };
+#pragma unroll
+        for (int u = JB; u < NU; ++u) {
+            xform(fa[u]);
+            xform(fe[u]);
+            fe[u][0].x *= i0; fe[u][0].y *= i1; fe[u][1].x *= i2; fe[u][1].y *= i3;
+        }
+        if (te + G * JB < j0 + 4) { // columns up to the end of the panel take no update
+            fe[JB][0].x = 0.0; fe[JB][0].y = 0.0; fe[JB][1].x = 0.0; fe[JB][1].y = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u <= JB; ++u) xform(fr[u]);
+#pragma unroll
+        for (int u = JB; u < NU; ++u)
+#pragma unroll
+            for (int w = u; w < NU; ++w)
+                h[u][w] = fma(-fa[u][1].y, fe[w][1].y, fma(-fa[u][1].x, fe[w][1].x,
+                          fma(-fa[u][0].y, fe[w][0].y, fma(-fa[u][0].x, fe[w][0].x, h[u][w]))));
+#pragma unroll
+        for (int u = 0; u <= JB; ++u)
+#pragma unroll
+            for (int w = JB; w < NU; ++w)
+                y[u][w] = fma(-fr[u][1].y, fe[w][1].y, fma(-fr[u][1].x, fe[w][1].x,
+                          fma(-fr[u][0].y, fe[w][0].y, fma(-fr[u][0].x, fe[w][0].x, y[u][w]))));
+        // the pivot columns of Y themselves are final now
+        if ((te >> 2) == ((j0 & (G - 1)) >> 2)) {
+            const int pp = te & 3;
+#pragma unroll
+            for (int u = 0; u <= JB; ++u) {
+                const double lo = (pp & 1) ? fr[u][0].y : fr[u][0].x;
+                const double hi = (pp & 1) ? fr[u][1].y : fr[u][1].x;
+                y[u][JB] = (pp & 2) ? hi : lo;
+            }
+        }
+        if (dwriter) { // 1/sqrt(pivot)
+            const double lo = (dp & 1) ? a1 : a0, hi = (dp & 1) ? a3 : a2;
+            dinv[j0 + dp] = rsqrt((dp & 2) ? hi : lo);
+        }
+        if (j0 + 4 < npad) {
+            if (j0 + 4 < G * JB + G) publish_panel<LG, NU, WLOCAL, JB>(c, h, y, ta, te, j0 + 4, RB, YB);
+            else publish_panel<LG, NU, WLOCAL, JN>(c, h, y, ta, te, j0 + 4, RB, YB);
+        }
+    }
+    if constexpr (JB + 1 < NU) {
+        if (npad > G * (JB + 1)) eliminate_block<LG, NU, WLOCAL, JB + 1>(c, h, y, ta, te, npad, RB, YB, dinv, dwriter, dp);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // one QP on one workgroup of 256 threads
 // ------------------------------------------------------------------------------------------------
 template <typename TI>
@@ -1401,132 +1529,26 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                 const int r = ta + 16 * u, q = te + 16 * w;
                 if (r >= nv || q >= nv) h[u][w] = (r == q) ? 1.0 : 0.0;
             }
-        // ---- blocked elimination, four pivots per barrier.  S = [H; Y] (Y from the identity) is reduced by column
-        //      operations: with P the four pivot columns, S(:,k) -= S(:,P) H_PP^-1 H_Pk for every later column k.  What the
-        //      sequential form publishes one row / one column at a time travels once per panel, RAW: the four pivot rows of
-        //      H (rb[column][p]) and the four pivot columns of Y (yb[row][p]).  Every thread factors the 4 x 4 pivot block
-        //      itself (H_PP = U~' D U~, U~ unit upper triangular, four chained reciprocals) and brings its own slices of
-        //      the rows / columns to the state the sequential elimination would have published (x' = U~^-T x).
-        //      J = U^-1 then is Y scaled by 1/sqrt(pivot) as before.  JB = panel start >> 4 is a compile-time constant per
-        //      block of four panels: only h[u >= JB][.] and y[u <= JB][w >= JB] can change.
+        // ---- H -> J = U^-1 by blocked elimination (eliminate_block), four pivots per barrier
         double y[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int w = 0; w < 4; ++w) y[u][w] = 0.0;
-        double* RB = c.s;      // [2][64][4]
-        double* YB = c.stash;  // [2][64][4] (stash + the first two slots of part)
-        auto publish = [&](auto UUc, int j0n) __attribute__((always_inline)) {
-            constexpr int UU = decltype(UUc)::value;
-            const int par = (j0n >> 2) & 1;
-            const int grp = (j0n & 15) >> 2;
-            if ((ta >> 2) == grp) { // rows j0n + p, p = ta & 3: one whole wave
-                double* dst = RB + par * 256 + (ta & 3);
+        // the force-regularisation blocks H_ff = w F'F + reg I (12 x 12 per contact) go one per wave afterwards; their
+        // constants are fetched now so that the loads overlap the dv block
+        const int la = c.lane >> 3, le = c.lane & 7;
+        double hF[2][2], yF[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        {
+            const int cs = (c.wave < nc) ? c.wave : 0;
+            const double* ftf = S.ftf + cs * 144;
 #pragma unroll
-                for (int w = UU; w < 4; ++w) dst[(te + 16 * w) * 4] = h[UU][w];
-            }
-            if ((te >> 2) == grp) { // columns j0n + p of Y, p = te & 3
-                const int pp = te & 3;
-                double* dst = YB + par * 256 + pp;
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int u = 0; u < UU; ++u) dst[(ta + 16 * u) * 4] = y[u][UU];
-                const int r = ta + 16 * UU;
-                dst[r * 4] = (r < j0n) ? y[UU][UU] : ((r == j0n + pp) ? 1.0 : 0.0);
-            }
-        };
-        auto factor_block = [&](auto JBc) __attribute__((always_inline)) {
-            constexpr int JB = decltype(JBc)::value;
-            constexpr int JN = (JB < 3) ? JB + 1 : 3;
-            const int nvp = (nv + 3) & ~3;
-            const int jend = min(16 * JB + 16, nvp);
-            for (int j0 = 16 * JB; j0 < jend; j0 += 4) {
-                bsync();
-                const int par = (j0 >> 2) & 1;
-                const double* rb = RB + par * 256;
-                const double* yb = YB + par * 256;
-                // operands: pivot block, this thread's row-role and column-role slices, its rows of Y
-                double2v hq[4][2], fa[4][2], fe[4][2], fr[4][2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    hq[q][0] = ld2(rb + (j0 + q) * 4);
-                    hq[q][1] = ld2(rb + (j0 + q) * 4 + 2);
-                }
-#pragma unroll
-                for (int u = JB; u < 4; ++u) {
-                    fe[u][0] = ld2(rb + (te + 16 * u) * 4);
-                    fe[u][1] = ld2(rb + (te + 16 * u) * 4 + 2);
-                    fa[u][0] = ld2(rb + (ta + 16 * u) * 4);
-                    fa[u][1] = ld2(rb + (ta + 16 * u) * 4 + 2);
-                }
-#pragma unroll
-                for (int u = 0; u <= JB; ++u) {
-                    fr[u][0] = ld2(yb + (ta + 16 * u) * 4);
-                    fr[u][1] = ld2(yb + (ta + 16 * u) * 4 + 2);
-                }
-                // H_PP = U~' D U~ : H(p,q) = hq[q][p>>1][p&1] for p <= q
-                const double a0 = hq[0][0].x, i0 = fast_rcp(a0);
-                const double u01 = hq[1][0].x * i0, u02 = hq[2][0].x * i0, u03 = hq[3][0].x * i0;
-                const double a1 = fma(-u01, hq[1][0].x, hq[1][0].y), i1 = fast_rcp(a1);
-                const double t12 = fma(-u01, hq[2][0].x, hq[2][0].y), t13 = fma(-u01, hq[3][0].x, hq[3][0].y);
-                const double u12 = t12 * i1, u13 = t13 * i1;
-                const double a2 = fma(-u12, t12, fma(-u02, hq[2][0].x, hq[2][1].x)), i2 = fast_rcp(a2);
-                const double t23 = fma(-u12, t13, fma(-u02, hq[3][0].x, hq[3][1].x));
-                const double u23 = t23 * i2;
-                const double a3 = fma(-u23, t23, fma(-u13, t13, fma(-u03, hq[3][0].x, hq[3][1].y))), i3 = fast_rcp(a3);
-                auto xform = [&](double2v (&x)[2]) __attribute__((always_inline)) { // x' = U~^-T x (also g' = g U~^-1)
-                    x[0].y = fma(-u01, x[0].x, x[0].y);
-                    x[1].x = fma(-u12, x[0].y, fma(-u02, x[0].x, x[1].x));
-                    x[1].y = fma(-u23, x[1].x, fma(-u13, x[0].y, fma(-u03, x[0].x, x[1].y)));
-                };
-#pragma unroll
-                for (int u = JB; u < 4; ++u) {
-                    xform(fa[u]);
-                    xform(fe[u]);
-                    fe[u][0].x *= i0; fe[u][0].y *= i1; fe[u][1].x *= i2; fe[u][1].y *= i3;
-                }
-                if (te + 16 * JB < j0 + 4) { // columns up to the end of the panel take no update
-                    fe[JB][0].x = 0.0; fe[JB][0].y = 0.0; fe[JB][1].x = 0.0; fe[JB][1].y = 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u <= JB; ++u) xform(fr[u]);
-#pragma unroll
-                for (int u = JB; u < 4; ++u)
-#pragma unroll
-                    for (int w = u; w < 4; ++w)
-                        h[u][w] = fma(-fa[u][1].y, fe[w][1].y, fma(-fa[u][1].x, fe[w][1].x,
-                                  fma(-fa[u][0].y, fe[w][0].y, fma(-fa[u][0].x, fe[w][0].x, h[u][w]))));
-#pragma unroll
-                for (int u = 0; u <= JB; ++u)
-#pragma unroll
-                    for (int w = JB; w < 4; ++w)
-                        y[u][w] = fma(-fr[u][1].y, fe[w][1].y, fma(-fr[u][1].x, fe[w][1].x,
-                                  fma(-fr[u][0].y, fe[w][0].y, fma(-fr[u][0].x, fe[w][0].x, y[u][w]))));
-                // the pivot columns of Y themselves are final now
-                if ((te >> 2) == ((j0 & 15) >> 2)) {
-                    const int pp = te & 3;
-#pragma unroll
-                    for (int u = 0; u <= JB; ++u) {
-                        const double lo = (pp & 1) ? fr[u][0].y : fr[u][0].x;
-                        const double hi = (pp & 1) ? fr[u][1].y : fr[u][1].x;
-                        y[u][JB] = (pp & 2) ? hi : lo;
-                    }
-                }
-                if (tid >= 128 && tid < 132) { // 1/sqrt(pivot), off the publishing wave's path
-                    const int pp = tid & 3;
-                    const double lo = (pp & 1) ? a1 : a0, hi = (pp & 1) ? a3 : a2;
-                    c.dinv[j0 + pp] = rsqrt((pp & 2) ? hi : lo);
-                }
-                if (j0 + 4 < nvp) {
-                    if (j0 + 4 < 16 * JB + 16) publish(std::integral_constant<int, JB>{}, j0 + 4);
-                    else publish(std::integral_constant<int, JN>{}, j0 + 4);
-                }
-            }
-        };
-        publish(std::integral_constant<int, 0>{}, 0);
-        factor_block(std::integral_constant<int, 0>{});
-        if (nv > 16) factor_block(std::integral_constant<int, 1>{});
-        if (nv > 32) factor_block(std::integral_constant<int, 2>{});
-        if (nv > 48) factor_block(std::integral_constant<int, 3>{});
+                for (int w = 0; w < 2; ++w) hF[u][w] = (nc > 0) ? ftf[min(la + 8 * u, 11) * 12 + min(le + 8 * w, 11)] : 0.0;
+        }
+        publish_panel<4, 4, false, 0>(c, h, y, ta, te, 0, c.s, c.stash);
+        eliminate_block<4, 4, false, 0>(c, h, y, ta, te, (nv + 3) & ~3, c.s, c.stash, c.dinv, tid >= 128 && tid < 132, tid & 3);
         STAMP(2)
         bsync();
         // final: J(r,q) = Y(r,q) dinv[q], J(r,r) = dinv[r]
@@ -1538,74 +1560,44 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                 if (q < nv && r < q) c.J[r * ldj + q] = y[u][w] * c.dinv[q];
                 else if (r == q && r < nv) c.J[r * ldj + r] = c.dinv[r];
             }
-        // ---- the 12 x 12 force-regularisation blocks, two contacts at a time, same fused scheme with one position per thread
-        for (int ct0 = 0; ct0 < nc; ct0 += 2) {
-            double hf[2], yf[2];
-            int fb[2];
-            bool cv[2];
-            const bool mine = ta < 12 && te < 12 && te >= ta;
+        // ---- force blocks: wave-local (8 x 8 lane grid, 2 x 2 positions per lane), no workgroup barrier inside
+        for (int ct = c.wave; ct < nc; ct += kWaves) {
+            const int fb = nv + 12 * ct;
+            const double wt = c.w[S.forcereg_task[ct]];
+            if (ct != c.wave) { // contacts beyond the first four: fetch now
+                const double* ftf = S.ftf + ct * 144;
 #pragma unroll
-            for (int z2 = 0; z2 < 2; ++z2) {
-                const int ct = ct0 + z2;
-                cv[z2] = ct < nc;
-                const int cs = cv[z2] ? ct : ct0;
-                fb[z2] = nv + 12 * cs;
-                const double wt = c.w[S.forcereg_task[cs]];
-                hf[z2] = mine ? wt * S.ftf[cs * 144 + ta * 12 + te] : 0.0;
-                yf[z2] = 0.0;
-                if (mine && ta == te) {
-                    hf[z2] += S.hessian_reg;
-                    if (cv[z2]) trace += hf[z2];
-                }
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) hF[u][w] = ftf[min(la + 8 * u, 11) * 12 + min(le + 8 * w, 11)];
             }
-            bsync();
-            if (tid < 64) c.stash[(tid >> 5) * 128 + (tid & 31)] = 0.0;
-            bsync();
-            auto pub = [&](int sn) __attribute__((always_inline)) {
-                if (mine && ta == sn) {
 #pragma unroll
-                    for (int z2 = 0; z2 < 2; ++z2)
-                        if (cv[z2]) {
-                            if (te > sn) c.J[(fb[z2] + sn) * ldj + fb[z2] + te] = hf[z2];
-                            else {
-                                const double inv = rsqrt(hf[z2]);
-                                c.dinv[fb[z2] + sn] = inv;
-                                c.q[fb[z2] + sn] = inv * inv;
-                            }
-                        }
-                }
-                if (te == sn && ta < 12) {
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int z2 = 0; z2 < 2; ++z2) {
-                        if (ta < sn) c.stash[(sn & 1) * 128 + 16 * z2 + ta] = yf[z2];
-                        else if (ta == sn) c.stash[(sn & 1) * 128 + 16 * z2 + ta] = 1.0;
+                for (int w = 0; w < 2; ++w) {
+                    const int r = la + 8 * u, q = le + 8 * w;
+                    if (r < 12 && q < 12) {
+                        hF[u][w] = wt * hF[u][w] + ((r == q) ? S.hessian_reg : 0.0);
+                        if (r == q) trace += hF[u][w];
                     }
+                    else hF[u][w] = (r == q) ? 1.0 : 0.0;
+                    yF[u][w] = 0.0;
                 }
-            };
-            pub(0);
-            for (int sidx = 0; sidx < 12; ++sidx) {
-                bsync();
+            double* RBf = c.s + c.wave * 128;
+            double* YBf = RBf + 64;
+            publish_panel<3, 2, true, 0>(c, hF, yF, la, le, 0, RBf, YBf);
+            eliminate_block<3, 2, true, 0>(c, hF, yF, la, le, 12, RBf, YBf, c.dinv + fb, c.lane < 4, c.lane & 3);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int z2 = 0; z2 < 2; ++z2) {
-                    const double* Jr = c.J + (fb[z2] + sidx) * ldj + fb[z2];
-                    const double inv2 = c.q[fb[z2] + sidx];
-                    const double fa_ = Jr[min(ta, 11)], fe_ = Jr[min(te, 11)];
-                    const double fr_ = c.stash[(sidx & 1) * 128 + 16 * z2 + min(ta, 11)];
-                    hf[z2] = fma(-(fa_ * inv2), fe_, hf[z2]);
-                    yf[z2] = fma(-(fr_ * inv2), fe_, yf[z2]);
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int w = u; w < 2; ++w) {
+                    const int r = la + 8 * u, q = le + 8 * w;
+                    if (q < 12 && r < q) c.J[(fb + r) * ldj + fb + q] = yF[u][w] * c.dinv[fb + q];
+                    else if (r == q && r < 12) c.J[(fb + r) * ldj + fb + r] = c.dinv[fb + r];
                 }
-                if (sidx + 1 < 12) pub(sidx + 1);
-            }
-            bsync();
-            if (mine) {
-#pragma unroll
-                for (int z2 = 0; z2 < 2; ++z2)
-                    if (cv[z2]) {
-                        const int r = fb[z2] + ta, q = fb[z2] + te;
-                        c.J[r * ldj + q] = (ta == te) ? c.dinv[r] : yf[z2] * c.dinv[q];
-                    }
-            }
         }
+        bsync();
         c1 = block_sum(c, trace);
         double tr2 = 0.0;
         for (int i = tid; i < n; i += kThreads) tr2 += c.dinv[i];
