@@ -785,72 +785,121 @@ __device__ __forceinline__ void copy_in(const TI* __restrict__ src, double* dst,
 }
 
 
-// One Householder step of the QR of B (n x m, leading dimension c.ldb) on column j.  Thread (column e = j+1+(tid>>4),
-// rows kk = j + (tid&15) + 16 t, t < NT = ceil((n-j)/16)).  B carries 16 zero rows below row n-1, so rows past the end need no
-// mask: they contribute nothing and stay zero.  The squared norm of column j's tail was left in nrm2[j&1] by the
-// previous step; this step leaves the next one.  Returns false when the column is (numerically) dependent.
-template <int NT>
-__device__ __forceinline__ bool qr_step(Ctx& c, double* Bm, double* tau, double* rdiag, double* nrm2, int j, double v0_prev,
-                                        double& alpha, double& v0)
+// sum over the 8 lanes of an aligned lane group (every lane of the group gets the total)
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v)
 {
-    const int m = c.neq, ldb = c.ldb, tid = c.tid;
-    const int kc = tid & 15;
-    const int e = j + 1 + (tid >> 4);
-    const bool ev = e < m;
-    const int es = ev ? e : j;
-    // loads first: the pivot data and this thread's elements of column j and column e
-    const double nrm = nrm2[j & 1];
-    const double x0 = Bm[j * ldb + j];
-    const double* colj = Bm + (j + kc) * ldb + j;
-    double* cole = Bm + (j + kc) * ldb + es;
-    double vk[NT], bk[NT];
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double grp8_sum(double v)
+{
+    v += dpp_get<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_get<0x141>(v); // row_half_mirror: the other quad of the same 8 lanes
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Householder QR of B (n x m, n <= 80, m <= 32 columns), columns resident in registers: 8 lanes per column, lane kc of a
+// column keeps the row pairs (2 kc + 16 t, + 1), t < 5.  Per step only the reflector travels: the owner of column j leaves
+// v_j (zeros above row j, v0 on it) and (tau_j, alpha_j) in LDS, every later column reads it once (5 x 16 bytes per
+// lane), reduces its dot product over its 8 lanes by DPP and updates its registers; the lanes of column j + 1 go on to
+// the next reflector.  One barrier per column, no reloads or stores of the trailing matrix.  On return B holds V (unit
+// part scaled as LAPACK's is not: v0 on the diagonal) below and R's strict upper part above; rdiag / tau the rest.
+// Returns false when a column is (numerically) dependent on its predecessors.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, double* rdiag, double* vbuf, double* sc)
+{
+    const int n = c.n, m = c.neq, ldb = c.ldb, tid = c.tid;
+    const int e = tid >> 3, kc = tid & 7;
+    const bool colv = e < m;
+    const int es = colv ? e : 0;
+    double b[5][2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        vk[t] = colj[16 * t * ldb];
-        bk[t] = cole[16 * t * ldb];
-    }
-    const double inx = rsqrt(nrm);
-    const double nx = (nrm > 0.0) ? nrm * inx : 0.0; // exactly dependent column: alpha = 0 -> reported as redundant
-    alpha = (x0 >= 0.0) ? -nx : nx;
-    v0 = x0 - alpha;
-    const double tj = inx / (nx + fabs(x0));
-    if (kc == 0) vk[0] = v0;
-    double dot = 0.0;
+    for (int t = 0; t < 5; ++t)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) dot = fma(vk[t], bk[t], dot);
-    dot = row16_sum(dot) * tj;
-    double sq = 0.0;
+        for (int i = 0; i < 2; ++i) {
+            const int row = 2 * kc + 16 * t + i;
+            const double v = Bm[min(row, n - 1) * ldb + es];
+            b[t][i] = (row < n) ? v : 0.0;
+        }
+    // reflector of column jn from the registers of its 8 lanes (call under e == jn)
+    auto prepare = [&](int jn) __attribute__((always_inline)) {
+        double sq0 = 0.0, sq1 = 0.0, x0 = 0.0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const double nb_ = fma(-dot, vk[t], bk[t]);
-        if (ev) cole[16 * t * ldb] = nb_;
-        if (t > 0 || kc > 0) sq = fma(nb_, nb_, sq);
-    }
-    sq = row16_sum(sq);
-    // columns beyond the first 16 (m - j - 1 > 16): generic pass
-    for (int eb = j + 17; eb < m; eb += 16) {
-        const int e2 = eb + (tid >> 4);
-        const int e2s = (e2 < m) ? e2 : j;
-        double d2 = 0.0;
+        for (int t = 0; t < 5; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) d2 = fma((t == 0 && kc == 0) ? v0 : colj[16 * t * ldb], Bm[(j + kc + 16 * t) * ldb + e2s], d2);
-        d2 = row16_sum(d2) * tj;
-        if (e2 < m) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                double* pe = Bm + (j + kc + 16 * t) * ldb + e2;
-                *pe = fma(-d2, (t == 0 && kc == 0) ? v0 : colj[16 * t * ldb], *pe);
+            for (int i = 0; i < 2; ++i) {
+                const int row = 2 * kc + 16 * t + i;
+                const double v = (row >= jn) ? b[t][i] : 0.0;
+                if (i == 0) sq0 = fma(v, v, sq0);
+                else sq1 = fma(v, v, sq1);
+                if (t < 2) x0 += (row == jn) ? v : 0.0; // jn < 32
             }
+        const double nrm = grp8_sum(sq0 + sq1);
+        x0 = grp8_sum(x0);
+        const double inx = rsqrt(nrm);
+        const double nx = (nrm > 0.0) ? nrm * inx : 0.0; // exactly dependent column: alpha = 0 -> reported as redundant
+        const double alpha = (x0 >= 0.0) ? -nx : nx;
+        const double v0 = x0 - alpha;
+        const double tj = fast_rcp(fma(nx, fabs(x0), nrm)); // 2 / v'v
+        double* vb = vbuf + (jn & 1) * 80;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            double2v o;
+            const int row = 2 * kc + 16 * t;
+            if (t < 2) {
+                if (row == jn) b[t][0] = v0;
+                if (row + 1 == jn) b[t][1] = v0;
+            }
+            o.x = (row >= jn) ? b[t][0] : 0.0;
+            o.y = (row + 1 >= jn) ? b[t][1] : 0.0;
+            *reinterpret_cast<double2v*>(__builtin_assume_aligned(vb + row, 16)) = o;
+        }
+        if (kc == 0) {
+            sc[(jn & 1) * 2] = tj;
+            sc[(jn & 1) * 2 + 1] = alpha;
+            tau[jn] = tj;
+            rdiag[jn] = alpha;
+        }
+    };
+    if (e == 0) prepare(0);
+    for (int j = 0; j < m; ++j) {
+        bsync();
+        const double tj = sc[(j & 1) * 2], alpha = sc[(j & 1) * 2 + 1];
+        if (!(fabs(alpha) > 2.220446049250313e-16 * c.R_norm)) return false; // also catches a NaN pivot
+        c.R_norm = fmax(c.R_norm, fabs(alpha));
+        if (colv && e > j) {
+            const double* vb = vbuf + (j & 1) * 80 + 2 * kc;
+            double2v v[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) v[t] = ld2(vb + 16 * t);
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                d0 = fma(v[t].x, b[t][0], d0);
+                d1 = fma(v[t].y, b[t][1], d1);
+            }
+            const double coef = grp8_sum(d0 + d1) * tj;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                b[t][0] = fma(-coef, v[t].x, b[t][0]);
+                b[t][1] = fma(-coef, v[t].y, b[t][1]);
+            }
+            if (e == j + 1) prepare(j + 1);
         }
     }
-    if (tid == 0) {
-        nrm2[(j + 1) & 1] = sq; // threads 0..15 own column j+1
-        rdiag[j] = alpha;
-        tau[j] = tj;
-        if (j > 0) Bm[(j - 1) * ldb + (j - 1)] = v0_prev; // nobody reads B(j-1,j-1) any more
+    if (colv) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 2 * kc + 16 * t + i;
+                if (row < n) Bm[row * ldb + e] = b[t][i];
+            }
     }
-    if (fabs(alpha) <= 2.220446049250313e-16 * c.R_norm) return false;
-    c.R_norm = fmax(c.R_norm, fabs(alpha));
     return true;
 }
 
@@ -933,7 +982,6 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     double* tau = Tm + m * (m + 1);
     double* rdiag = tau + m;
     double* rhs = rdiag + m;   // later y
-    double* nrm2 = rhs + m;    // [2]
 
     // ---- N = CE': base dynamics rows [M_u | -J_u'], then the contact motion rows [A_c | 0]
     for (int e2 = tid; e2 < n * m; e2 += kThreads) {
@@ -982,35 +1030,9 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     for (int e2 = tid; e2 < 16 * ldb; e2 += kThreads) Bm[n * ldb + e2] = 0.0; // zero rows below B for the maskless QR steps
     bsync();
     STAMP(5)
-    // squared norm of column 0
-    {
-        double sq = 0.0;
-        if (tid < n) {
-            const double v = Bm[tid * ldb];
-            sq = v * v;
-        }
-        sq = block_sum(c, sq);
-        if (tid == 0) nrm2[0] = sq;
-        bsync();
-    }
-    // ---- Householder QR of B, one barrier per column. Thread (column e = j+1+(tid>>4), rows k = j + (tid&15) + 16 t).
-    double v0_prev = 0.0;
-    for (int j = 0; j < m; ++j) {
-        double alpha, v0;
-        bool ok;
-        switch ((n - j + 15) >> 4) {
-        case 1: ok = qr_step<1>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
-        case 2: ok = qr_step<2>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
-        case 3: ok = qr_step<3>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
-        case 4: ok = qr_step<4>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
-        case 5: ok = qr_step<5>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break;
-        default: ok = qr_step<6>(c, Bm, tau, rdiag, nrm2, j, v0_prev, alpha, v0); break; // n <= 85
-        }
-        if (!ok) return false; // redundant equalities
-        v0_prev = v0;
-        bsync();
-    }
-    if (tid == 0) Bm[(m - 1) * ldb + (m - 1)] = v0_prev;
+    // ---- Householder QR of B with the columns in registers, one barrier per column
+    if (!qr_resident(c, Bm, tau, rdiag, c.part, c.part + 160)) return false; // redundant equalities
+    bsync();
     STAMP(6)
     // ---- R (packed, the active-set factor) from the strict upper part of B and the Householder alphas; that part is
     //      cleared on the way so that B is exactly V.  The G area is zeroed for the padded solves below.
