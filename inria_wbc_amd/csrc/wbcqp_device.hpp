@@ -1396,6 +1396,19 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         const int meta0 = (nin2 > 0) ? S.rowmeta[min(tid, nin2 - 1)] : 0;
         const int meta1 = (nin2 > 0) ? S.rowmeta[min(tid + kThreads, nin2 - 1)] : 0;
         const int drt = (n_dense > 0) ? S.dense_row_task[min(tid, n_dense - 1)] : 0;
+        // selection rows (posture) and force-regularisation right-hand sides: constants now, arithmetic after the barrier
+        int selc = 0, selt = 0, frt = 0;
+        double ftc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (n_sel > 0) {
+            selc = S.sel_col[min(tid, n_sel - 1)];
+            selt = S.sel_task[min(tid, n_sel - 1)];
+        }
+        if (nc > 0) {
+            const int fm = min(tid, k - 1);
+            frt = S.forcereg_task[fm / 12];
+#pragma unroll
+            for (int qd = 0; qd < 6; ++qd) ftc[qd] = S.ft[(fm / 12) * 72 + (fm % 12) * 6 + qd];
+        }
         // ---- land: packed M goes straight to both triangles of the full matrix
 #pragma unroll
         for (int u = 0; u < RM; ++u) {
@@ -1444,65 +1457,55 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         for (int e = tid + RC * kThreads; e < lenAc; e += kThreads) c.Ac[e] = (double)pAc[e];
         for (int e = tid + RT * kThreads; e < lenT; e += kThreads) c.J[e] = S.force_gen[e];
         for (int i = tid + 2 * kThreads; i < nin2; i += kThreads) c.meta[i] = S.rowmeta[i];
-    }
-    bsync();
-    if (tid < n_dense) c.wrow[tid] = c.w[c.iai[tid]];
-    // Jc = T' A_c  (12 x nv per contact)
-    for (int e = tid; e < k * nv; e += kThreads) {
-        const int m = e / nv, j = e - m * nv;
-        const int ct = m / 12, mm = m - 12 * ct;
-        const double* T = c.J + ct * 72;
-        const double* Acc = c.Ac + ct * 6 * nv;
-        double sacc = 0.0;
+        if (tid < nv) { // diagonal additions / right-hand sides of the selection rows
+            c.z[tid] = 0.0;
+            c.d[tid] = 0.0;
+        }
+        bsync();
+        if (tid < n_dense) c.wrow[tid] = c.w[c.iai[tid]];
+        // selection rows (posture): H(c,c) += w, g(c) -= w b  (distinct columns)
+        for (int sidx = tid; sidx < n_sel; sidx += kThreads) {
+            const int col = (sidx == tid) ? selc : S.sel_col[sidx];
+            const double wt = c.w[(sidx == tid) ? selt : S.sel_task[sidx]];
+            c.z[col] = wt;
+            c.d[col] = wt * c.b1[n_dense + sidx];
+        }
+        // force regularisation: g_f = -w F' b
+        if (tid < k) {
+            const double* bb = c.b1 + n_dense + n_sel + 6 * (tid / 12);
+            double sacc = 0.0;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) sacc = fma(T[r * 12 + mm], Acc[r * nv + j], sacc);
-        c.Jc[m * ldc + j] = sacc;
+            for (int qd = 0; qd < 6; ++qd) sacc = fma(ftc[qd], bb[qd], sacc);
+            c.g[nv + tid] = -c.w[frt] * sacc;
+        }
+        // Jc = T' A_c  (12 x nv per contact): thread = (row m of Jc, every G-th column), its six T coefficients in registers
+        if (k > 0) {
+            const int G = kThreads / k;
+            const int m = tid % k, jg = tid / k;
+            if (jg < G) {
+                const int ct = m / 12, mm = m - 12 * ct;
+                const double* T = c.J + ct * 72 + mm;
+                const double* Acc = c.Ac + ct * 6 * nv;
+                double tc[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) tc[r] = T[r * 12];
+#pragma unroll 2
+                for (int j = jg; j < nv; j += G) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) sacc = fma(tc[r], Acc[r * nv + j], sacc);
+                    c.Jc[m * ldc + j] = sacc;
+                }
+            }
+        }
     }
     bsync();
-    for (int e = tid; e < n * ldj; e += kThreads) c.J[e] = 0.0;
-    bsync();
+    for (int e = tid; e < n * ldj; e += kThreads) c.J[e] = 0.0; // nobody touches J before the factorisation writes it
     STAMP(0)
 
     // ---------------- phases 1-2b in registers: H assembly, Cholesky H = U'U, J = U^-1 ----------------
     // Thread (ta, te) of a 16 x 16 grid OWNS the strided positions (ta + 16u, te + 16w) of the upper triangle of the
-    // dv block for the whole pipeline: H is accumulated, factorised and inverted in its registers.  Only what another
-    // thread must see travels through LDS: the pivot row of each Cholesky step (written once, final), the pivot column of
-    // each inversion step.  One barrier per step, no element reloads, no masks (the zeros of the strict lower triangle
-    // and of the off-diagonal blocks make dead positions inert).
-    // g_j = - sum_r w_r A(r,j) b(r)
-    for (int j = tid; j < nv; j += kThreads) {
-        const double* Aj = As + j;
-        double g0 = 0.0, g1 = 0.0;
-        int r = 0;
-        for (; r + 2 <= n_dense; r += 2) {
-            g0 = fma(Aj[r * nv] * c.wrow[r], c.b1[r], g0);
-            g1 = fma(Aj[(r + 1) * nv] * c.wrow[r + 1], c.b1[r + 1], g1);
-        }
-        for (; r < n_dense; ++r) g0 = fma(Aj[r * nv] * c.wrow[r], c.b1[r], g0);
-        c.g[j] = -(g0 + g1);
-        c.z[j] = 0.0; // diagonal additions of the selection rows
-    }
-    for (int m = tid; m < k; m += kThreads) c.g[nv + m] = 0.0;
-    bsync();
-    // selection rows (posture): H(c,c) += w, g(c) -= w b
-    for (int sidx = tid; sidx < n_sel; sidx += kThreads) {
-        const int col = S.sel_col[sidx];
-        const double wt = c.w[S.sel_task[sidx]];
-        c.z[col] += wt; // distinct columns
-        c.g[col] -= wt * c.b1[n_dense + sidx];
-    }
-    for (int ct = 0; ct < nc; ++ct) {
-        const double wt = c.w[S.forcereg_task[ct]];
-        const double* Ft = S.ft + ct * 72;
-        const double* bb = c.b1 + n_dense + n_sel + 6 * ct;
-        if (tid < 12) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int qd = 0; qd < 6; ++qd) sacc = fma(Ft[tid * 6 + qd], bb[qd], sacc);
-            c.g[nv + 12 * ct + tid] = -wt * sacc;
-        }
-    }
-    bsync();
+    // dv block for the whole pipeline: H is accumulated, factorised and inverted in its registers (eliminate_block).
     double c1, c2;
     { // nv <= 64 is checked on the host
         const int ta = tid >> 4, te = tid & 15;
@@ -1517,19 +1520,47 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
 #pragma unroll
                 for (int w = 0; w < 4; ++w) h[u][w] = 0.0;
             }
-            for (int r = 0; r < n_dense; ++r) {
+            // rows of the next task line are in flight while this one multiplies; g_j = -sum_r w_r A(r,j) b(r) rides along
+            double gacc[4] = {0.0, 0.0, 0.0, 0.0};
+            auto ldrow = [&](int r, double (&ai)[4], double (&aj)[4], double& wr, double& br) __attribute__((always_inline)) {
                 const double* Ar = As + r * nv;
-                const double wr = c.wrow[r];
-                double ai[4], aj[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     ai[u] = Ar[ri[u]];
-                    aj[u] = Ar[ci[u]] * wr;
+                    aj[u] = Ar[ci[u]];
                 }
+                wr = c.wrow[r];
+                br = c.b1[r];
+            };
+            auto macrow = [&](const double (&ai)[4], const double (&aj)[4], double wr, double br) __attribute__((always_inline)) {
+                double ajw[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) ajw[w] = aj[w] * wr;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int w = u; w < 4; ++w) h[u][w] = fma(ai[u], aj[w], h[u][w]);
+                    for (int w = u; w < 4; ++w) h[u][w] = fma(ai[u], ajw[w], h[u][w]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) gacc[w] = fma(ajw[w], br, gacc[w]);
+            };
+            if (n_dense > 0) {
+                double ai0[4], aj0[4], ai1[4], aj1[4], wr0, br0, wr1, br1;
+                ldrow(0, ai0, aj0, wr0, br0);
+                int r = 0;
+                for (; r + 2 <= n_dense; r += 2) {
+                    ldrow(r + 1, ai1, aj1, wr1, br1);
+                    macrow(ai0, aj0, wr0, br0);
+                    ldrow(min(r + 2, n_dense - 1), ai0, aj0, wr0, br0);
+                    macrow(ai1, aj1, wr1, br1);
+                }
+                if (r < n_dense) macrow(ai0, aj0, wr0, br0);
+            }
+            if (ta == 0) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int col = te + 16 * w;
+                    if (col < nv) c.g[col] = -gacc[w] - c.d[col];
+                }
             }
             if (ta == te) {
 #pragma unroll
