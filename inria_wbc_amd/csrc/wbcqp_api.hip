@@ -132,6 +132,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     D.o_vec = take(V_COUNT * kSlot);
     D.o_eqw = take(D.neq > 0 ? (n + 1) * D.ldb + 8 : 0);
     D.o_eqt = take(D.neq > 0 ? D.neq * (D.neq + 1) + 4 * D.neq + 16 : 0);
+    D.fric_lds = (D.nc > 0 && (o - D.o_eqw) >= 238 * D.nc) ? 1 : 0;
     D.o_int = o;
     o += kIntCount / 2 + 2;
     D.lds_doubles = o;

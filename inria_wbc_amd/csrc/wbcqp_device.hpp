@@ -68,6 +68,7 @@ struct DevStruct {
     int ldj, ldm, ldc, ldb;
     int o_J, o_R, o_M, o_Jc, o_Ac, o_vec, o_eqw, o_eqt;
     int o_int; // int area (fixed slots, see kInt*)
+    int fric_lds; // 1: the friction tables (238 doubles per contact) fit the equality-phase scratch, which is free in the inequality loop
     int lds_doubles;
 };
 
@@ -106,6 +107,14 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_movi(int v)
 {
     return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+// value of the lane a DPP control selects (all source lanes valid: no old value to preserve, no copy)
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v)
+{
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double bcast_lane(double v, int src)
 {
@@ -377,6 +386,41 @@ __device__ __forceinline__ void compute_d_unit(Ctx& c, int row, double sign)
     bsync();
 }
 
+// r = R[:iq,:iq]^-1 d[:iq] for the rows rlo..iq-1 on ONE wave (update_r): column-oriented back substitution, the pivot
+// travels by readlane, 1/R(j,j) and the column entries of four steps are fetched ahead of the dependent chain.
+__device__ __forceinline__ void update_r_wave(Ctx& c, int rlo)
+{
+    const int lane = c.lane, iq = c.iq;
+    if (iq <= rlo) return;
+        double v0 = (lane < iq) ? c.d[lane] : 0.0;
+        double v1 = (lane + kWave < iq) ? c.d[lane + kWave] : 0.0;
+        auto step = [&](int j, double rd, double ra, double rb) {
+            const double dj = (j < kWave) ? bcast_lane(v0, j) : bcast_lane(v1, j - kWave);
+            const double rj = dj * rd;
+            if (lane == (j & (kWave - 1))) c.r[j] = rj;
+            if (lane < j) v0 = fma(-rj, ra, v0);
+            if (lane + kWave < j) v1 = fma(-rj, rb, v1);
+        };
+        int j = iq - 1;
+        for (; j >= rlo + 3; j -= 4) {
+            double rd[4], ra[4], rb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = j - u;
+                const double* Rc = c.R + roff(jj);
+                rd[u] = c.rdinv[jj];
+                ra[u] = Rc[min(lane, jj)];
+                rb[u] = Rc[min(lane + kWave, jj)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) step(j - u, rd[u], ra[u], rb[u]);
+        }
+        for (; j >= rlo; --j) {
+            const double* Rc = c.R + roff(j);
+            step(j, c.rdinv[j], Rc[min(lane, j)], Rc[min(lane + kWave, j)]);
+        }
+}
+
 // z = J[:, iq:] d[iq:] (update_z) on waves 0..2 (each a third of the columns, both row sets), and
 // r = R[:iq,:iq]^-1 d[:iq] (update_r) on wave 3: column-oriented back substitution, the pivot travels by
 // readlane, 1/R(j,j) and the column entries of four steps are fetched ahead of the dependent chain.  Only r[rlo:iq] is
@@ -417,35 +461,7 @@ __device__ __forceinline__ void update_z_r(Ctx& c, int rlo)
             if (has1) c.part[c.wave * 128 + k1] = a1 + b1;
         }
     }
-    else if (iq > rlo) {
-        double v0 = (lane < iq) ? c.d[lane] : 0.0;
-        double v1 = (lane + kWave < iq) ? c.d[lane + kWave] : 0.0;
-        auto step = [&](int j, double rd, double ra, double rb) {
-            const double dj = (j < kWave) ? bcast_lane(v0, j) : bcast_lane(v1, j - kWave);
-            const double rj = dj * rd;
-            if (lane == (j & (kWave - 1))) c.r[j] = rj;
-            if (lane < j) v0 = fma(-rj, ra, v0);
-            if (lane + kWave < j) v1 = fma(-rj, rb, v1);
-        };
-        int j = iq - 1;
-        for (; j >= rlo + 3; j -= 4) {
-            double rd[4], ra[4], rb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int jj = j - u;
-                const double* Rc = c.R + roff(jj);
-                rd[u] = c.rdinv[jj];
-                ra[u] = Rc[min(lane, jj)];
-                rb[u] = Rc[min(lane + kWave, jj)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) step(j - u, rd[u], ra[u], rb[u]);
-        }
-        for (; j >= rlo; --j) {
-            const double* Rc = c.R + roff(j);
-            step(j, c.rdinv[j], Rc[min(lane, j)], Rc[min(lane + kWave, j)]);
-        }
-    }
+    else update_r_wave(c, rlo);
     bsync();
     if (c.tid < n) c.z[c.tid] = (c.part[c.tid] + c.part[128 + c.tid]) + c.part[256 + c.tid];
     bsync();
@@ -677,9 +693,8 @@ struct OwnRows {
     double ci0[2];
     double coef[2][12]; // friction rows only
 };
-__device__ __forceinline__ void own_rows_init(Ctx& c, OwnRows& o)
+__device__ __forceinline__ void own_rows_init(Ctx& c, OwnRows& o, const double* fmat, const double* flb, const double* fub)
 {
-    const DevStruct& S = *c.S;
 #pragma unroll
     for (int z2 = 0; z2 < 2; ++z2) {
         const int i = c.tid + z2 * kThreads;
@@ -695,8 +710,8 @@ __device__ __forceinline__ void own_rows_init(Ctx& c, OwnRows& o)
             if (kind == INEQ_BOUNDS) o.ci0[z2] = neg ? c.bub[rr] : -c.blb[rr];
             else if (kind == INEQ_ACTUATION) o.ci0[z2] = neg ? c.tu[rr] : -c.tl[rr];
             else {
-                o.ci0[z2] = neg ? S.fric_ub[ct * 17 + rr] : -S.fric_lb[ct * 17 + rr];
-                const double* B = S.fric_mat + (ct * 17 + rr) * 12;
+                o.ci0[z2] = neg ? fub[ct * 17 + rr] : -flb[ct * 17 + rr];
+                const double* B = fmat + (ct * 17 + rr) * 12;
 #pragma unroll
                 for (int m = 0; m < 12; ++m) o.coef[z2][m] = neg ? -B[m] : B[m];
             }
@@ -751,6 +766,61 @@ __device__ __forceinline__ double compute_s_owned(Ctx& c, const OwnRows& o)
     return psi;
 }
 
+// tau' = M_a xn - J_a' fn with xn = x + t z formed on the fly (t = 0: xn = x exactly), four lanes per actuated row,
+// partial sums meet by DPP inside the quad.  Every call sums in the same order, so the value for x + t z here is bitwise
+// the value a later call on the stored x would give.  No barrier inside; out[rr] is written by the quad's first lane.
+__device__ __forceinline__ void act_rows(Ctx& c, double* out, double t)
+{
+    const int nv = c.nv, nu = c.nu, k = c.k, na = c.na;
+    const int rr = c.tid >> 2, q4 = c.tid & 3;
+    const int row = nu + min(rr, na - 1);
+    const double* Mr = c.M + row * c.ldm;
+    double a0 = 0.0, a1 = 0.0;
+    int j = q4;
+    for (; j + 4 < nv; j += 8) {
+        a0 = fma(Mr[j], fma(t, c.z[j], c.x[j]), a0);
+        a1 = fma(Mr[j + 4], fma(t, c.z[j + 4], c.x[j + 4]), a1);
+    }
+    if (j < nv) a0 = fma(Mr[j], fma(t, c.z[j], c.x[j]), a0);
+    for (int m = q4; m < k; m += 4) a1 = fma(-c.Jc[m * c.ldc + row], fma(t, c.z[nv + m], c.x[nv + m]), a1);
+    double acc = a0 + a1;
+    acc += dpp_get<0xB1>(acc);
+    acc += dpp_get<0x4E>(acc);
+    if (q4 == 0 && rr < na) out[rr] = acc;
+}
+
+// s = CI x + ci0 for the (at most two) rows this thread owns; tact = tau' of act_rows.  Stores s and returns
+// sum min(s, 0) and the most violated eligible row (first index on ties).
+__device__ __forceinline__ void own_rows_eval(Ctx& c, const OwnRows& o, const double* tact, double& psi, ValIdx& best)
+{
+    psi = 0.0;
+    best = ValIdx{0.0, 0x7fffffff};
+#pragma unroll
+    for (int z2 = 0; z2 < 2; ++z2) {
+        const int mt = o.meta[z2];
+        if (mt >= 0) {
+            const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
+            const bool neg = (mt >> 2) & 1;
+            double v;
+            if (kind == INEQ_BOUNDS) v = neg ? -c.x[col] : c.x[col];
+            else if (kind == INEQ_ACTUATION) v = neg ? -tact[rr] : tact[rr];
+            else {
+                const double* f = c.x + c.nv + 12 * ct;
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < 12; ++m) a = fma(o.coef[z2][m], f[m], a);
+                v = a;
+            }
+            v += o.ci0[z2];
+            const int i = c.tid + z2 * kThreads;
+            c.s[i] = v;
+            c.iaexcl[i] = 1;
+            psi += fmin(0.0, v);
+            if (v < 0.0 && c.iai[i] != -1) best = vi_min(best, ValIdx{v, i});
+        }
+    }
+}
+
 // global -> LDS copy, all 256 threads, 4 loads in flight per thread
 // R rounds of 256 elements into registers; indices are clamped instead of masked so that the loads stay unconditional
 // (a predicated load becomes an exec-mask branch and splits the block the scheduler works in).  len >= 1.
@@ -786,13 +856,6 @@ __device__ __forceinline__ void copy_in(const TI* __restrict__ src, double* dst,
 
 
 // sum over the 8 lanes of an aligned lane group (every lane of the group gets the total)
-template <int CTRL>
-__device__ __forceinline__ double dpp_get(double v)
-{
-    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
-    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double grp8_sum(double v)
 {
     v += dpp_get<0xB1>(v);  // quad_perm [1,0,3,2]
@@ -1728,148 +1791,344 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     }
 
     // ---------------- phase 4: inequality loop (GI steps 1, 2, 2a-2c) ----------------
+    // The common iteration (full step, constraint added) takes five barriers:
+    //   P1  every thread evaluates the rows of s it owns, psi and the most violated row meet in one reduction     | B1
+    //   P2  d = J'n straight from the row's sources (no staging of n), lanes of one column meet by DPP            | B2
+    //   P3  waves 0-2: z = J2 d2 (lanes of one row meet by DPP) + z'z, z'n, |d2|^2; wave 3: r = R^-1 d, t1        | B3
+    //   P4  step lengths from the slots; w = tau (z - alpha J(:,iq)); tau' = A_act (x + t z) for the next P1        | B4
+    //   P5  J -= w v', new column of R, x, u, A, iai                                                               | B5
+    // Partial steps, dual-only steps and rejected (dependent) constraints keep the plain barrier-per-phase code.
     if (status == -2) {
         for (int i = tid; i < nin2; i += kThreads) c.iai[i] = i;
+        // friction tables: LDS copy in the (now free) equality scratch when they fit
+        const double *fmat = S.fric_mat, *flb = S.fric_lb, *fub = S.fric_ub;
+        if (S.fric_lds && nc > 0) {
+            double* tb = c.eqw;
+            for (int e = tid; e < nc * 204; e += kThreads) tb[e] = S.fric_mat[e];
+            for (int e = tid; e < nc * 17; e += kThreads) {
+                tb[nc * 204 + e] = S.fric_lb[e];
+                tb[nc * 221 + e] = S.fric_ub[e];
+            }
+            fmat = tb;
+            flb = tb + nc * 204;
+            fub = tb + nc * 221;
+            bsync();
+        }
         OwnRows own;
-        own_rows_init(c, own);
+        own_rows_init(c, own, fmat, flb, fub);
+        double* tact = c.part + 512;
+        if (na > 0) act_rows(c, tact, 0.0);
         bsync();
         const double psi_tol = (double)nin2 * eps * c1 * c2 * 100.0;
+        bool redo_l2 = false, tau_stale = false;
         while (status == -2) {
-            // l1
-            ++iter;
-            if (iter >= S.max_iter) {
-                status = HQP_MAX_ITER;
-                break;
+            ValIdx best;
+            if (!redo_l2) {
+                // l1
+                ++iter;
+                if (iter >= S.max_iter) {
+                    status = HQP_MAX_ITER;
+                    break;
+                }
+                if (tau_stale) {
+                    if (na > 0) act_rows(c, tact, 0.0);
+                    bsync();
+                    tau_stale = false;
+                }
+                for (int i = tid; i < c.iq; i += kThreads) {
+                    c.uold[i] = c.u[i];
+                    c.Aold[i] = c.A[i];
+                }
+                for (int i = tid; i < n; i += kThreads) c.xold[i] = c.x[i];
+                double psi;
+                own_rows_eval(c, own, tact, psi, best);
+                psi = wave_sum(psi);
+                best = wave_argmin(best);
+                double* slot = c.red + c.rslot * 16;
+                if (c.lane == 0) {
+                    slot[c.wave] = psi;
+                    slot[4 + c.wave] = best.v;
+                    slot[8 + c.wave] = __hiloint2double(0, best.i);
+                }
+                bsync(); // B1
+                psi = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+                best = ValIdx{slot[4], __double2loint(slot[8])};
+#pragma unroll
+                for (int w = 1; w < kWaves; ++w) best = vi_min(best, ValIdx{slot[4 + w], __double2loint(slot[8 + w])});
+                c.rslot ^= 1;
+                if (fabs(psi) <= psi_tol) {
+                    status = HQP_OPTIMAL;
+                    break;
+                }
+                STAMP(9)
             }
-            for (int i = neq + tid; i < c.iq; i += kThreads) c.iai[c.A[i]] = -1;
-            actuation_product(c);
-            for (int i = tid; i < c.iq; i += kThreads) {
-                c.uold[i] = c.u[i];
-                c.Aold[i] = c.A[i];
-            }
-            for (int i = tid; i < n; i += kThreads) c.xold[i] = c.x[i];
-            bsync();
-            double psi = compute_s_owned(c, own);
-            psi = block_sum(c, psi);
-            if (fabs(psi) <= psi_tol) {
-                status = HQP_OPTIMAL;
-                break;
-            }
-            STAMP(9)
-
-            bool again_l2 = true;
-            while (again_l2 && status == -2) {
-                again_l2 = false;
-                // l2: most violated non-active, non-excluded constraint (first index on ties)
-                ValIdx best{0.0, 0x7fffffff};
+            else {
+                // l2 again after a rejected constraint: s is still valid, the rejected row is excluded
+                best = ValIdx{0.0, 0x7fffffff};
                 for (int i = tid; i < nin2; i += kThreads) {
                     const double sv = c.s[i];
                     if (sv < 0.0 && c.iai[i] != -1 && c.iaexcl[i]) best = vi_min(best, ValIdx{sv, i});
                 }
                 best = block_argmin(c, best);
-                if (best.v >= 0.0) {
-                    status = HQP_OPTIMAL;
-                    break;
-                }
-                const int ip = best.i;
-                int k0, k1, ucol;
-                double ci0, usign;
-                build_ineq_row(c, ip, k0, k1, ci0, ucol, usign);
-                if (tid == kThreads - 1) {
-                    c.u[c.iq] = 0.0;
-                    c.A[c.iq] = ip;
-                }
-                bsync();
-                STAMP(10)
+                redo_l2 = false;
+            }
+            if (best.v >= 0.0) {
+                status = HQP_OPTIMAL;
+                break;
+            }
+            const int ip = best.i;
+            // the row n of constraint ip: kind, support [k0, k1), sign; n itself is staged for z'n and the slow paths
+            const int mt = c.meta[ip];
+            const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
+            const double sg = ((mt >> 2) & 1) ? -1.0 : 1.0;
+            int k0, k1;
+            if (kind == INEQ_BOUNDS) {
+                k0 = col;
+                k1 = col + 1;
+                if (tid == 0) c.np[col] = sg;
+            }
+            else if (kind == INEQ_ACTUATION) {
+                k0 = 0;
+                k1 = n;
+                const int row = nu + rr;
+                if (tid < nv) c.np[tid] = sg * c.M[row * ldm + tid];
+                else if (tid < n) c.np[tid] = -sg * c.Jc[(tid - nv) * ldc + row];
+            }
+            else {
+                k0 = nv + 12 * ct;
+                k1 = k0 + 12;
+                if (tid < 12) c.np[k0 + tid] = sg * fmat[(ct * 17 + rr) * 12 + tid];
+            }
+            if (tid == kThreads - 1) {
+                c.u[c.iq] = 0.0;
+                c.A[c.iq] = ip;
+            }
+            STAMP(10)
 
-                // l2a
-                while (true) {
-                    if (ucol >= 0)
-                        compute_d_unit(c, ucol, usign);
-                    else
-                        compute_d(c, k0, k1);
-                    STAMP(11)
-                    update_z_r(c, neq);
-                    STAMP(12)
-                    const int iq = c.iq;
-                    // step 2b: partial step length t1 (dual feasibility) and full step length t2
+            // l2a
+            while (true) {
+                const int iq = c.iq;
+                // ---- P2: d = J' n
+                if (kind == INEQ_BOUNDS) {
+                    if (tid < n) c.d[tid] = sg * c.J[col * ldj + tid];
+                }
+                else if (kind == INEQ_FORCE) {
+                    if (tid < n) {
+                        const double* F = fmat + (ct * 17 + rr) * 12;
+                        const double* Jb = c.J + k0 * ldj + tid;
+                        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 12; m += 2) {
+                            a0 = fma(F[m], Jb[m * ldj], a0);
+                            a1 = fma(F[m + 1], Jb[(m + 1) * ldj], a1);
+                        }
+                        c.d[tid] = sg * (a0 + a1);
+                    }
+                }
+                else { // actuation row: two lanes per column, halves of the support
+                    const int idx = tid >> 1, hf = tid & 1;
+                    const int ic = min(idx, n - 1);
+                    const int row = nu + rr;
+                    const int mid = (n + 1) >> 1;
+                    const int ka = hf ? mid : 0, kb = hf ? n : mid;
+                    const double* Mr = c.M + row * ldm;
+                    const double* Jcol = c.J + ic;
+                    double a0 = 0.0, a1 = 0.0;
+                    int kk = ka;
+                    const int kv = min(kb, nv);
+                    for (; kk + 2 <= kv; kk += 2) {
+                        a0 = fma(Mr[kk], Jcol[kk * ldj], a0);
+                        a1 = fma(Mr[kk + 1], Jcol[(kk + 1) * ldj], a1);
+                    }
+                    if (kk < kv) {
+                        a0 = fma(Mr[kk], Jcol[kk * ldj], a0);
+                        ++kk;
+                    }
+                    kk = max(kk, nv);
+                    for (; kk < kb; ++kk) a1 = fma(-c.Jc[(kk - nv) * ldc + row], Jcol[kk * ldj], a1);
+                    double acc = a0 + a1;
+                    acc += dpp_get<0xB1>(acc);
+                    if (hf == 0 && idx < n) c.d[idx] = sg * acc;
+                }
+                bsync(); // B2
+                STAMP(11)
+                // ---- P3: z, r and the reductions of step 2b
+                double* slot = c.red + c.rslot * 16;
+                if (c.wave < 3) {
+                    const int lpr = (2 * n <= 3 * kWave) ? 2 : 1; // lanes per row
+                    const int idx = (lpr == 2) ? (tid >> 1) : tid, hf = (lpr == 2) ? (tid & 1) : 0;
+                    const int ir = min(idx, n - 1);
+                    const int span = n - iq, hlen = (lpr == 2) ? ((span + 1) >> 1) : span;
+                    const int ca = iq + hf * hlen, cb = min(n, ca + hlen);
+                    const double* Jr = c.J + ir * ldj;
+                    double a0 = 0.0, a1 = 0.0;
+                    int cc = ca;
+                    for (; cc + 2 <= cb; cc += 2) {
+                        a0 = fma(Jr[cc], c.d[cc], a0);
+                        a1 = fma(Jr[cc + 1], c.d[cc + 1], a1);
+                    }
+                    if (cc < cb) a0 = fma(Jr[cc], c.d[cc], a0);
+                    double zv = a0 + a1;
+                    if (lpr == 2) zv += dpp_get<0xB1>(zv);
+                    double zz = 0.0, znp = 0.0, dn2 = 0.0;
+                    if (hf == 0 && idx < n) {
+                        c.z[idx] = zv;
+                        zz = zv * zv;
+                        if (idx >= iq) {
+                            const double dv = c.d[idx];
+                            dn2 = dv * dv;
+                        }
+                        if (idx >= k0 && idx < k1) znp = zv * c.np[idx];
+                    }
+                    zz = wave_sum(zz);
+                    znp = wave_sum(znp);
+                    dn2 = wave_sum(dn2);
+                    if (c.lane == 0) {
+                        slot[c.wave] = zz;
+                        slot[4 + c.wave] = znp;
+                        slot[8 + c.wave] = dn2;
+                    }
+                }
+                else {
+                    update_r_wave(c, neq);
+                    // step 2b, partial step length t1 (dual feasibility): this wave just wrote r, LDS keeps its order
                     ValIdx bt{inf, 0x7fffffff};
-                    for (int kk = neq + tid; kk < iq; kk += kThreads) {
+                    for (int kk = neq + c.lane; kk < iq; kk += kWave) {
                         const double rk = c.r[kk];
                         if (rk > 0.0) bt = vi_min(bt, ValIdx{c.u[kk] / rk, kk});
                     }
-                    bt = block_argmin(c, bt);
-                    const double t1 = bt.v;
-                    const int lpos = bt.i;
-                    const int l = (t1 < inf) ? c.A[lpos] : 0;
-                    double zz = 0.0, znp = 0.0, dn2 = 0.0, dummy = 0.0;
-                    if (tid < n) {
-                        const double zv = c.z[tid];
-                        zz = zv * zv;
-                        if (tid >= iq) dn2 = c.d[tid] * c.d[tid];
-                        if (tid >= k0 && tid < k1) znp = zv * c.np[tid];
+                    bt = wave_argmin(bt);
+                    if (c.lane == 0) {
+                        slot[12] = bt.v;
+                        slot[13] = __hiloint2double(0, bt.i);
                     }
-                    block_sum4(c, zz, znp, dn2, dummy);
-                    const double sip = c.s[ip];
-                    const double uiq = c.u[iq];
-                    const double t2 = (fabs(zz) > eps) ? (-sip / znp) : inf;
-                    const double t = fmin(t1, t2);
-                    if (t >= inf) {
-                        status = HQP_INFEASIBLE; // eiquadprog UNBOUNDED (dual) -> tsid INFEASIBLE
-                        break;
-                    }
+                }
+                bsync(); // B3
+                STAMP(12)
+                // ---- P4: step lengths
+                const double zz = (slot[0] + slot[1]) + slot[2], znp = (slot[4] + slot[5]) + slot[6];
+                const double dn2 = (slot[8] + slot[9]) + slot[10];
+                const double t1 = slot[12];
+                const int lpos = __double2loint(slot[13]);
+                c.rslot ^= 1;
+                const int l = (t1 < inf) ? c.A[lpos] : 0;
+                const double sip = c.s[ip];
+                const double uiq = c.u[iq];
+                const double t2 = (fabs(zz) > eps) ? (-sip / znp) : inf;
+                const double t = fmin(t1, t2);
+                if (t >= inf) {
+                    status = HQP_INFEASIBLE; // eiquadprog UNBOUNDED (dual) -> tsid INFEASIBLE
+                    break;
+                }
+                if (t2 >= inf) {
+                    // (ii) dual step only, drop l
                     bsync(); // everyone has read s[ip], u[iq], A[lpos] before they change
-                    if (t2 >= inf) {
-                        // (ii) dual step only, drop l
-                        for (int j = neq + tid; j < iq; j += kThreads) c.u[j] = fma(-t, c.r[j], c.u[j]);
-                        if (tid == kThreads - 1) {
-                            c.u[iq] = uiq + t;
-                            c.iai[l] = l;
-                        }
-                        bsync();
-                        STAMP(13)
-                        delete_constraint(c, l);
-                        STAMP(15)
-                        continue;
+                    for (int j = neq + tid; j < iq; j += kThreads) c.u[j] = fma(-t, c.r[j], c.u[j]);
+                    if (tid == kThreads - 1) {
+                        c.u[iq] = uiq + t;
+                        c.iai[l] = l;
                     }
-                    // (iii) primal + dual step
-                    if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
-                    f_value += t * znp * (0.5 * t + uiq);
-                    if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
-                    if (tid == kThreads - 1) c.u[iq] = uiq + t;
                     bsync();
                     STAMP(13)
-                    if (t == t2) {
-                        // full step: add ip to the active set
-                        const bool added_ = add_constraint_hh(c, dn2);
-                        STAMP(14)
-                        if (!added_) {
-                            if (tid == 0) c.iaexcl[ip] = 0;
-                            bsync();
-                            delete_constraint(c, ip);
-                            for (int i = tid; i < nin2; i += kThreads) c.iai[i] = i;
-                            bsync();
-                            for (int i = tid; i < c.iq; i += kThreads) {
-                                const int av = c.Aold[i];
-                                c.A[i] = av;
-                                if (av >= 0) c.iai[av] = -1;
-                                c.u[i] = c.uold[i];
-                            }
-                            for (int i = tid; i < n; i += kThreads) c.x[i] = c.xold[i];
-                            bsync();
-                            again_l2 = true;
-                        }
-                        else {
-                            if (tid == 0) c.iai[ip] = -1;
-                            bsync();
-                        }
-                        break; // -> l1 (or l2 again)
-                    }
-                    // partial step: drop l, refresh s(ip)
-                    if (tid == 0) c.iai[l] = l;
-                    bsync();
                     delete_constraint(c, l);
                     STAMP(15)
+                    continue;
+                }
+                f_value += t * znp * (0.5 * t + uiq);
+                if (t == t2) {
+                    // (iii) full step: add ip to the active set.  One reflector H = I - tau v v' (v = d[iq:] - alpha e_0)
+                    // zeroes d[iq+1:]; J[:, iq:] v = z - alpha J[:, iq] needs no new matvec.
+                    const double diq = c.d[iq];
+                    double alpha = diq, v0 = 0.0, tau = 0.0;
+                    const bool reflect = (iq + 1 < n && dn2 > 0.0);
+                    if (reflect) {
+                        const double inx = rsqrt(dn2);
+                        const double nx = dn2 * inx;
+                        alpha = (diq >= 0.0) ? -nx : nx;
+                        v0 = diq - alpha;
+                        tau = fast_rcp(fma(nx, fabs(diq), dn2));
+                    }
+                    const bool accepted = fabs(alpha) > eps * c.R_norm;
+                    if (reflect && tid < n) c.part[tid] = tau * (c.z[tid] - alpha * c.J[tid * ldj + iq]);
+                    if (na > 0) act_rows(c, tact, t); // tau' of the next iterate, x + t z formed on the fly
+                    bsync(); // B4
+                    STAMP(13)
+                    // ---- P5
+                    if (reflect) {
+                        const int kr = tid & 127, half = tid >> 7;
+                        if (kr < n) {
+                            const int span = n - iq;
+                            const int ca = iq + half * ((span + 1) >> 1), cb = half ? n : iq + ((span + 1) >> 1);
+                            double* Jk = c.J + kr * ldj;
+                            const double wk = c.part[kr];
+                            int cc = ca;
+                            if (cc == iq && cc < cb) {
+                                Jk[cc] = fma(-wk, v0, Jk[cc]);
+                                ++cc;
+                            }
+                            for (; cc + 4 <= cb; cc += 4) {
+                                const double d0 = c.d[cc], d1 = c.d[cc + 1], d2 = c.d[cc + 2], d3 = c.d[cc + 3];
+                                const double j0 = Jk[cc], j1 = Jk[cc + 1], j2 = Jk[cc + 2], j3 = Jk[cc + 3];
+                                Jk[cc] = fma(-wk, d0, j0);
+                                Jk[cc + 1] = fma(-wk, d1, j1);
+                                Jk[cc + 2] = fma(-wk, d2, j2);
+                                Jk[cc + 3] = fma(-wk, d3, j3);
+                            }
+                            for (; cc < cb; ++cc) Jk[cc] = fma(-wk, c.d[cc], Jk[cc]);
+                        }
+                    }
+                    {
+                        double* Rc = c.R + roff(iq);
+                        for (int i = tid; i < iq; i += kThreads) Rc[i] = c.d[i];
+                        if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
+                        if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                        if (tid == kThreads - 1) {
+                            Rc[iq] = alpha;
+                            c.rdinv[iq] = 1.0 / alpha;
+                            c.u[iq] = uiq + t;
+                            if (accepted) c.iai[ip] = -1;
+                        }
+                    }
+                    c.iq = iq + 1;
+                    bsync(); // B5
+                    STAMP(14)
+                    if (accepted) c.R_norm = fmax(c.R_norm, fabs(alpha));
+                    else {
+                        // numerically dependent: take the constraint out again, back to the saved iterate, pick another
+                        if (tid == 0) c.iaexcl[ip] = 0;
+                        bsync();
+                        delete_constraint(c, ip);
+                        for (int i = tid; i < nin2; i += kThreads) c.iai[i] = i;
+                        bsync();
+                        for (int i = tid; i < c.iq; i += kThreads) {
+                            const int av = c.Aold[i];
+                            c.A[i] = av;
+                            if (av >= 0) c.iai[av] = -1;
+                            c.u[i] = c.uold[i];
+                        }
+                        for (int i = tid; i < n; i += kThreads) c.x[i] = c.xold[i];
+                        bsync();
+                        redo_l2 = true;
+                        tau_stale = true;
+                    }
+                    break; // -> l1 (or l2 again)
+                }
+                // (iii) partial step: primal + dual step, drop l, refresh s(ip)
+                bsync(); // everyone has read s[ip], u[iq], A[lpos] before they change
+                if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
+                if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                if (tid == kThreads - 1) c.u[iq] = uiq + t;
+                if (tid == 0) c.iai[l] = l;
+                bsync();
+                STAMP(13)
+                tau_stale = true;
+                delete_constraint(c, l);
+                STAMP(15)
+                {
+                    double ci0;
+                    if (kind == INEQ_BOUNDS) ci0 = (sg < 0.0) ? c.bub[rr] : -c.blb[rr];
+                    else if (kind == INEQ_ACTUATION) ci0 = (sg < 0.0) ? c.tu[rr] : -c.tl[rr];
+                    else ci0 = (sg < 0.0) ? fub[ct * 17 + rr] : -flb[ct * 17 + rr];
                     double part = 0.0;
                     for (int j = k0 + tid; j < k1; j += kThreads) part = fma(c.np[j], c.x[j], part);
                     part = block_sum(c, part);
