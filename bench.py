@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--squat", action="store_true", help="CoM reference follows etc/talos/squat.yaml (BASELINE config 4)")
     p.add_argument("--no-allgather", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--index-order", action="store_true",
+                   help="launch the QPs in index order instead of longest-first (WBCQP_FLAG_INDEX_ORDER)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
     p.add_argument("--traffic", type=float, default=None,
                    help="HBM bytes per launch from rocprofv3 PMC passes (default: scaled from profiles/pmc_latest.json)")
@@ -83,7 +85,7 @@ def main():
                  iters=torch.zeros(B, dtype=torch.int32, device=dev))
     tau_all = torch.zeros(world * B, max(st.na, 1), dtype=torch.float64, device=dev) if distributed else None
 
-    h = capi.Handle(device=local_rank, dtype=capi.F64)
+    h = capi.Handle(device=local_rank, dtype=capi.F64, flags=capi.FLAG_INDEX_ORDER if args.index_order else 0)
     h.set_structure(0, st)
     layout = capi.layout_of(st)
     do_gather = distributed and not args.no_allgather
@@ -152,6 +154,7 @@ def main():
             "config": {"workload": "%s_pos_tracker%s_b%d_fp64_one_workgroup_per_qp" % (args.robot, "_squat" if args.squat else "", B),
                        "batch_per_gpu": B, "n": st.n, "neq": st.neq, "nin": st.nin, "level1_rows": st.r1,
                        "parallelism": "batch-shard x%d" % world,
+                       "schedule": "index-order" if args.index_order else "longest-first (iteration counts of the previous step)",
                        "allgather_tau": bool(gather_state["ok"]), "lds_bytes_per_qp": layout["lds_bytes"],
                        "qps_resident_per_cu": layout["waves_per_cu"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -164,6 +167,20 @@ def main():
         }
         if gather_state["err"]:
             result["config"]["allgather_error"] = gather_state["err"]
+        if world == 1 and not args.index_order:
+            # the same K steps with the launch in plain index order (WBCQP_FLAG_INDEX_ORDER), reported beside `value`
+            h2 = capi.Handle(device=local_rank, dtype=capi.F64, flags=capi.FLAG_INDEX_ORDER)
+            h2.set_structure(0, st)
+            for _ in range(args.warmup):
+                h2.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                h2.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            result["index_order"] = {"value": B * args.steps / (time.perf_counter() - t1), "unit": "QP/s",
+                                     "note": "same batch, QPs launched in index order (no schedule from the previous step)"}
+            h2.close()
 
         if not args.no_cpu_baseline and world == 1:
             # the oracle is the checker here and the reported CPU baseline -- never the thing shipped

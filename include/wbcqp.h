@@ -144,10 +144,15 @@ typedef struct {
     int32_t* n_active;/* [batch] size of the final active set incl. equalities, may be NULL  */
 } wbcqp_outputs;
 
+/* wbcqp_desc.flags */
+#define WBCQP_FLAG_INDEX_ORDER 1 /* launch the QPs of a batch in index order.  Default (0): longest-first -- a launch is
+                                    ordered by the active-set iteration counts of the previous launch of the same shape on
+                                    the same stream (control ticks change little); results do not depend on the order */
+
 typedef struct {
     int32_t device;   /* HIP device ordinal */
     int32_t dtype;    /* wbcqp_dtype of every input/output array */
-    int32_t flags;    /* reserved, 0 */
+    int32_t flags;    /* WBCQP_FLAG_* */
 } wbcqp_desc;
 
 /* one homogeneous group of a ragged (mixed-robot) batch */

@@ -156,17 +156,20 @@ def layout_of(st: Structure) -> Dict[str, int]:
     return {k: getattr(L, k) for k, _ in CLayout._fields_}
 
 
+FLAG_INDEX_ORDER = 1  # wbcqp_desc.flags: launch in index order (default: longest-first, see include/wbcqp.h)
+
+
 class Handle:
     """wbcqp_handle bound to one HIP device."""
 
-    def __init__(self, device: int = 0, dtype: int = F64):
+    def __init__(self, device: int = 0, dtype: int = F64, flags: int = 0):
         self.lib = load_library()
         self.dtype = dtype
         self.np_dtype = np.float64 if dtype == F64 else np.float32
         self.device = device
         self._h = C.c_void_p()
         self._structs: Dict[int, Structure] = {}
-        desc = CDesc(device, dtype, 0)
+        desc = CDesc(device, dtype, flags)
         rc = self.lib.wbcqp_create(C.byref(desc), C.byref(self._h))
         if rc != WBCQP_OK:
             raise WbcqpError(rc, (self.lib.wbcqp_last_error(None) or b"").decode())

@@ -45,6 +45,13 @@ struct wbcqp_handle {
     Staging stage_in, stage_out;
     int max_lds = 0;
     long long* dbg = nullptr; // diagnostic builds only (wbcqp_debug_set_stamp_buffer)
+    // longest-first schedule (schedule_kernel): launch order for the next solve of the same shape on the same stream
+    int flags = 0;
+    int* order = nullptr;
+    int order_cap = 0;
+    int order_total = 0;              // 0: no valid order
+    unsigned long long order_sig = 0; // shape of the launch the order belongs to
+    hipStream_t order_stream = nullptr;
 };
 
 namespace {
@@ -208,7 +215,7 @@ int check_io(wbcqp_handle* h, const Slot& s, int batch, const wbcqp_inputs* in, 
 }
 
 template <typename TI>
-int launch(wbcqp_handle* h, const GroupTable<TI>& tab, int total, int lds_bytes, hipStream_t stream)
+int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipStream_t stream)
 {
     if (total == 0) return WBCQP_OK;
     if (lds_bytes > h->max_lds) {
@@ -216,8 +223,37 @@ int launch(wbcqp_handle* h, const GroupTable<TI>& tab, int total, int lds_bytes,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         h->max_lds = lds_bytes;
     }
+    // schedule: the order left by the previous launch is used when it is of this very shape and was produced on this
+    // stream (stream order then guarantees that it is complete); otherwise index order
+    const bool sched = !(h->flags & WBCQP_FLAG_INDEX_ORDER) && total > 1;
+    unsigned long long sig = 1469598103934665603ull;
+    ScheduleArgs sa{};
+    sa.n = tab.n;
+    for (int g = 0; g < tab.n; ++g) {
+        sig = (sig ^ (unsigned long long)(uintptr_t)tab.g[g].st) * 1099511628211ull;
+        sig = (sig ^ (unsigned long long)tab.g[g].count) * 1099511628211ull;
+        sa.iters[g] = tab.g[g].iters;
+        sa.count[g] = tab.g[g].count;
+    }
+    tab.order = (sched && h->order_total == total && h->order_sig == sig && h->order_stream == stream) ? h->order : nullptr;
     hipLaunchKernelGGL(solve_kernel<TI>, dim3(total), dim3(kThreads), lds_bytes, stream, tab);
     HIP_TRY(h, hipGetLastError());
+    if (sched) {
+        if (total > h->order_cap) { // first launch of a larger shape: the only allocation on this path
+            HIP_TRY(h, hipStreamSynchronize(stream));
+            if (h->order) (void)hipFree(h->order);
+            h->order = nullptr;
+            h->order_cap = 0;
+            h->order_total = 0;
+            HIP_TRY(h, hipMalloc(&h->order, sizeof(int) * (size_t)total));
+            h->order_cap = total;
+        }
+        hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, stream, sa, h->order, total);
+        HIP_TRY(h, hipGetLastError());
+        h->order_total = total;
+        h->order_sig = sig;
+        h->order_stream = stream;
+    }
     return WBCQP_OK;
 }
 
@@ -270,6 +306,7 @@ int wbcqp_create(const wbcqp_desc* desc, wbcqp_handle** out)
     wbcqp_handle* h = new wbcqp_handle();
     h->device = desc->device;
     h->dtype = desc->dtype;
+    h->flags = desc->flags;
     *out = h;
     return WBCQP_OK;
 }
@@ -281,6 +318,7 @@ int wbcqp_destroy(wbcqp_handle* h)
     for (auto& s : h->slots) release(s);
     if (h->stage_in.dev) (void)hipFree(h->stage_in.dev);
     if (h->stage_out.dev) (void)hipFree(h->stage_out.dev);
+    if (h->order) (void)hipFree(h->order);
     delete h;
     return WBCQP_OK;
 }

@@ -163,3 +163,38 @@ def test_full_size_properties(handle, oracle_mod):
     sub = {k: v[:32] for k, v in inputs.items()}
     ref = oracle_mod.tick_batch(st, sub, nthreads=4)
     assert_parity(st, {k: v[:32] for k, v in got.items()}, ref, what="talos-1024-sample")
+
+
+@pytest.mark.gpu
+def test_longest_first_schedule_changes_nothing_but_the_order():
+    """The second launch of a shape runs longest-first (order from the first launch's iteration counts): every QP is
+    solved exactly once and bitwise as in index order."""
+    import torch
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.talos_structure()
+    B = 300
+    inputs = synth.generate(st, B, synth.SEED_BASE["talos"] + 977)
+    dev = torch.device("cuda", 0)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
+
+    def run(flags, launches):
+        h = capi.Handle(0, capi.F64, flags=flags)
+        h.set_structure(0, st)
+        outs = []
+        for _ in range(launches):
+            d_out = dict(x=torch.full((B, st.n), float("nan"), dtype=torch.float64, device=dev),
+                         tau=torch.full((B, st.na), float("nan"), dtype=torch.float64, device=dev),
+                         status=torch.full((B,), -99, dtype=torch.int32, device=dev),
+                         iters=torch.full((B,), -1, dtype=torch.int32, device=dev))
+            h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs.append({k: v.cpu().numpy() for k, v in d_out.items()})
+        h.close()
+        return outs
+
+    plain = run(capi.FLAG_INDEX_ORDER, 1)[0]
+    sched = run(0, 3)
+    assert (plain["status"] == 0).all() and plain["iters"].max() > plain["iters"].min()
+    for o in sched:
+        for k in ("x", "tau", "status", "iters"):
+            assert np.array_equal(o[k], plain[k]), k

@@ -59,6 +59,21 @@ def main():
         if mean[i] > 0:
             print("  %-18s %12.0f  %5.1f %%" % (nm, mean[i], 100 * mean[i] / mean.sum()))
             rows.append({"phase": nm, "ticks": float(mean[i]), "share": float(mean[i] / mean.sum())})
+    # what the spread of per-QP cycles costs a launch of B workgroups on 256 CUs, one QP per CU at a time:
+    # in-order greedy dispatch (what the hardware does) against longest-first order and against the perfect split
+    import heapq
+    def makespan(costs, cus=256):
+        heap = [0.0] * cus
+        for cst in costs:
+            heapq.heappush(heap, heapq.heappop(heap) + cst)
+        return max(heap)
+    ideal = tot.sum() / 256.0
+    print("  schedule on 256 CUs: in-order %.0f, longest-first %.0f, perfect split %.0f cycles (iters max %d)" %
+          (makespan(tot), makespan(sorted(tot, reverse=True)), ideal, int(iters.max())))
+    hist = np.bincount(np.minimum(iters, 20), minlength=21)
+    print("  iterations histogram:", hist.tolist())
+    by_it = [float(tot[iters == k].mean()) if (iters == k).any() else 0.0 for k in range(1, 13)]
+    print("  mean cycles by iteration count 1..12:", [int(v) for v in by_it])
     if args.out:
         with open(args.out, "w") as fh:
             json.dump({"robot": args.robot, "batch": B, "noise": args.noise, "iters_mean": float(iters.mean()),
