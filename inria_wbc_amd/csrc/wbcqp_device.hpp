@@ -872,16 +872,20 @@ __device__ __forceinline__ double grp8_sum(double v)
     return v;
 }
 
+constexpr int kGS = 24; // row stride of G = striu(V'V) in the part slots (24 x 24 doubles), zero outside the m x m corner
+
 // ------------------------------------------------------------------------------------------------
-// Householder QR of B (n x m, n <= 80, m <= 32 columns), columns resident in registers: 8 lanes per column, lane kc of a
-// column keeps the row pairs (2 kc + 16 t, + 1), t < 5.  Per step only the reflector travels: the owner of column j leaves
-// v_j (zeros above row j, v0 on it) and (tau_j, alpha_j) in LDS, every later column reads it once (5 x 16 bytes per
-// lane), reduces its dot product over its 8 lanes by DPP and updates its registers; the lanes of column j + 1 go on to
-// the next reflector.  One barrier per column, no reloads or stores of the trailing matrix.  On return B holds V (unit
-// part scaled as LAPACK's is not: v0 on the diagonal) below and R's strict upper part above; rdiag / tau the rest.
+// Householder QR of B (n x m, n <= 80, m <= 22), columns resident in registers: 8 lanes per column, lane
+// kc of a column keeps the row pairs (2 kc + 16 t, + 1), t < 5.  Per step only the reflector travels: the owner of column
+// j leaves v_j (zeros above row j, v0 on it) and (tau_j, alpha_j) in LDS, every other column reads it once (5 x 16
+// bytes per lane) and reduces its dot product with it over its 8 lanes by DPP: later columns update their registers, the
+// lanes of column j + 1 go on to the next reflector, EARLIER columns (which hold v_l by now) leave G(l,j) = v_l'v_j.
+// One barrier per column, no reloads or stores of the trailing matrix.  On return: V (v0 on the diagonal, zeros above)
+// in B, the packed R and 1/R(j,j), tau, G = striu(V'V) (row stride kGS).
+// (W = J0 V in the shadow of the idle lanes was tried: 74 lanes cannot keep up with a QR step, 67 k cycles against 27 k.)
 // Returns false when a column is (numerically) dependent on its predecessors.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, double* rdiag, double* vbuf, double* sc)
+__device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, double* vbuf, double* sc, double* G)
 {
     const int n = c.n, m = c.neq, ldb = c.ldb, tid = c.tid;
     const int e = tid >> 3, kc = tid & 7;
@@ -896,6 +900,7 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, dou
             const double v = Bm[min(row, n - 1) * ldb + es];
             b[t][i] = (row < n) ? v : 0.0;
         }
+    double my_alpha = 1.0;
     // reflector of column jn from the registers of its 8 lanes (call under e == jn)
     auto prepare = [&](int jn) __attribute__((always_inline)) {
         double sq0 = 0.0, sq1 = 0.0, x0 = 0.0;
@@ -904,10 +909,10 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, dou
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 2 * kc + 16 * t + i;
-                const double v = (row >= jn) ? b[t][i] : 0.0;
+                const double v = (t >= 2 || row >= jn) ? b[t][i] : 0.0; // jn < 32: rows of t >= 2 are always below
                 if (i == 0) sq0 = fma(v, v, sq0);
                 else sq1 = fma(v, v, sq1);
-                if (t < 2) x0 += (row == jn) ? v : 0.0; // jn < 32
+                if (t < 2) x0 += (row == jn) ? v : 0.0;
             }
         const double nrm = grp8_sum(sq0 + sq1);
         x0 = grp8_sum(x0);
@@ -916,6 +921,7 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, dou
         const double alpha = (x0 >= 0.0) ? -nx : nx;
         const double v0 = x0 - alpha;
         const double tj = fast_rcp(fma(nx, fabs(x0), nrm)); // 2 / v'v
+        my_alpha = alpha;
         double* vb = vbuf + (jn & 1) * 80;
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
@@ -924,16 +930,19 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, dou
             if (t < 2) {
                 if (row == jn) b[t][0] = v0;
                 if (row + 1 == jn) b[t][1] = v0;
+                o.x = (row >= jn) ? b[t][0] : 0.0;
+                o.y = (row + 1 >= jn) ? b[t][1] : 0.0;
             }
-            o.x = (row >= jn) ? b[t][0] : 0.0;
-            o.y = (row + 1 >= jn) ? b[t][1] : 0.0;
+            else {
+                o.x = b[t][0];
+                o.y = b[t][1];
+            }
             *reinterpret_cast<double2v*>(__builtin_assume_aligned(vb + row, 16)) = o;
         }
         if (kc == 0) {
             sc[(jn & 1) * 2] = tj;
             sc[(jn & 1) * 2 + 1] = alpha;
             tau[jn] = tj;
-            rdiag[jn] = alpha;
         }
     };
     if (e == 0) prepare(0);
@@ -942,8 +951,9 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, dou
         const double tj = sc[(j & 1) * 2], alpha = sc[(j & 1) * 2 + 1];
         if (!(fabs(alpha) > 2.220446049250313e-16 * c.R_norm)) return false; // also catches a NaN pivot
         c.R_norm = fmax(c.R_norm, fabs(alpha));
-        if (colv && e > j) {
-            const double* vb = vbuf + (j & 1) * 80 + 2 * kc;
+        const double* vbj = vbuf + (j & 1) * 80;
+        if (colv && e != j) {
+            const double* vb = vbj + 2 * kc;
             double2v v[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) v[t] = ld2(vb + 16 * t);
@@ -953,28 +963,41 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, dou
                 d0 = fma(v[t].x, b[t][0], d0);
                 d1 = fma(v[t].y, b[t][1], d1);
             }
-            const double coef = grp8_sum(d0 + d1) * tj;
+            const double dot = grp8_sum(d0 + d1);
+            if (e > j) {
+                const double coef = dot * tj;
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                b[t][0] = fma(-coef, v[t].x, b[t][0]);
-                b[t][1] = fma(-coef, v[t].y, b[t][1]);
+                for (int t = 0; t < 5; ++t) {
+                    b[t][0] = fma(-coef, v[t].x, b[t][0]);
+                    b[t][1] = fma(-coef, v[t].y, b[t][1]);
+                }
+                if (e == j + 1) prepare(j + 1);
             }
-            if (e == j + 1) prepare(j + 1);
+            else if (kc == 0) G[e * kGS + j] = dot; // v_e has zeros where its R entries sit in b: v_j is zero above row j > e
         }
     }
+    // V into B (zeros in place of R), R packed, 1/R(j,j)
     if (colv) {
+        double* Rc = c.R + roff(e);
 #pragma unroll
         for (int t = 0; t < 5; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 2 * kc + 16 * t + i;
-                if (row < n) Bm[row * ldb + e] = b[t][i];
+                if (row < e) {
+                    Rc[row] = b[t][i];
+                    Bm[row * ldb + e] = 0.0;
+                }
+                else if (row < n) Bm[row * ldb + e] = b[t][i];
             }
+        if (kc == 0) {
+            Rc[e] = my_alpha;
+            c.rdinv[e] = 1.0 / my_alpha;
+        }
     }
     return true;
 }
 
-constexpr int kGS = 24; // row stride of G = striu(V'V) in the part slots (24 x 24 doubles), zero outside the m x m corner
 
 // y = R'^-1 rhs (forward), u = R^-1 y (backward) on one wave: lane = index.  Column `lane` and row `lane` of the packed R
 // sit in registers (clamped loads, all in flight at once); lanes past m carry zeros, so the loops run to the
@@ -1051,8 +1074,7 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     double* Bm = c.R + 256;    // B -> V (lower trapezoid) / R (strict upper), in the unused tail of the R region
     double* Tm = c.eqt;        // T (m x (m+1))
     double* tau = Tm + m * (m + 1);
-    double* rdiag = tau + m;
-    double* rhs = rdiag + m;   // later y
+    double* rhs = tau + 2 * m;  // later y
 
     // ---- N = CE': base dynamics rows [M_u | -J_u'], then the contact motion rows [A_c | 0]
     for (int e2 = tid; e2 < n * m; e2 += kThreads) {
@@ -1098,69 +1120,16 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
                 }
         }
     }
-    for (int e2 = tid; e2 < 16 * ldb; e2 += kThreads) Bm[n * ldb + e2] = 0.0; // zero rows below B for the maskless QR steps
+    for (int e2 = tid; e2 < kGS * kGS; e2 += kThreads) c.part[e2] = 0.0; // G = striu(V'V), zero-padded for the solves
     bsync();
     STAMP(5)
-    // ---- Householder QR of B with the columns in registers, one barrier per column
-    if (!qr_resident(c, Bm, tau, rdiag, c.part, c.part + 160)) return false; // redundant equalities
+    // ---- Householder QR of B with the columns in registers, one barrier per column; G = striu(V'V) and W = J0 V are
+    //      formed in its shadow (qr_resident) -- W = J0 V follows.  Compact WY without forming T: Q = I - V T V' with
+    //      T^-1 = striu(V'V) + diag(1/tau)  (T^-1 + T^-T = V'V), so W T is the solution X of X T^-1 = W.
+    if (!qr_resident(c, Bm, tau, c.s, c.s + 160, c.part)) return false; // redundant equalities
     bsync();
     STAMP(6)
-    // ---- R (packed, the active-set factor) from the strict upper part of B and the Householder alphas; that part is
-    //      cleared on the way so that B is exactly V.  The G area is zeroed for the padded solves below.
-    for (int e2 = tid; e2 < m * m; e2 += kThreads) {
-        const int i = e2 / m, jj = e2 - i * m;
-        if (i < jj) {
-            c.R[roff(jj) + i] = Bm[i * ldb + jj];
-            Bm[i * ldb + jj] = 0.0;
-        }
-        else if (i == jj) {
-            const double a = rdiag[jj];
-            c.R[roff(jj) + jj] = a;
-            c.rdinv[jj] = 1.0 / a;
-        }
-    }
-    for (int e2 = tid; e2 < kGS * kGS; e2 += kThreads) c.part[e2] = 0.0;
-    bsync();
     const double* Vm = Bm;
-    // ---- compact WY without forming T: Q = I - V T V' with T^-1 = striu(V'V) + diag(1/tau)  (T^-1 + T^-T = V'V), so
-    //      W T is the solution X of X T^-1 = W, one forward substitution per row.  G(l,j) = v_l'v_j, l < j, one pair per
-    //      thread of waves 0..2, eight k-steps of operands in flight.  Meanwhile the last wave solves y = R'^-1 rhs and
-    //      u = R^-1 y (lane = index, its column and row of R in registers, pivots by readlane).
-    if (c.wave < 3) {
-        const int npair = m * (m - 1) / 2;
-        for (int pidx = tid; pidx < npair; pidx += 3 * kWave) {
-            int bb = (int)((sqrtf(8.0f * (float)pidx + 1.0f) + 1.0f) * 0.5f); // bb(bb-1)/2 <= pidx < bb(bb+1)/2, bb >= 1
-            while (bb * (bb - 1) / 2 > pidx) --bb;
-            while ((bb + 1) * bb / 2 <= pidx) ++bb;
-            const int aa = pidx - bb * (bb - 1) / 2; // aa < bb
-            const double* pa = Vm + aa;
-            const double* pb = Vm + bb;
-            double a0 = 0.0, a1 = 0.0;
-            int kk = bb;
-            for (; kk + 8 <= n; kk += 8) {
-                double va[8], vb[8];
-#pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) {
-                    va[s8] = pa[(kk + s8) * ldb];
-                    vb[s8] = pb[(kk + s8) * ldb];
-                }
-#pragma unroll
-                for (int s8 = 0; s8 < 8; s8 += 2) {
-                    a0 = fma(va[s8], vb[s8], a0);
-                    a1 = fma(va[s8 + 1], vb[s8 + 1], a1);
-                }
-            }
-            for (; kk < n; ++kk) a0 = fma(pa[kk * ldb], pb[kk * ldb], a0);
-            c.part[aa * kGS + bb] = a0 + a1; // G(aa,bb)
-        }
-    }
-    else {
-        if (m <= 12) solve_yu<12>(c, rhs);
-        else if (m <= 20) solve_yu<20>(c, rhs);
-        else solve_yu<24>(c, rhs);
-    }
-    bsync();
-    STAMP(7)
     // ---- W = J0 V: item (pair of rows, 4 columns), wave-uniform k range as for B
     {
         const int ncg = (m + 3) >> 2;
@@ -1184,12 +1153,18 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     }
     bsync();
     STAMP(18)
-    // ---- W <- W T by forward substitution with T^-1: thread = row
+    // ---- W <- W T by forward substitution with T^-1: thread = row (n <= 80: waves 0 and 1); meanwhile the last wave
+    //      solves y = R'^-1 rhs and u = R^-1 y (lane = index, its column and row of R in registers, pivots by readlane)
     if (tid < n) {
         double* Wr = Nm + tid * ldb;
         if (m <= 12) solve_wt<12>(c, Wr, tau);
         else if (m <= 20) solve_wt<20>(c, Wr, tau);
         else solve_wt<24>(c, Wr, tau);
+    }
+    else if (c.wave == 3) {
+        if (m <= 12) solve_yu<12>(c, rhs);
+        else if (m <= 20) solve_yu<20>(c, rhs);
+        else solve_yu<24>(c, rhs);
     }
     bsync();
     STAMP(19)
