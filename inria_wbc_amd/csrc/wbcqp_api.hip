@@ -24,8 +24,7 @@ thread_local std::string g_create_error;
 
 struct Slot {
     bool set = false;
-    DevStruct host{};           // host copy (device pointers inside)
-    DevStruct* dev = nullptr;   // device copy
+    DevStruct host{};           // sizes, LDS layout and device pointers of the tables: travels by value with every launch
     std::vector<void*> allocs;  // device arrays owned by this slot
     wbcqp_layout layout{};
 };
@@ -75,7 +74,7 @@ int fail(wbcqp_handle* h, int code, const std::string& msg)
 int odd(int v) { return v | 1; }
 
 // Validates a structure and derives sizes + LDS layout. Pure host code.
-int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string& why)
+int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout& L, std::string& why)
 {
     if (!st) { why = "structure is NULL"; return WBCQP_ERR_INVALID; }
     if (st->nv <= 0 || st->na < 0 || st->na > st->nv || st->nc < 0) { why = "bad nv/na/nc"; return WBCQP_ERR_INVALID; }
@@ -91,10 +90,10 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
     D.act_bounds = st->act_bounds ? 1 : 0;
     D.neq = D.nu + 6 * D.nc;
     D.r1 = D.n_dense + D.n_sel + 6 * D.nc;
-    D.n_blocks = st->n_ineq_blocks;
+    HB.n_blocks = st->n_ineq_blocks;
     int off = 0;
     bool has_act = false;
-    for (int b = 0; b < D.n_blocks; ++b) {
+    for (int b = 0; b < HB.n_blocks; ++b) {
         const int kind = st->ineq_kind[b];
         int rows;
         if (kind == WBCQP_INEQ_BOUNDS) rows = D.n_bound;
@@ -104,7 +103,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, wbcqp_layout& L, std::string
             if (st->ineq_arg[b] < 0 || st->ineq_arg[b] >= D.nc) { why = "force block names a missing contact"; return WBCQP_ERR_INVALID; }
         }
         else { why = "unknown inequality kind"; return WBCQP_ERR_INVALID; }
-        D.blk_kind[b] = kind; D.blk_arg[b] = st->ineq_arg[b]; D.blk_off[b] = off; D.blk_rows[b] = rows;
+        HB.blk_kind[b] = kind; HB.blk_arg[b] = st->ineq_arg[b]; HB.blk_off[b] = off; HB.blk_rows[b] = rows;
         off += 2 * rows;
     }
     if (has_act != (D.act_bounds != 0)) { why = "act_bounds flag and inequality blocks disagree"; return WBCQP_ERR_INVALID; }
@@ -175,15 +174,13 @@ void release(Slot& s)
 {
     for (void* p : s.allocs) (void)hipFree(p);
     s.allocs.clear();
-    if (s.dev) (void)hipFree(s.dev);
-    s.dev = nullptr;
     s.set = false;
 }
 
 template <typename TI>
 void fill_group(GroupArgs<TI>& g, const Slot& s, int batch, const wbcqp_inputs* in, const wbcqp_outputs* out)
 {
-    g.st = s.dev;
+    g.st = s.host;
     g.M = static_cast<const TI*>(in->M); g.h = static_cast<const TI*>(in->h); g.A = static_cast<const TI*>(in->A);
     g.b1 = static_cast<const TI*>(in->b1); g.Ac = static_cast<const TI*>(in->Ac); g.bc = static_cast<const TI*>(in->bc);
     g.blb = static_cast<const TI*>(in->blb); g.bub = static_cast<const TI*>(in->bub);
@@ -230,7 +227,8 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     ScheduleArgs sa{};
     sa.n = tab.n;
     for (int g = 0; g < tab.n; ++g) {
-        sig = (sig ^ (unsigned long long)(uintptr_t)tab.g[g].st) * 1099511628211ull;
+        sig = (sig ^ (unsigned long long)(uintptr_t)tab.g[g].st.rowmeta) * 1099511628211ull;
+        sig = (sig ^ (unsigned long long)tab.g[g].st.lds_doubles) * 1099511628211ull;
         sig = (sig ^ (unsigned long long)tab.g[g].count) * 1099511628211ull;
         sa.iters[g] = tab.g[g].iters;
         sa.count[g] = tab.g[g].count;
@@ -279,9 +277,10 @@ const char* wbcqp_last_error(const wbcqp_handle* handle) { return handle ? handl
 int wbcqp_layout_of(const wbcqp_structure* st, wbcqp_layout* out)
 {
     DevStruct D;
+    HostBlocks HB;
     wbcqp_layout L;
     std::string why;
-    int rc = derive(st, D, L, why);
+    int rc = derive(st, D, HB, L, why);
     if (rc != WBCQP_OK) return fail(nullptr, rc, why);
     if (out) *out = L;
     return WBCQP_OK;
@@ -328,9 +327,10 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     if (!h) return WBCQP_ERR_INVALID;
     if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES) return fail(h, WBCQP_ERR_INVALID, "slot out of range");
     DevStruct D;
+    HostBlocks HB;
     wbcqp_layout L;
     std::string why;
-    int rc = derive(st, D, L, why);
+    int rc = derive(st, D, HB, L, why);
     if (rc != WBCQP_OK) return fail(h, rc, why);
     HIP_TRY(h, hipSetDevice(h->device));
     Slot& s = h->slots[slot];
@@ -367,22 +367,25 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     UP(fric_ub, st->fric_ub, nc * 17);
     {
         std::vector<int> meta((size_t)D.nin2 + 1, 0);
-        for (int b = 0; b < D.n_blocks; ++b) {
-            const int rows = D.blk_rows[b], off = D.blk_off[b], kind = D.blk_kind[b];
+        for (int b = 0; b < HB.n_blocks; ++b) {
+            const int rows = HB.blk_rows[b], off = HB.blk_off[b], kind = HB.blk_kind[b];
             for (int r = 0; r < rows; ++r) {
                 const int col = (kind == WBCQP_INEQ_BOUNDS) ? st->bound_col[r] : 0;
-                const int ct = (kind == WBCQP_INEQ_FORCE) ? D.blk_arg[b] : 0;
+                const int ct = (kind == WBCQP_INEQ_FORCE) ? HB.blk_arg[b] : 0;
                 meta[off + r] = row_meta_pack(kind, 0, r, ct, col);
                 meta[off + rows + r] = row_meta_pack(kind, 1, r, ct, col);
             }
         }
         UP(rowmeta, meta.data(), D.nin2);
     }
+    {
+        std::vector<unsigned> mp((size_t)D.nv * (D.nv + 1) / 2 + 1, 0u);
+        for (int i = 0; i < D.nv; ++i)
+            for (int j = 0; j <= i; ++j)
+                mp[(size_t)i * (i + 1) / 2 + j] = (unsigned)(i * D.ldm + j) | ((unsigned)(j * D.ldm + i) << 16);
+        UP(mpack, mp.data(), D.nv * (D.nv + 1) / 2);
+    }
 #undef UP
-    void* dv = nullptr;
-    HIP_TRY(h, hipMalloc(&dv, sizeof(DevStruct)));
-    s.dev = static_cast<DevStruct*>(dv);
-    HIP_TRY(h, hipMemcpy(s.dev, &D, sizeof(DevStruct), hipMemcpyHostToDevice));
     s.host = D;
     s.layout = L;
     s.set = true;

@@ -50,12 +50,16 @@ enum { INEQ_BOUNDS = 0, INEQ_ACTUATION = 1, INEQ_FORCE = 2 };
 enum { HQP_UNKNOWN = -1, HQP_OPTIMAL = 0, HQP_INFEASIBLE = 1, HQP_UNBOUNDED = 2, HQP_MAX_ITER = 3, HQP_ERROR = 4 };
 
 // Constant structure of a task stack, resident in device memory (one per slot).
+// inequality blocks in task-stack order (host side only: the device works from the packed row descriptors)
+struct HostBlocks {
+    int n_blocks;
+    int blk_kind[kMaxBlocks], blk_arg[kMaxBlocks], blk_off[kMaxBlocks], blk_rows[kMaxBlocks];
+};
+
 struct DevStruct {
     int nv, na, nc, k, n, nu;
     int n_dense, n_tasks, n_sel, n_bound, act_bounds;
     int neq, nin2, r1;
-    int n_blocks;
-    int blk_kind[kMaxBlocks], blk_arg[kMaxBlocks], blk_off[kMaxBlocks], blk_rows[kMaxBlocks];
     int max_iter;
     double hessian_reg;
     const int *dense_row_task, *sel_col, *sel_task, *forcereg_task, *bound_col;
@@ -64,6 +68,7 @@ struct DevStruct {
     const double *ft;        // [nc][12][6]   F'
     const double *fric_mat, *fric_lb, *fric_ub;
     const int* rowmeta;      // [nin2] packed descriptor of every one-sided inequality row (see row_meta_*)
+    const unsigned* mpack;   // [nv(nv+1)/2] packed-M element e=(i,j) -> LDS offsets (i ldm + j) | (j ldm + i) << 16
     // LDS layout: leading dimensions and element offsets (in doubles)
     int ldj, ldm, ldc, ldb;
     int o_J, o_R, o_M, o_Jc, o_Ac, o_vec, o_eqw, o_eqt;
@@ -74,7 +79,7 @@ struct DevStruct {
 
 template <typename TI>
 struct GroupArgs {
-    const DevStruct* st;
+    DevStruct st; // by value: the sizes, offsets and table pointers arrive with the kernel arguments, not behind a pointer
     const TI *M, *h, *A, *b1, *Ac, *bc, *blb, *bub, *tlb, *tub, *w;
     TI *x, *tau, *objective;
     int *status, *iters, *n_active;
@@ -1418,7 +1423,9 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         const TI* pAc = ga.Ac + qp * (size_t)lenAc;
         TI vM[RM], vA[RA], vC[RC];
         double vT[RT];
+        unsigned vP[RM];
         ld_regs<TI, RM>(pM, lenM, tid, vM);
+        ld_regs<unsigned, RM>(S.mpack, lenM, tid, vP);
         if (lenA > 0) ld_regs<TI, RA>(pA, lenA, tid, vA);
         if (nc > 0) {
             ld_regs<TI, RC>(pAc, lenAc, tid, vC);
@@ -1455,24 +1462,22 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
 #pragma unroll
             for (int qd = 0; qd < 6; ++qd) ftc[qd] = S.ft[(fm / 12) * 72 + (fm % 12) * 6 + qd];
         }
-        // ---- land: packed M goes straight to both triangles of the full matrix
+        // while the record is on its way: J starts from zero (only the factorisation's final writes touch it)
+        for (int e = tid; e < n * ldj; e += kThreads) c.J[e] = 0.0;
+        // ---- land: packed M goes straight to both triangles of the full matrix (offsets from the structure's table)
 #pragma unroll
         for (int u = 0; u < RM; ++u) {
             const int e = tid + u * kThreads;
             if (e < lenM) {
-                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                while (i * (i + 1) / 2 > e) --i;
-                while ((i + 1) * (i + 2) / 2 <= e) ++i;
-                const int j = e - i * (i + 1) / 2;
                 const double v = (double)vM[u];
-                c.M[i * ldm + j] = v;
-                c.M[j * ldm + i] = v;
+                c.M[vP[u] & 0xffffu] = v;
+                c.M[vP[u] >> 16] = v;
             }
         }
         if (lenA > 0) st_regs<TI, RA>(As, lenA, tid, vA);
         if (nc > 0) {
             st_regs<TI, RC>(c.Ac, lenAc, tid, vC);
-            st_regs<double, RT>(c.J, lenT, tid, vT); // force generators staged in the (still unused) J region
+            st_regs<double, RT>(c.eqw, lenT, tid, vT); // force generators staged in the (still unused) equality scratch
             if (tid < nc * 6) c.bc[tid] = (double)vbc;
         }
         if (tid < nv) c.h[tid] = (double)vh;
@@ -1491,17 +1496,14 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         c.iai[tid] = drt; // parked until w has landed (iai is initialised in phase 4)
         // tails of arrays longer than the register rounds (none for the humanoid stacks)
         for (int e = tid + RM * kThreads; e < lenM; e += kThreads) {
-            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while (i * (i + 1) / 2 > e) --i;
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            const int j = e - i * (i + 1) / 2;
+            const unsigned pk = S.mpack[e];
             const double v = (double)pM[e];
-            c.M[i * ldm + j] = v;
-            c.M[j * ldm + i] = v;
+            c.M[pk & 0xffffu] = v;
+            c.M[pk >> 16] = v;
         }
         for (int e = tid + RA * kThreads; e < lenA; e += kThreads) As[e] = (double)pA[e];
         for (int e = tid + RC * kThreads; e < lenAc; e += kThreads) c.Ac[e] = (double)pAc[e];
-        for (int e = tid + RT * kThreads; e < lenT; e += kThreads) c.J[e] = S.force_gen[e];
+        for (int e = tid + RT * kThreads; e < lenT; e += kThreads) c.eqw[e] = S.force_gen[e];
         for (int i = tid + 2 * kThreads; i < nin2; i += kThreads) c.meta[i] = S.rowmeta[i];
         if (tid < nv) { // diagonal additions / right-hand sides of the selection rows
             c.z[tid] = 0.0;
@@ -1530,7 +1532,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
             const int m = tid % k, jg = tid / k;
             if (jg < G) {
                 const int ct = m / 12, mm = m - 12 * ct;
-                const double* T = c.J + ct * 72 + mm;
+                const double* T = c.eqw + ct * 72 + mm;
                 const double* Acc = c.Ac + ct * 6 * nv;
                 double tc[6];
 #pragma unroll
@@ -1546,7 +1548,6 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         }
     }
     bsync();
-    for (int e = tid; e < n * ldj; e += kThreads) c.J[e] = 0.0; // nobody touches J before the factorisation writes it
     STAMP(0)
 
     // ---------------- phases 1-2b in registers: H assembly, Cholesky H = U'U, J = U^-1 ----------------
@@ -2196,7 +2197,7 @@ __global__ __launch_bounds__(kThreads) void solve_kernel(const GroupTable<TI> ta
         ++gi;
     }
     const GroupArgs<TI>& ga = tab.g[gi];
-    const DevStruct& S = *ga.st;
+    const DevStruct& S = ga.st;
     solve_one<TI>(ga, S, b, lds);
 }
 
