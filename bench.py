@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--squat", action="store_true", help="CoM reference follows etc/talos/squat.yaml (BASELINE config 4)")
     p.add_argument("--no-allgather", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-compare", action="store_true", help="skip the extra index-order run reported beside `value`")
     p.add_argument("--index-order", action="store_true",
                    help="launch the QPs in index order instead of longest-first (WBCQP_FLAG_INDEX_ORDER)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
@@ -167,7 +168,7 @@ def main():
         }
         if gather_state["err"]:
             result["config"]["allgather_error"] = gather_state["err"]
-        if world == 1 and not args.index_order:
+        if world == 1 and not args.index_order and not args.no_compare:
             # the same K steps with the launch in plain index order (WBCQP_FLAG_INDEX_ORDER), reported beside `value`
             h2 = capi.Handle(device=local_rank, dtype=capi.F64, flags=capi.FLAG_INDEX_ORDER)
             h2.set_structure(0, st)

@@ -877,50 +877,71 @@ __device__ __forceinline__ double grp8_sum(double v)
     return v;
 }
 
-constexpr int kGS = 24; // row stride of G = striu(V'V) in the part slots (24 x 24 doubles), zero outside the m x m corner
+// sum over the 4 lanes of a quad (every lane gets the total)
+__device__ __forceinline__ double quad_sum(double v)
+{
+    v += dpp_get<0xB1>(v); // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v); // quad_perm [2,3,0,1]
+    return v;
+}
 
 // ------------------------------------------------------------------------------------------------
-// Householder QR of B (n x m, n <= 80, m <= 22), columns resident in registers: 8 lanes per column, lane
-// kc of a column keeps the row pairs (2 kc + 16 t, + 1), t < 5.  Per step only the reflector travels: the owner of column
-// j leaves v_j (zeros above row j, v0 on it) and (tau_j, alpha_j) in LDS, every other column reads it once (5 x 16
-// bytes per lane) and reduces its dot product with it over its 8 lanes by DPP: later columns update their registers, the
-// lanes of column j + 1 go on to the next reflector, EARLIER columns (which hold v_l by now) leave G(l,j) = v_l'v_j.
-// One barrier per column, no reloads or stores of the trailing matrix.  On return: V (v0 on the diagonal, zeros above)
-// in B, the packed R and 1/R(j,j), tau, G = striu(V'V) (row stride kGS).
-// (W = J0 V in the shadow of the idle lanes was tried: 74 lanes cannot keep up with a QR step, 67 k cycles against 27 k.)
-// Returns false when a column is (numerically) dependent on its predecessors.
+// Householder QR of B (n x m, n <= 80, m <= 22: 4 m + 2 n <= 256) with J <- J Q in its shadow.
+// QR: columns resident in registers, 4 lanes per column (the first 4 m lanes), lane kc of a column keeps the row pairs
+// (2 kc + 8 t, + 1), t < 10.  Per step only the reflector travels: the owner of column j leaves v_j (zeros above row j,
+// v0 on it) and (tau_j, alpha_j) in LDS, every later column reads it once (10 x 16 bytes per lane), reduces its dot
+// product over its quad by DPP and updates its registers; the lanes of column j + 1 go on to the next reflector.  One
+// barrier per column, no reloads or stores of the trailing matrix.
+// J Q: the last 2 n lanes are not part of the QR.  A lane pair keeps ROW r of J (40 + 40 doubles) in registers and
+// applies every reflector as it appears: row <- row - tau (row . v_j) v_j' -- row-local, the two halves of the dot
+// product meet by DPP, no barrier of its own, and it fits in the time the QR needs for its step.  This replaces the
+// compact-WY route (W = J V, W T, J - W T V': three LDS GEMM phases, 20 k cycles) by work nobody waits for.
+// (One lane per row needs 160 VGPRs for the row: the allocator then parks it in AGPRs, 4 k cycles per step.)
+// On return: J = J0 Q in LDS, the packed R and 1/R(j,j).  Returns false when a column is (numerically) dependent.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, double* vbuf, double* sc, double* G)
+__device__ __forceinline__ bool qr_resident(Ctx& c, const double* Bm, double* vbuf, double* sc)
 {
-    const int n = c.n, m = c.neq, ldb = c.ldb, tid = c.tid;
-    const int e = tid >> 3, kc = tid & 7;
+    const int n = c.n, m = c.neq, ldb = c.ldb, ldj = c.ldj, tid = c.tid;
+    const int e = tid >> 2, kc = tid & 3;
     const bool colv = e < m;
     const int es = colv ? e : 0;
-    double b[5][2];
+    const int jl = tid - (kThreads - 2 * n); // lane pair of a row of J (the last 2 n lanes), < 0: none
+    const int jr = jl >> 1, jh = jl & 1;
+    double b[10][2];
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = 2 * kc + 16 * t + i;
+            const int row = 2 * kc + 8 * t + i;
             const double v = Bm[min(row, n - 1) * ldb + es];
             b[t][i] = (row < n) ? v : 0.0;
         }
+    double jrow[40];
+    if (jl >= 0) {
+        const double* Jr = c.J + jr * ldj;
+#pragma unroll
+        for (int q = 0; q < 40; ++q) {
+            const int cc = 40 * jh + q;
+            const double v = Jr[min(cc, n - 1)];
+            jrow[q] = (cc < n) ? v : 0.0;
+        }
+    }
     double my_alpha = 1.0;
-    // reflector of column jn from the registers of its 8 lanes (call under e == jn)
+    // reflector of column jn from the registers of its 4 lanes (call under e == jn)
     auto prepare = [&](int jn) __attribute__((always_inline)) {
         double sq0 = 0.0, sq1 = 0.0, x0 = 0.0;
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
+        for (int t = 0; t < 10; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int row = 2 * kc + 16 * t + i;
-                const double v = (t >= 2 || row >= jn) ? b[t][i] : 0.0; // jn < 32: rows of t >= 2 are always below
+                const int row = 2 * kc + 8 * t + i;
+                const double v = (t >= 4 || row >= jn) ? b[t][i] : 0.0; // jn < 32: rows of t >= 4 are always below
                 if (i == 0) sq0 = fma(v, v, sq0);
                 else sq1 = fma(v, v, sq1);
-                if (t < 2) x0 += (row == jn) ? v : 0.0;
+                if (t < 4) x0 += (row == jn) ? v : 0.0;
             }
-        const double nrm = grp8_sum(sq0 + sq1);
-        x0 = grp8_sum(x0);
+        const double nrm = quad_sum(sq0 + sq1);
+        x0 = quad_sum(x0);
         const double inx = rsqrt(nrm);
         const double nx = (nrm > 0.0) ? nrm * inx : 0.0; // exactly dependent column: alpha = 0 -> reported as redundant
         const double alpha = (x0 >= 0.0) ? -nx : nx;
@@ -929,10 +950,10 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, dou
         my_alpha = alpha;
         double* vb = vbuf + (jn & 1) * 80;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
+        for (int t = 0; t < 10; ++t) {
             double2v o;
-            const int row = 2 * kc + 16 * t;
-            if (t < 2) {
+            const int row = 2 * kc + 8 * t;
+            if (t < 4) {
                 if (row == jn) b[t][0] = v0;
                 if (row + 1 == jn) b[t][1] = v0;
                 o.x = (row >= jn) ? b[t][0] : 0.0;
@@ -947,7 +968,6 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, dou
         if (kc == 0) {
             sc[(jn & 1) * 2] = tj;
             sc[(jn & 1) * 2 + 1] = alpha;
-            tau[jn] = tj;
         }
     };
     if (e == 0) prepare(0);
@@ -957,52 +977,72 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, double* Bm, double* tau, dou
         if (!(fabs(alpha) > 2.220446049250313e-16 * c.R_norm)) return false; // also catches a NaN pivot
         c.R_norm = fmax(c.R_norm, fabs(alpha));
         const double* vbj = vbuf + (j & 1) * 80;
-        if (colv && e != j) {
+        if (colv && e > j) {
             const double* vb = vbj + 2 * kc;
-            double2v v[5];
+            double2v v[10];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) v[t] = ld2(vb + 16 * t);
-            double d0 = 0.0, d1 = 0.0;
+            for (int t = 0; t < 10; ++t) v[t] = ld2(vb + 8 * t);
+            double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
+            for (int t = 0; t < 10; t += 2) {
                 d0 = fma(v[t].x, b[t][0], d0);
                 d1 = fma(v[t].y, b[t][1], d1);
+                d2 = fma(v[t + 1].x, b[t + 1][0], d2);
+                d3 = fma(v[t + 1].y, b[t + 1][1], d3);
             }
-            const double dot = grp8_sum(d0 + d1);
-            if (e > j) {
-                const double coef = dot * tj;
+            const double coef = quad_sum((d0 + d1) + (d2 + d3)) * tj;
 #pragma unroll
-                for (int t = 0; t < 5; ++t) {
-                    b[t][0] = fma(-coef, v[t].x, b[t][0]);
-                    b[t][1] = fma(-coef, v[t].y, b[t][1]);
-                }
-                if (e == j + 1) prepare(j + 1);
+            for (int t = 0; t < 10; ++t) {
+                b[t][0] = fma(-coef, v[t].x, b[t][0]);
+                b[t][1] = fma(-coef, v[t].y, b[t][1]);
             }
-            else if (kc == 0) G[e * kGS + j] = dot; // v_e has zeros where its R entries sit in b: v_j is zero above row j > e
+            if (e == j + 1) prepare(j + 1);
+        }
+        else if (jl >= 0) {
+            const double* vh = vbj + 40 * jh;
+            double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 20; q += 2) {
+                const double2v va = ld2(vh + 2 * q), vb2 = ld2(vh + 2 * q + 2);
+                d0 = fma(va.x, jrow[2 * q], d0);
+                d1 = fma(va.y, jrow[2 * q + 1], d1);
+                d2 = fma(vb2.x, jrow[2 * q + 2], d2);
+                d3 = fma(vb2.y, jrow[2 * q + 3], d3);
+            }
+            double dot = (d0 + d1) + (d2 + d3);
+            dot += dpp_get<0xB1>(dot); // the other half of the row
+            const double coef = dot * tj;
+#pragma unroll
+            for (int q = 0; q < 20; ++q) {
+                const double2v va = ld2(vh + 2 * q);
+                jrow[2 * q] = fma(-coef, va.x, jrow[2 * q]);
+                jrow[2 * q + 1] = fma(-coef, va.y, jrow[2 * q + 1]);
+            }
         }
     }
-    // V into B (zeros in place of R), R packed, 1/R(j,j)
+    // R packed, 1/R(j,j); J rows back to LDS
     if (colv) {
         double* Rc = c.R + roff(e);
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
+        for (int t = 0; t < 10; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int row = 2 * kc + 16 * t + i;
-                if (row < e) {
-                    Rc[row] = b[t][i];
-                    Bm[row * ldb + e] = 0.0;
-                }
-                else if (row < n) Bm[row * ldb + e] = b[t][i];
+                const int row = 2 * kc + 8 * t + i;
+                if (row < e) Rc[row] = b[t][i];
             }
         if (kc == 0) {
             Rc[e] = my_alpha;
             c.rdinv[e] = 1.0 / my_alpha;
         }
     }
+    if (jl >= 0) {
+        double* Jr = c.J + jr * ldj + 40 * jh;
+#pragma unroll
+        for (int q = 0; q < 40; ++q)
+            if (40 * jh + q < n) Jr[q] = jrow[q];
+    }
     return true;
 }
-
 
 // y = R'^-1 rhs (forward), u = R^-1 y (backward) on one wave: lane = index.  Column `lane` and row `lane` of the packed R
 // sit in registers (clamped loads, all in flight at once); lanes past m carry zeros, so the loops run to the
@@ -1039,26 +1079,6 @@ __device__ __forceinline__ void solve_yu(Ctx& c, double* rhs)
     if (live) {
         c.u[lane] = uv;
         c.A[lane] = -lane - 1;
-    }
-}
-
-// One row of X = W T, i.e. X T^-1 = W with T^-1 = striu(G) + diag(1/tau): right-looking, so that only one FMA per column
-// sits on the dependent chain.  Columns m..MM-1 of the register row are scratch (G is zero there, nothing is stored).
-template <int MM>
-__device__ __forceinline__ void solve_wt(Ctx& c, double* Wr, const double* tau)
-{
-    const int m = c.neq;
-    double wrow[MM];
-#pragma unroll
-    for (int j = 0; j < MM; ++j) wrow[j] = Wr[min(j, m - 1)];
-#pragma unroll
-    for (int j = 0; j < MM; ++j) {
-        if (j < m) {
-            const double xj = wrow[j] * tau[j];
-            Wr[j] = xj;
-#pragma unroll
-            for (int l = j + 1; l < MM; ++l) wrow[l] = fma(-xj, c.part[j * kGS + l], wrow[l]);
-        }
     }
 }
 
@@ -1125,106 +1145,20 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
                 }
         }
     }
-    for (int e2 = tid; e2 < kGS * kGS; e2 += kThreads) c.part[e2] = 0.0; // G = striu(V'V), zero-padded for the solves
     bsync();
     STAMP(5)
-    // ---- Householder QR of B with the columns in registers, one barrier per column; G = striu(V'V) and W = J0 V are
-    //      formed in its shadow (qr_resident) -- W = J0 V follows.  Compact WY without forming T: Q = I - V T V' with
-    //      T^-1 = striu(V'V) + diag(1/tau)  (T^-1 + T^-T = V'V), so W T is the solution X of X T^-1 = W.
-    if (!qr_resident(c, Bm, tau, c.s, c.s + 160, c.part)) return false; // redundant equalities
+    // ---- Householder QR of B (columns in registers, one barrier per column) and J <- J Q in its shadow (rows in registers)
+    if (!qr_resident(c, Bm, c.s, c.s + 160)) return false; // redundant equalities
     bsync();
     STAMP(6)
-    const double* Vm = Bm;
-    // ---- W = J0 V: item (pair of rows, 4 columns), wave-uniform k range as for B
-    {
-        const int ncg = (m + 3) >> 2;
-        const int rp = tid / ncg, cg = tid - rp * ncg;
-        const int r0 = 2 * rp, r1 = min(r0 + 1, n - 1);
-        const bool act = r0 < n;
-        int kmin = act ? r0 : n, kmax = act ? blk_end(r1, nv) : 0;
-        kmin = wave_min_int(kmin);
-        kmax = wave_max_int(kmax);
-        double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-        const int r0s = act ? r0 : 0, r1s = act ? r1 : 0;
-        tile2x4(c.J, r0s * ldj, r1s * ldj, 1, Vm + 4 * cg, ldb, kmin, kmax, acc);
-        if (act) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (4 * cg + q < m) {
-                    Nm[r0 * ldb + 4 * cg + q] = acc[0][q];
-                    if (r0 + 1 < n) Nm[(r0 + 1) * ldb + 4 * cg + q] = acc[1][q];
-                }
-        }
-    }
-    bsync();
-    STAMP(18)
-    // ---- W <- W T by forward substitution with T^-1: thread = row (n <= 80: waves 0 and 1); meanwhile the last wave
-    //      solves y = R'^-1 rhs and u = R^-1 y (lane = index, its column and row of R in registers, pivots by readlane)
-    if (tid < n) {
-        double* Wr = Nm + tid * ldb;
-        if (m <= 12) solve_wt<12>(c, Wr, tau);
-        else if (m <= 20) solve_wt<20>(c, Wr, tau);
-        else solve_wt<24>(c, Wr, tau);
-    }
-    else if (c.wave == 3) {
+    // ---- y = R'^-1 rhs, u = R^-1 y on one wave
+    if (c.wave == 0) {
         if (m <= 12) solve_yu<12>(c, rhs);
         else if (m <= 20) solve_yu<20>(c, rhs);
         else solve_yu<24>(c, rhs);
     }
     bsync();
     STAMP(19)
-    // ---- J <- J - (W T) V': 16 x 16 thread grid, thread (ta, te) owns rows ta + 16a, columns te + 16b (n <= 80);
-    //      the operands of the next equality are in flight while this one multiplies.  Rows and columns past n are
-    //      clamped (their results are dropped): nothing in the unrolled code sits behind a per-lane branch.
-    {
-        const int ta = tid >> 4, te = tid & 15;
-        const double* wp[5];
-        const double* vp[5];
-        double* jp[5];
-        int cq[5];
-#pragma unroll
-        for (int a = 0; a < 5; ++a) {
-            wp[a] = Nm + min(ta + 16 * a, n - 1) * ldb;
-            vp[a] = Vm + min(te + 16 * a, n - 1) * ldb;
-            jp[a] = c.J + min(ta + 16 * a, n - 1) * ldj;
-            cq[a] = min(te + 16 * a, n - 1);
-        }
-        double acc[5][5];
-#pragma unroll
-        for (int a = 0; a < 5; ++a)
-#pragma unroll
-            for (int b = 0; b < 5; ++b) acc[a][b] = jp[a][cq[b]];
-        auto ld = [&](int e, double (&wk)[5], double (&vc)[5]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int a = 0; a < 5; ++a) {
-                wk[a] = wp[a][e];
-                vc[a] = vp[a][e];
-            }
-        };
-        auto mac = [&](const double (&wk)[5], const double (&vc)[5]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int a = 0; a < 5; ++a)
-#pragma unroll
-                for (int b = 0; b < 5; ++b) acc[a][b] = fma(-wk[a], vc[b], acc[a][b]);
-        };
-        double w0[5], v0[5], w1[5], v1[5];
-        ld(0, w0, v0);
-        int e = 0;
-        for (; e + 2 <= m; e += 2) {
-            ld(e + 1, w1, v1);
-            mac(w0, v0);
-            ld(min(e + 2, m - 1), w0, v0);
-            mac(w1, v1);
-        }
-        if (e < m) mac(w0, v0);
-#pragma unroll
-        for (int a = 0; a < 5; ++a)
-#pragma unroll
-            for (int b = 0; b < 5; ++b)
-                if (ta + 16 * a < n && te + 16 * b < n) jp[a][cq[b]] = acc[a][b];
-    }
-    bsync();
-    STAMP(20)
     // ---- x = x0 + J[:, :m] y ; f += y'y / 2
     {
         double yy = 0.0;

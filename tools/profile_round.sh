@@ -1,0 +1,23 @@
+#!/bin/bash
+# One measurement pass on the GPU box: bench line (with CPU baseline), rocprofv3 kernel-trace stats, the two PMC passes
+# (FETCH_SIZE / WRITE_SIZE separately), in-kernel phase shares.  Usage: tools/profile_round.sh <tag>
+set -u
+TAG=${1:-vX}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd $ROOT
+python3 bench.py --steps 20 --warmup 3 --sweep $OUT/sweep.json > $OUT/bench.json 2> $OUT/bench.err
+python3 tools/phase_profile.py --out $OUT/phase.json > $OUT/phase.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-compare > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/write.log 2>&1
+cd $OUT
+find . -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+find ./fetch -name "*counter_collection.csv" -exec cp {} $OUT/pmc_fetch_size.csv \;
+find ./write -name "*counter_collection.csv" -exec cp {} $OUT/pmc_write_size.csv \;
+rm -rf trace fetch write
+ls -la $OUT
+tail -1 $OUT/bench.json | cut -c1-300
+head -3 $OUT/kernel_stats.csv
