@@ -351,6 +351,36 @@ __device__ __forceinline__ void tile2x4(const double* base_a, int oa0, int oa1, 
     if (kk < k1) mac(a0, b0);
 }
 
+// sum_{k in [k0,k1)} a[k sa] b[k sb] with eight products' operands in flight before the first FMA (one wave per SIMD:
+// nothing else hides the LDS latency; a two-term loop body costs a full round trip per two terms)
+__device__ __forceinline__ double dot8(const double* a, int sa, const double* b, int sb, int k0, int k1)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        double x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = a[(k + u) * sa];
+            y[u] = b[(k + u) * sb];
+        }
+        s0 = fma(x[0], y[0], s0); s1 = fma(x[1], y[1], s1); s2 = fma(x[2], y[2], s2); s3 = fma(x[3], y[3], s3);
+        s0 = fma(x[4], y[4], s0); s1 = fma(x[5], y[5], s1); s2 = fma(x[6], y[6], s2); s3 = fma(x[7], y[7], s3);
+    }
+    if (k < k1) { // tail: clamp the index, zero the weight
+        double x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = min(k + u, k1 - 1);
+            x[u] = a[kk * sa];
+            y[u] = (k + u < k1) ? b[kk * sb] : 0.0;
+        }
+        s0 = fma(x[0], y[0], s0); s1 = fma(x[1], y[1], s1); s2 = fma(x[2], y[2], s2); s3 = fma(x[3], y[3], s3);
+        s0 = fma(x[4], y[4], s0); s1 = fma(x[5], y[5], s1); s2 = fma(x[6], y[6], s2); s3 = fma(x[7], y[7], s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
 // row sum over the 16 lanes of a DPP row (every lane of the row gets the total)
 __device__ __forceinline__ double row16_sum(double v)
 {
@@ -788,15 +818,37 @@ __device__ __forceinline__ void act_rows(Ctx& c, double* out, double t)
     const int rr = c.tid >> 2, q4 = c.tid & 3;
     const int row = nu + min(rr, na - 1);
     const double* Mr = c.M + row * c.ldm;
-    double a0 = 0.0, a1 = 0.0;
-    int j = q4;
-    for (; j + 4 < nv; j += 8) {
-        a0 = fma(Mr[j], fma(t, c.z[j], c.x[j]), a0);
-        a1 = fma(Mr[j + 4], fma(t, c.z[j + 4], c.x[j + 4]), a1);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    // the lane's terms j = q4 + 4 i, four in flight; past the end: index clamped, weight zero
+    for (int j = q4; j < nv; j += 16) {
+        double mv[4], zv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = min(j + 4 * u, nv - 1);
+            mv[u] = (j + 4 * u < nv) ? Mr[jj] : 0.0;
+            zv[u] = c.z[jj];
+            xv[u] = c.x[jj];
+        }
+        a0 = fma(mv[0], fma(t, zv[0], xv[0]), a0);
+        a1 = fma(mv[1], fma(t, zv[1], xv[1]), a1);
+        a2 = fma(mv[2], fma(t, zv[2], xv[2]), a2);
+        a3 = fma(mv[3], fma(t, zv[3], xv[3]), a3);
     }
-    if (j < nv) a0 = fma(Mr[j], fma(t, c.z[j], c.x[j]), a0);
-    for (int m = q4; m < k; m += 4) a1 = fma(-c.Jc[m * c.ldc + row], fma(t, c.z[nv + m], c.x[nv + m]), a1);
-    double acc = a0 + a1;
+    for (int m = q4; m < k; m += 16) {
+        double jv[4], zv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int mm = min(m + 4 * u, k - 1);
+            jv[u] = (m + 4 * u < k) ? c.Jc[mm * c.ldc + row] : 0.0;
+            zv[u] = c.z[nv + mm];
+            xv[u] = c.x[nv + mm];
+        }
+        a0 = fma(-jv[0], fma(t, zv[0], xv[0]), a0);
+        a1 = fma(-jv[1], fma(t, zv[1], xv[1]), a1);
+        a2 = fma(-jv[2], fma(t, zv[2], xv[2]), a2);
+        a3 = fma(-jv[3], fma(t, zv[3], xv[3]), a3);
+    }
+    double acc = (a0 + a1) + (a2 + a3);
     acc += dpp_get<0xB1>(acc);
     acc += dpp_get<0x4E>(acc);
     if (q4 == 0 && rr < na) out[rr] = acc;
@@ -927,20 +979,26 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, const double* Bm, double* vb
         }
     }
     double my_alpha = 1.0;
-    // reflector of column jn from the registers of its 4 lanes (call under e == jn)
-    auto prepare = [&](int jn) __attribute__((always_inline)) {
-        double sq0 = 0.0, sq1 = 0.0, x0 = 0.0;
+    // reflector of column jn from the registers of its 4 lanes (call under e == jn).  T0 = jn >> 3 is a compile-time
+    // constant per instance: row pairs below T0 lie above the diagonal, pairs past it below -- only pair T0 needs masks
+    auto prepare_t = [&](auto T0c, int jn) __attribute__((always_inline)) {
+        constexpr int T0 = decltype(T0c)::value;
+        const int row0 = 2 * kc + 8 * T0;
+        const double e0 = (row0 >= jn) ? b[T0][0] : 0.0, e1 = (row0 + 1 >= jn) ? b[T0][1] : 0.0;
+        double sq0 = e0 * e0, sq1 = e1 * e1, sq2 = 0.0, sq3 = 0.0;
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = 2 * kc + 8 * t + i;
-                const double v = (t >= 4 || row >= jn) ? b[t][i] : 0.0; // jn < 32: rows of t >= 4 are always below
-                if (i == 0) sq0 = fma(v, v, sq0);
-                else sq1 = fma(v, v, sq1);
-                if (t < 4) x0 += (row == jn) ? v : 0.0;
-            }
-        const double nrm = quad_sum(sq0 + sq1);
+        for (int t = T0 + 1; t + 1 < 10; t += 2) {
+            sq0 = fma(b[t][0], b[t][0], sq0);
+            sq1 = fma(b[t][1], b[t][1], sq1);
+            sq2 = fma(b[t + 1][0], b[t + 1][0], sq2);
+            sq3 = fma(b[t + 1][1], b[t + 1][1], sq3);
+        }
+        if constexpr (((10 - (T0 + 1)) & 1) != 0) {
+            sq0 = fma(b[9][0], b[9][0], sq0);
+            sq1 = fma(b[9][1], b[9][1], sq1);
+        }
+        double x0 = (row0 == jn) ? b[T0][0] : ((row0 + 1 == jn) ? b[T0][1] : 0.0);
+        const double nrm = quad_sum((sq0 + sq1) + (sq2 + sq3));
         x0 = quad_sum(x0);
         const double inx = rsqrt(nrm);
         const double nx = (nrm > 0.0) ? nrm * inx : 0.0; // exactly dependent column: alpha = 0 -> reported as redundant
@@ -948,26 +1006,37 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, const double* Bm, double* vb
         const double v0 = x0 - alpha;
         const double tj = fast_rcp(fma(nx, fabs(x0), nrm)); // 2 / v'v
         my_alpha = alpha;
-        double* vb = vbuf + (jn & 1) * 80;
+        double* vb = vbuf + (jn & 1) * 80 + 2 * kc;
+        if (row0 == jn) b[T0][0] = v0;
+        if (row0 + 1 == jn) b[T0][1] = v0;
 #pragma unroll
         for (int t = 0; t < 10; ++t) {
             double2v o;
-            const int row = 2 * kc + 8 * t;
-            if (t < 4) {
-                if (row == jn) b[t][0] = v0;
-                if (row + 1 == jn) b[t][1] = v0;
-                o.x = (row >= jn) ? b[t][0] : 0.0;
-                o.y = (row + 1 >= jn) ? b[t][1] : 0.0;
+            if (t < T0) {
+                o.x = 0.0;
+                o.y = 0.0;
+            }
+            else if (t == T0) {
+                o.x = (row0 >= jn) ? b[T0][0] : 0.0;
+                o.y = (row0 + 1 >= jn) ? b[T0][1] : 0.0;
             }
             else {
                 o.x = b[t][0];
                 o.y = b[t][1];
             }
-            *reinterpret_cast<double2v*>(__builtin_assume_aligned(vb + row, 16)) = o;
+            *reinterpret_cast<double2v*>(__builtin_assume_aligned(vb + 8 * t, 16)) = o;
         }
         if (kc == 0) {
             sc[(jn & 1) * 2] = tj;
             sc[(jn & 1) * 2 + 1] = alpha;
+        }
+    };
+    auto prepare = [&](int jn) __attribute__((always_inline)) {
+        switch (jn >> 3) { // jn < 32
+        case 0: prepare_t(std::integral_constant<int, 0>{}, jn); break;
+        case 1: prepare_t(std::integral_constant<int, 1>{}, jn); break;
+        case 2: prepare_t(std::integral_constant<int, 2>{}, jn); break;
+        default: prepare_t(std::integral_constant<int, 3>{}, jn); break;
         }
     };
     if (e == 0) prepare(0);
@@ -1649,15 +1718,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         {
             const int kb0 = blk_begin(ic, nv), len = ic + 1 - kb0, hl = (len + 1) >> 1;
             const int ka = kb0 + hf * hl, kb = hf ? ic + 1 : kb0 + hl;
-            const double* Jc0 = c.J + ic;
-            double a0 = 0.0, a1 = 0.0;
-            int kk = ka;
-            for (; kk + 2 <= kb; kk += 2) {
-                a0 = fma(Jc0[kk * ldj], c.g[kk], a0);
-                a1 = fma(Jc0[(kk + 1) * ldj], c.g[kk + 1], a1);
-            }
-            if (kk < kb) a0 = fma(Jc0[kk * ldj], c.g[kk], a0);
-            double dv = a0 + a1;
+            double dv = dot8(c.J + ic, ldj, c.g, 1, ka, kb);
             dv += dpp_get<0xB1>(dv);
             if (hf == 0 && idx < n) c.d[idx] = dv;
         }
@@ -1671,15 +1732,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         {
             const int ce = blk_end(ic, nv), len = ce - ic, hl = (len + 1) >> 1;
             const int ca = ic + hf * hl, cb = hf ? ce : ic + hl;
-            const double* Jr = c.J + ic * ldj;
-            double a0 = 0.0, a1 = 0.0;
-            int cc = ca;
-            for (; cc + 2 <= cb; cc += 2) {
-                a0 = fma(Jr[cc], c.d[cc], a0);
-                a1 = fma(Jr[cc + 1], c.d[cc + 1], a1);
-            }
-            if (cc < cb) a0 = fma(Jr[cc], c.d[cc], a0);
-            double zv = a0 + a1;
+            double zv = dot8(c.J + ic * ldj, 1, c.d, 1, ca, cb);
             zv += dpp_get<0xB1>(zv);
             if (hf == 0 && idx < n) {
                 c.z[idx] = zv;
@@ -1883,20 +1936,10 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                     const int ka = hf ? mid : 0, kb = hf ? n : mid;
                     const double* Mr = c.M + row * ldm;
                     const double* Jcol = c.J + ic;
-                    double a0 = 0.0, a1 = 0.0;
-                    int kk = ka;
-                    const int kv = min(kb, nv);
-                    for (; kk + 2 <= kv; kk += 2) {
-                        a0 = fma(Mr[kk], Jcol[kk * ldj], a0);
-                        a1 = fma(Mr[kk + 1], Jcol[(kk + 1) * ldj], a1);
-                    }
-                    if (kk < kv) {
-                        a0 = fma(Mr[kk], Jcol[kk * ldj], a0);
-                        ++kk;
-                    }
-                    kk = max(kk, nv);
-                    for (; kk < kb; ++kk) a1 = fma(-c.Jc[(kk - nv) * ldc + row], Jcol[kk * ldj], a1);
-                    double acc = a0 + a1;
+                    const int kv = min(kb, nv), kf = max(ka, nv);
+                    double acc = 0.0;
+                    if (ka < kv) acc = dot8(Mr, 1, Jcol, ldj, ka, kv);
+                    if (kf < kb) acc -= dot8(c.Jc + row, ldc, Jcol + nv * ldj, ldj, kf - nv, kb - nv);
                     acc += dpp_get<0xB1>(acc);
                     if (hf == 0 && idx < n) c.d[idx] = sg * acc;
                 }
@@ -1911,14 +1954,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                     const int span = n - iq, hlen = (lpr == 2) ? ((span + 1) >> 1) : span;
                     const int ca = iq + hf * hlen, cb = min(n, ca + hlen);
                     const double* Jr = c.J + ir * ldj;
-                    double a0 = 0.0, a1 = 0.0;
-                    int cc = ca;
-                    for (; cc + 2 <= cb; cc += 2) {
-                        a0 = fma(Jr[cc], c.d[cc], a0);
-                        a1 = fma(Jr[cc + 1], c.d[cc + 1], a1);
-                    }
-                    if (cc < cb) a0 = fma(Jr[cc], c.d[cc], a0);
-                    double zv = a0 + a1;
+                    double zv = dot8(Jr, 1, c.d, 1, ca, cb);
                     if (lpr == 2) zv += dpp_get<0xB1>(zv);
                     double zz = 0.0, znp = 0.0, dn2 = 0.0;
                     if (hf == 0 && idx < n) {
