@@ -819,34 +819,40 @@ __device__ __forceinline__ void act_rows(Ctx& c, double* out, double t)
     const int row = nu + min(rr, na - 1);
     const double* Mr = c.M + row * c.ldm;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    // the lane's terms j = q4 + 4 i, four in flight; past the end: index clamped, weight zero
-    for (int j = q4; j < nv; j += 16) {
-        double mv[4], zv[4], xv[4];
+    // the lane's terms j = q4 + 4 i, eight in flight; past the end: index clamped, weight zero
+    for (int j = q4; j < nv; j += 32) {
+        double mv[8], zv[8], xv[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int jj = min(j + 4 * u, nv - 1);
             mv[u] = (j + 4 * u < nv) ? Mr[jj] : 0.0;
             zv[u] = c.z[jj];
             xv[u] = c.x[jj];
         }
-        a0 = fma(mv[0], fma(t, zv[0], xv[0]), a0);
-        a1 = fma(mv[1], fma(t, zv[1], xv[1]), a1);
-        a2 = fma(mv[2], fma(t, zv[2], xv[2]), a2);
-        a3 = fma(mv[3], fma(t, zv[3], xv[3]), a3);
-    }
-    for (int m = q4; m < k; m += 16) {
-        double jv[4], zv[4], xv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; u += 4) {
+            a0 = fma(mv[u], fma(t, zv[u], xv[u]), a0);
+            a1 = fma(mv[u + 1], fma(t, zv[u + 1], xv[u + 1]), a1);
+            a2 = fma(mv[u + 2], fma(t, zv[u + 2], xv[u + 2]), a2);
+            a3 = fma(mv[u + 3], fma(t, zv[u + 3], xv[u + 3]), a3);
+        }
+    }
+    for (int m = q4; m < k; m += 32) {
+        double jv[8], zv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
             const int mm = min(m + 4 * u, k - 1);
             jv[u] = (m + 4 * u < k) ? c.Jc[mm * c.ldc + row] : 0.0;
             zv[u] = c.z[nv + mm];
             xv[u] = c.x[nv + mm];
         }
-        a0 = fma(-jv[0], fma(t, zv[0], xv[0]), a0);
-        a1 = fma(-jv[1], fma(t, zv[1], xv[1]), a1);
-        a2 = fma(-jv[2], fma(t, zv[2], xv[2]), a2);
-        a3 = fma(-jv[3], fma(t, zv[3], xv[3]), a3);
+#pragma unroll
+        for (int u = 0; u < 8; u += 4) {
+            a0 = fma(-jv[u], fma(t, zv[u], xv[u]), a0);
+            a1 = fma(-jv[u + 1], fma(t, zv[u + 1], xv[u + 1]), a1);
+            a2 = fma(-jv[u + 2], fma(t, zv[u + 2], xv[u + 2]), a2);
+            a3 = fma(-jv[u + 3], fma(t, zv[u + 3], xv[u + 3]), a3);
+        }
     }
     double acc = (a0 + a1) + (a2 + a3);
     acc += dpp_get<0xB1>(acc);
@@ -2052,13 +2058,15 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                                 Jk[cc] = fma(-wk, v0, Jk[cc]);
                                 ++cc;
                             }
-                            for (; cc + 4 <= cb; cc += 4) {
-                                const double d0 = c.d[cc], d1 = c.d[cc + 1], d2 = c.d[cc + 2], d3 = c.d[cc + 3];
-                                const double j0 = Jk[cc], j1 = Jk[cc + 1], j2 = Jk[cc + 2], j3 = Jk[cc + 3];
-                                Jk[cc] = fma(-wk, d0, j0);
-                                Jk[cc + 1] = fma(-wk, d1, j1);
-                                Jk[cc + 2] = fma(-wk, d2, j2);
-                                Jk[cc + 3] = fma(-wk, d3, j3);
+                            for (; cc + 8 <= cb; cc += 8) {
+                                double dd[8], jj[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    dd[u] = c.d[cc + u];
+                                    jj[u] = Jk[cc + u];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) Jk[cc + u] = fma(-wk, dd[u], jj[u]);
                             }
                             for (; cc < cb; ++cc) Jk[cc] = fma(-wk, c.d[cc], Jk[cc]);
                         }
