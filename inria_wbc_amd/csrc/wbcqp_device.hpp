@@ -1119,22 +1119,19 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, const double* Bm, double* vb
     return true;
 }
 
-// y = R'^-1 rhs (forward), u = R^-1 y (backward) on one wave: lane = index.  Column `lane` and row `lane` of the packed R
-// sit in registers (clamped loads, all in flight at once); lanes past m carry zeros, so the loops run to the
-// compile-time bound MM >= m without guards.
+// y = R'^-1 rhs (forward substitution) on one wave: lane = index.  Column `lane` of the packed R sits in registers
+// (clamped loads, all in flight at once); lanes past m carry zeros, so the loop runs to the compile-time bound MM >= m
+// without guards.  The multipliers u = R^-1 y of the equality rows are not formed: no later decision reads them (the
+// step-length test runs over the inequality rows only) and they are not an output.
 template <int MM>
-__device__ __forceinline__ void solve_yu(Ctx& c, double* rhs)
+__device__ __forceinline__ void solve_y(Ctx& c, double* rhs)
 {
     const int m = c.neq, lane = c.lane;
     const bool live = lane < m;
     const int ls = live ? lane : 0;
-    double rc[MM], rr[MM];
+    double rc[MM];
 #pragma unroll
-    for (int i = 0; i < MM; ++i) {
-        rc[i] = c.R[roff(ls) + min(i, ls)];            // R(i, lane), used for i < lane
-        const int jj = min(max(i, ls), m - 1);
-        rr[i] = c.R[roff(jj) + ls];                    // R(lane, i), used for i > lane
-    }
+    for (int i = 0; i < MM; ++i) rc[i] = c.R[roff(ls) + min(i, ls)]; // R(i, lane), used for i < lane
     const double rinv = live ? c.rdinv[ls] : 0.0;
     double yv = live ? rhs[ls] : 0.0;
 #pragma unroll
@@ -1143,16 +1140,9 @@ __device__ __forceinline__ void solve_yu(Ctx& c, double* rhs)
         if (lane == i) yv = yi;
         if (lane > i) yv = fma(-yi, rc[i], yv);
     }
-    if (live) rhs[lane] = yv; // y
-    double uv = yv;
-#pragma unroll
-    for (int i = MM - 1; i >= 0; --i) {
-        const double ui = bcast_lane(uv * rinv, i);
-        if (lane == i) uv = ui;
-        if (lane < i) uv = fma(-ui, rr[i], uv);
-    }
     if (live) {
-        c.u[lane] = uv;
+        rhs[lane] = yv; // y
+        c.u[lane] = 0.0;
         c.A[lane] = -lane - 1;
     }
 }
@@ -1176,22 +1166,37 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     double* tau = Tm + m * (m + 1);
     double* rhs = tau + 2 * m;  // later y
 
-    // ---- N = CE': base dynamics rows [M_u | -J_u'], then the contact motion rows [A_c | 0]
-    for (int e2 = tid; e2 < n * m; e2 += kThreads) {
-        const int kk = e2 / m, e = e2 - kk * m;
-        double v;
-        if (e < nu) v = (kk < nv) ? c.M[kk * c.ldm + e] : -c.Jc[(kk - nv) * c.ldc + e];
-        else v = (kk < nv) ? c.Ac[(e - nu) * nv + kk] : 0.0;
-        Nm[kk * ldb + e] = v;
+    // ---- N = CE': base dynamics rows [M_u | -J_u'], then the contact motion rows [A_c | 0].  Thread = (equality e,
+    //      every 8th row): no index division, the ten loads of a thread are in flight together (m <= 22, n <= 80)
+    {
+        const int e = tid & 31, k8 = tid >> 5;
+        if (e < m) {
+            double v[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int kk = min(k8 + 8 * i, n - 1);
+                if (e < nu) v[i] = (kk < nv) ? c.M[kk * c.ldm + e] : -c.Jc[(kk - nv) * c.ldc + e];
+                else v[i] = (kk < nv) ? c.Ac[(e - nu) * nv + kk] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+                if (k8 + 8 * i < n) Nm[(k8 + 8 * i) * ldb + e] = v[i];
+        }
     }
     bsync();
-    // ---- rhs_e = -(N(:,e)'x0 + ce0_e): 16 lanes (one DPP row) per equality
-    for (int e0 = 0; e0 < m; e0 += 16) {
-        const int e = e0 + (tid >> 4), kc = tid & 15;
-        double acc = 0.0;
-        if (e < m)
-            for (int kk = kc; kk < n; kk += 16) acc = fma(Nm[kk * ldb + e], c.x[kk], acc);
-        acc = row16_sum(acc);
+    // ---- rhs_e = -(N(:,e)'x0 + ce0_e): 8 lanes per equality, ten terms each in flight
+    {
+        const int e = tid >> 3, kc = tid & 7;
+        const int es = min(e, m - 1);
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 10; i += 2) {
+            const int k0 = min(kc + 8 * i, n - 1), k1 = min(kc + 8 * i + 8, n - 1);
+            const double x0 = (kc + 8 * i < n) ? c.x[k0] : 0.0, x1 = (kc + 8 * i + 8 < n) ? c.x[k1] : 0.0;
+            a0 = fma(Nm[k0 * ldb + es], x0, a0);
+            a1 = fma(Nm[k1 * ldb + es], x1, a1);
+        }
+        const double acc = grp8_sum(a0 + a1);
         if (e < m && kc == 0) {
             const double ce0 = (e < nu) ? c.h[e] : -c.bc[e - nu];
             rhs[e] = -(acc + ce0);
@@ -1226,11 +1231,11 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     if (!qr_resident(c, Bm, c.s, c.s + 160)) return false; // redundant equalities
     bsync();
     STAMP(6)
-    // ---- y = R'^-1 rhs, u = R^-1 y on one wave
+    // ---- y = R'^-1 rhs on one wave
     if (c.wave == 0) {
-        if (m <= 12) solve_yu<12>(c, rhs);
-        else if (m <= 20) solve_yu<20>(c, rhs);
-        else solve_yu<24>(c, rhs);
+        if (m <= 12) solve_y<12>(c, rhs);
+        else if (m <= 20) solve_y<20>(c, rhs);
+        else solve_y<24>(c, rhs);
     }
     bsync();
     STAMP(19)
