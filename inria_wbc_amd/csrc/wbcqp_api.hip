@@ -129,7 +129,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; }; // keep 16-byte alignment
     D.o_J = take(n * D.ldj);
     int rsize = n * (n + 3) / 2 + 2;
-    if (D.n_dense * nv + 64 > rsize) rsize = D.n_dense * nv + 64;
+    if (D.n_dense * 66 + 8 > rsize) rsize = D.n_dense * 66 + 8; // staged task rows: 64 columns (transposed groups) + (w, b) pairs
     if (D.neq > 0 && 256 + (n + 17) * D.ldb + 8 > rsize) rsize = 256 + (n + 17) * D.ldb + 8; // B of the blocked equality phase + 16 zero rows // + 64: the 4x4 H tiles may read past the last staged row
     D.o_R = take(rsize);
     D.o_M = take(nv * D.ldm);
@@ -384,6 +384,12 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
             for (int j = 0; j <= i; ++j)
                 mp[(size_t)i * (i + 1) / 2 + j] = (unsigned)(i * D.ldm + j) | ((unsigned)(j * D.ldm + i) << 16);
         UP(mpack, mp.data(), D.nv * (D.nv + 1) / 2);
+    }
+    {
+        std::vector<unsigned> ap((size_t)D.n_dense * D.nv + 1, 0u);
+        for (int r = 0; r < D.n_dense; ++r)
+            for (int col = 0; col < D.nv; ++col) ap[(size_t)r * D.nv + col] = (unsigned)(r * 64 + (col & 15) * 4 + (col >> 4));
+        UP(apack, ap.data(), D.n_dense * D.nv);
     }
 #undef UP
     s.host = D;

@@ -69,6 +69,7 @@ struct DevStruct {
     const double *fric_mat, *fric_lb, *fric_ub;
     const int* rowmeta;      // [nin2] packed descriptor of every one-sided inequality row (see row_meta_*)
     const unsigned* mpack;   // [nv(nv+1)/2] packed-M element e=(i,j) -> LDS offsets (i ldm + j) | (j ldm + i) << 16
+    const unsigned* apack;   // [n_dense nv] task-row element (r, col) -> offset r 64 + (col & 15) 4 + (col >> 4) in the staged rows
     // LDS layout: leading dimensions and element offsets (in doubles)
     int ldj, ldm, ldc, ldb;
     int o_J, o_R, o_M, o_Jc, o_Ac, o_vec, o_eqw, o_eqt;
@@ -315,40 +316,62 @@ __device__ __forceinline__ double2v ld2(const double* p) { return *reinterpret_c
 __device__ __forceinline__ int wave_min_int(int v) { return -wave_max_int(-v); }
 
 // acc[2][4] += sum_k a_i(k) * b(k, 0..3) over the wave-uniform range [k0, k1): element k of operand i is at
-// base_a[oa_i + k sa], the four b's at pb[k sb .. + 3] (16-byte aligned).  Operands of step k+1 are in flight while step k
-// multiplies (one wave per SIMD: nothing else hides the LDS latency).
+// base_a[oa_i + k sa], the four b's at pb[k sb .. + 3] (16-byte aligned).  Four k-steps per trip; the operands of the
+// next trip are in flight while this one multiplies (one wave per SIMD: nothing else hides the LDS latency), and every
+// operand stream has its own running pointer so that a step costs no index arithmetic.  The prefetch of the last trip
+// reads up to four steps past k1 (never used; the rows after any operand here are still inside the LDS allocation).
 __device__ __forceinline__ void tile2x4(const double* base_a, int oa0, int oa1, int sa, const double* pb, int sb, int k0, int k1,
                                         double (&acc)[2][4])
 {
     if (k0 >= k1) return;
-    const double* pa0 = base_a + oa0;
-    const double* pa1 = base_a + opaque(oa1);
-    double a0[2], a1[2];
-    double2v b0[2], b1[2];
-    auto ld = [&](int kk, double (&a)[2], double2v (&b)[2]) __attribute__((always_inline)) {
-        a[0] = pa0[kk * sa];
-        a[1] = pa1[kk * sa];
-        b[0] = ld2(pb + kk * sb);
-        b[1] = ld2(pb + kk * sb + 2);
+    const double* pa0 = base_a + oa0 + k0 * sa;
+    const double* pa1 = base_a + opaque(oa1) + k0 * sa;
+    const double* pbk = pb + k0 * sb;
+    auto mac1 = [&](double x0, double x1, const double2v& u, const double2v& w) __attribute__((always_inline)) {
+        acc[0][0] = fma(x0, u.x, acc[0][0]); acc[0][1] = fma(x0, u.y, acc[0][1]);
+        acc[0][2] = fma(x0, w.x, acc[0][2]); acc[0][3] = fma(x0, w.y, acc[0][3]);
+        acc[1][0] = fma(x1, u.x, acc[1][0]); acc[1][1] = fma(x1, u.y, acc[1][1]);
+        acc[1][2] = fma(x1, w.x, acc[1][2]); acc[1][3] = fma(x1, w.y, acc[1][3]);
     };
-    auto mac = [&](const double (&a)[2], const double2v (&b)[2]) __attribute__((always_inline)) {
+    const int sa2 = 2 * sa, sa3 = 3 * sa, sb2 = 2 * sb, sb3 = 3 * sb;
+    auto ld4 = [&](double (&a)[4][2], double2v (&b)[4][2]) __attribute__((always_inline)) {
+        a[0][0] = pa0[0]; a[0][1] = pa1[0]; a[1][0] = pa0[sa]; a[1][1] = pa1[sa];
+        a[2][0] = pa0[sa2]; a[2][1] = pa1[sa2]; a[3][0] = pa0[sa3]; a[3][1] = pa1[sa3];
+        b[0][0] = ld2(pbk); b[0][1] = ld2(pbk + 2);
+        b[1][0] = ld2(pbk + sb); b[1][1] = ld2(pbk + sb + 2);
+        b[2][0] = ld2(pbk + sb2); b[2][1] = ld2(pbk + sb2 + 2);
+        b[3][0] = ld2(pbk + sb3); b[3][1] = ld2(pbk + sb3 + 2);
+        pa0 += 4 * sa;
+        pa1 += 4 * sa;
+        pbk += 4 * sb;
+    };
+    double a0[4][2], a1[4][2];
+    double2v b0[4][2], b1[4][2];
+    int left = k1 - k0;
+    ld4(a0, b0);
+    while (left >= 8) {
+        ld4(a1, b1);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            acc[i][0] = fma(a[i], b[0].x, acc[i][0]);
-            acc[i][1] = fma(a[i], b[0].y, acc[i][1]);
-            acc[i][2] = fma(a[i], b[1].x, acc[i][2]);
-            acc[i][3] = fma(a[i], b[1].y, acc[i][3]);
-        }
-    };
-    ld(k0, a0, b0);
-    int kk = k0;
-    for (; kk + 2 <= k1; kk += 2) {
-        ld(kk + 1, a1, b1);
-        mac(a0, b0);
-        ld(min(kk + 2, k1 - 1), a0, b0);
-        mac(a1, b1);
+        for (int q = 0; q < 4; ++q) mac1(a0[q][0], a0[q][1], b0[q][0], b0[q][1]);
+        ld4(a0, b0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mac1(a1[q][0], a1[q][1], b1[q][0], b1[q][1]);
+        left -= 8;
     }
-    if (kk < k1) mac(a0, b0);
+    if (left >= 4) {
+        ld4(a1, b1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mac1(a0[q][0], a0[q][1], b0[q][0], b0[q][1]);
+        left -= 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < left) mac1(a1[q][0], a1[q][1], b1[q][0], b1[q][1]);
+    }
+    else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < left) mac1(a0[q][0], a0[q][1], b0[q][0], b0[q][1]);
+    }
 }
 
 // sum_{k in [k0,k1)} a[k sa] b[k sb] with eight products' operands in flight before the first FMA (one wave per SIMD:
@@ -1171,12 +1194,25 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     {
         const int e = tid & 31, k8 = tid >> 5;
         if (e < m) {
+            // both candidate sources are read unconditionally (clamped addresses) and selected: a load behind a per-lane
+            // branch waits for its own round trip
             double v[10];
+            if (e < nu) {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int kk = min(k8 + 8 * i, n - 1);
-                if (e < nu) v[i] = (kk < nv) ? c.M[kk * c.ldm + e] : -c.Jc[(kk - nv) * c.ldc + e];
-                else v[i] = (kk < nv) ? c.Ac[(e - nu) * nv + kk] : 0.0;
+                for (int i = 0; i < 10; ++i) {
+                    const int kk = min(k8 + 8 * i, n - 1);
+                    const double mv = c.M[min(kk, nv - 1) * c.ldm + e];
+                    const double jv = (n > nv) ? c.Jc[max(kk - nv, 0) * c.ldc + e] : 0.0;
+                    v[i] = (kk < nv) ? mv : -jv;
+                }
+            }
+            else {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const int kk = min(k8 + 8 * i, n - 1);
+                    const double av = c.Ac[(e - nu) * nv + min(kk, nv - 1)];
+                    v[i] = (kk < nv) ? av : 0.0;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 10; ++i)
@@ -1184,6 +1220,7 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
         }
     }
     bsync();
+    STAMP(21)
     // ---- rhs_e = -(N(:,e)'x0 + ce0_e): 8 lanes per equality, ten terms each in flight
     {
         const int e = tid >> 3, kc = tid & 7;
@@ -1202,6 +1239,7 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
             rhs[e] = -(acc + ce0);
         }
     }
+    STAMP(22)
     // ---- B = J0' N: item (pair of columns of J0, 4 equalities).  The k range is the same for the whole wave (J0 is upper
     //      triangular and block diagonal: whatever lies outside a lane's own range is an exact zero), so every J0 read is
     //      a stride-1 row segment and every N read a broadcast.
@@ -1440,7 +1478,11 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         unsigned vP[RM];
         ld_regs<TI, RM>(pM, lenM, tid, vM);
         ld_regs<unsigned, RM>(S.mpack, lenM, tid, vP);
-        if (lenA > 0) ld_regs<TI, RA>(pA, lenA, tid, vA);
+        unsigned vQ[RA];
+        if (lenA > 0) {
+            ld_regs<TI, RA>(pA, lenA, tid, vA);
+            ld_regs<unsigned, RA>(S.apack, lenA, tid, vQ);
+        }
         if (nc > 0) {
             ld_regs<TI, RC>(pAc, lenAc, tid, vC);
             ld_regs<double, RT>(S.force_gen, lenT, tid, vT);
@@ -1488,7 +1530,16 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                 c.M[vP[u] >> 16] = v;
             }
         }
-        if (lenA > 0) st_regs<TI, RA>(As, lenA, tid, vA);
+        if (lenA > 0) {
+            // task rows land transposed inside each row: the four columns ta, ta + 16, .. a thread of the 16 x 16 grid
+            // needs are one 32-byte group (two 16-byte reads instead of four 8-byte ones).  Columns past nv are never
+            // written: what is read there only reaches positions that the identity padding below overwrites
+#pragma unroll
+            for (int u = 0; u < RA; ++u) {
+                const int e = tid + u * kThreads;
+                if (e < lenA) As[vQ[u]] = (double)vA[u];
+            }
+        }
         if (nc > 0) {
             st_regs<TI, RC>(c.Ac, lenAc, tid, vC);
             st_regs<double, RT>(c.eqw, lenT, tid, vT); // force generators staged in the (still unused) equality scratch
@@ -1515,7 +1566,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
             c.M[pk & 0xffffu] = v;
             c.M[pk >> 16] = v;
         }
-        for (int e = tid + RA * kThreads; e < lenA; e += kThreads) As[e] = (double)pA[e];
+        for (int e = tid + RA * kThreads; e < lenA; e += kThreads) As[S.apack[e]] = (double)pA[e];
         for (int e = tid + RC * kThreads; e < lenAc; e += kThreads) c.Ac[e] = (double)pAc[e];
         for (int e = tid + RT * kThreads; e < lenT; e += kThreads) c.eqw[e] = S.force_gen[e];
         for (int i = tid + 2 * kThreads; i < nin2; i += kThreads) c.meta[i] = S.rowmeta[i];
@@ -1524,7 +1575,10 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
             c.d[tid] = 0.0;
         }
         bsync();
-        if (tid < n_dense) c.wrow[tid] = c.w[c.iai[tid]];
+        if (tid < n_dense) { // (row weight, right-hand side) pairs behind the staged rows: one 16-byte read per row
+            As[n_dense * 64 + 2 * tid] = c.w[c.iai[tid]];
+            As[n_dense * 64 + 2 * tid + 1] = c.b1[tid];
+        }
         // selection rows (posture): H(c,c) += w, g(c) -= w b  (distinct columns)
         for (int sidx = tid; sidx < n_sel; sidx += kThreads) {
             const int col = (sidx == tid) ? selc : S.sel_col[sidx];
@@ -1573,48 +1627,43 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         double h[4][4];
         double trace = 0.0;
         {
-            int ri[4], ci[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ri[u] = min(ta + 16 * u, nv - 1);
-                ci[u] = min(te + 16 * u, nv - 1);
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) h[u][w] = 0.0;
-            }
             // rows of the next task line are in flight while this one multiplies; g_j = -sum_r w_r A(r,j) b(r) rides along
             double gacc[4] = {0.0, 0.0, 0.0, 0.0};
-            auto ldrow = [&](int r, double (&ai)[4], double (&aj)[4], double& wr, double& br) __attribute__((always_inline)) {
-                const double* Ar = As + r * nv;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ai[u] = Ar[ri[u]];
-                    aj[u] = Ar[ci[u]];
-                }
-                wr = c.wrow[r];
-                br = c.b1[r];
+            const double* Ai = As + ta * 4;
+            const double* Aj = As + te * 4;
+            const double* WB = As + n_dense * 64;
+            auto ldrow = [&](int r, double2v (&ai)[2], double2v (&aj)[2], double2v& wb) __attribute__((always_inline)) {
+                ai[0] = ld2(Ai + r * 64);
+                ai[1] = ld2(Ai + r * 64 + 2);
+                aj[0] = ld2(Aj + r * 64);
+                aj[1] = ld2(Aj + r * 64 + 2);
+                wb = ld2(WB + 2 * r);
             };
-            auto macrow = [&](const double (&ai)[4], const double (&aj)[4], double wr, double br) __attribute__((always_inline)) {
-                double ajw[4];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) ajw[w] = aj[w] * wr;
+            auto macrow = [&](const double2v (&ai)[2], const double2v (&aj)[2], const double2v& wb) __attribute__((always_inline)) {
+                const double a[4] = {ai[0].x, ai[0].y, ai[1].x, ai[1].y};
+                const double ajw[4] = {aj[0].x * wb.x, aj[0].y * wb.x, aj[1].x * wb.x, aj[1].y * wb.x};
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int w = u; w < 4; ++w) h[u][w] = fma(ai[u], ajw[w], h[u][w]);
+                    for (int w = u; w < 4; ++w) h[u][w] = fma(a[u], ajw[w], h[u][w]);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) gacc[w] = fma(ajw[w], br, gacc[w]);
+                for (int w = 0; w < 4; ++w) gacc[w] = fma(ajw[w], wb.y, gacc[w]);
             };
             if (n_dense > 0) {
-                double ai0[4], aj0[4], ai1[4], aj1[4], wr0, br0, wr1, br1;
-                ldrow(0, ai0, aj0, wr0, br0);
+                double2v ai0[2], aj0[2], ai1[2], aj1[2], wb0, wb1;
+                ldrow(0, ai0, aj0, wb0);
                 int r = 0;
                 for (; r + 2 <= n_dense; r += 2) {
-                    ldrow(r + 1, ai1, aj1, wr1, br1);
-                    macrow(ai0, aj0, wr0, br0);
-                    ldrow(min(r + 2, n_dense - 1), ai0, aj0, wr0, br0);
-                    macrow(ai1, aj1, wr1, br1);
+                    ldrow(r + 1, ai1, aj1, wb1);
+                    macrow(ai0, aj0, wb0);
+                    ldrow(min(r + 2, n_dense - 1), ai0, aj0, wb0);
+                    macrow(ai1, aj1, wb1);
                 }
-                if (r < n_dense) macrow(ai0, aj0, wr0, br0);
+                if (r < n_dense) macrow(ai0, aj0, wb0);
             }
             if (ta == 0) {
 #pragma unroll
