@@ -168,6 +168,27 @@ def main():
         }
         if gather_state["err"]:
             result["config"]["allgather_error"] = gather_state["err"]
+        if world == 1 and args.robot == "talos":
+            # after the path: state integration kernel on the solver's own output, outside `value`
+            nvv, nq = st.nv, st.nv + 1
+            gq = torch.zeros(B, nq, dtype=torch.float64, device=dev)
+            gq[:, 6] = 1.0
+            gdq = torch.zeros(B, nvv, dtype=torch.float64, device=dev)
+            gqn, gvn, gqs = torch.zeros_like(gq), torch.zeros_like(gdq), torch.zeros_like(gdq)
+            sp = torch.cuda.current_stream().cuda_stream
+            for _ in range(3):
+                h.integrate(B, nvv, True, 1e-3, gq, gdq, d_out["x"], st.n, d_out["status"], gqn, gvn, gqs, stream=sp)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                h.integrate(B, nvv, True, 1e-3, gq, gdq, d_out["x"], st.n, d_out["status"], gqn, gvn, gqs, stream=sp)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 50 * 1e3
+            ibytes = B * (8 * (2 * nq + 4 * nvv) + 4)  # q, dq, dv in; q_next, v_next, q_solver out; status
+            result["after_path"] = {"kernel": "wbcqp::integrate_kernel<double>", "us_per_launch": us, "bytes_per_launch": ibytes,
+                                    "achieved_GBps": ibytes / (us * 1e-6) / 1e9, "bound": "hbm (launch-latency sized at this batch)"}
         if world == 1 and not args.index_order and not args.no_compare:
             # the same K steps with the launch in plain index order (WBCQP_FLAG_INDEX_ORDER), reported beside `value`
             h2 = capi.Handle(device=local_rank, dtype=capi.F64, flags=capi.FLAG_INDEX_ORDER)

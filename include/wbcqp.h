@@ -194,6 +194,23 @@ int wbcqp_solve_ragged(wbcqp_handle* handle, int n_groups, const wbcqp_group* gr
 int wbcqp_allgather_tau(wbcqp_handle* handle, void* comm, const void* send, void* recv,
                         size_t count, void* stream);
 
+/* After the path -- what Controller::_solve does with an optimal solution, controller.cpp:250-272:
+ *   v_next = dq + dt dv;  q_next = pinocchio::integrate(model, q, dt v_next);  q_solver = q_next with the base orientation
+ *   repacked from quaternion to angle * axis (floating base) or q_next itself.
+ * Model: free-flyer root (q = [p, quat(x,y,z,w)], v = [v_lin, w] in the body frame, nq = nv + 1) followed by revolute
+ * joints when floating_base != 0, revolute joints only otherwise (nq = nv).  x is the solver output [batch][ldx], dv its
+ * first nv entries.  status may be NULL; an instance whose status is not WBCQP_HQP_OPTIMAL keeps its state (the
+ * reference throws there, controller.cpp:284-307).  q_solver ([batch][nv]) may be NULL.  DEVICE pointers of the handle's
+ * dtype, asynchronous on `stream`. */
+int wbcqp_integrate(wbcqp_handle* handle, int batch, int nv, int floating_base, double dt,
+                    const void* q, const void* dq, const void* x, int ldx, const int32_t* status,
+                    void* q_next, void* v_next, void* q_solver, void* stream);
+
+/* Same with HOST pointers: stages through device buffers owned by the handle, blocks until done. */
+int wbcqp_integrate_host(wbcqp_handle* handle, int batch, int nv, int floating_base, double dt,
+                         const void* q, const void* dq, const void* x, int ldx, const int32_t* status,
+                         void* q_next, void* v_next, void* q_solver);
+
 int wbcqp_sync(wbcqp_handle* handle, void* stream);
 
 #ifdef __cplusplus

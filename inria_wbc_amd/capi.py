@@ -24,7 +24,7 @@ FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
 # every symbol include/wbcqp.h declares
 EXPORTS = ("wbcqp_version", "wbcqp_last_error", "wbcqp_create", "wbcqp_destroy", "wbcqp_set_structure",
            "wbcqp_layout_of", "wbcqp_solve_batch", "wbcqp_solve_batch_host", "wbcqp_solve_ragged",
-           "wbcqp_allgather_tau", "wbcqp_sync")
+           "wbcqp_allgather_tau", "wbcqp_integrate", "wbcqp_integrate_host", "wbcqp_sync")
 
 c_i32_p = C.POINTER(C.c_int32)
 c_f64_p = C.POINTER(C.c_double)
@@ -99,6 +99,8 @@ def load_library(path: Optional[str] = None):
     lib.wbcqp_solve_ragged.argtypes = [C.c_void_p, C.c_int, C.POINTER(CGroup), C.c_void_p]
     lib.wbcqp_allgather_tau.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.wbcqp_sync.argtypes = [C.c_void_p, C.c_void_p]
+    lib.wbcqp_integrate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -223,6 +225,13 @@ class Handle:
             cin, cout = self._pack(slot, batch, inputs, outputs)
             arr[i].slot, arr[i].batch, arr[i].inp, arr[i].out = slot, batch, cin, cout
         self._check(self.lib.wbcqp_solve_ragged(self._h, len(groups), arr, C.c_void_p(stream)))
+
+    def integrate(self, batch: int, nv: int, floating_base: bool, dt: float, q, dq, x, ldx: int, status, q_next, v_next,
+                  q_solver=None, stream: int = 0):
+        """State integration after the path (controller.cpp:250-272) on device tensors (anything with .data_ptr())."""
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(self.lib.wbcqp_integrate(self._h, batch, nv, 1 if floating_base else 0, float(dt), ptr(q), ptr(dq), ptr(x), ldx,
+                                             ptr(status), ptr(q_next), ptr(v_next), ptr(q_solver), C.c_void_p(stream)))
 
     def sync(self, stream: int = 0):
         self._check(self.lib.wbcqp_sync(self._h, C.c_void_p(stream)))

@@ -185,16 +185,16 @@ namespace inria_wbc {
                         throw IWBC_EXCEPTION(error);
                     }
                 }
-                // a_tsid = dv ; v_tsid = dq + dt dv ; q = integrate(q, dt v)  (controller.cpp:250-256)
+                // a_tsid = dv ; v_tsid = dq + dt dv ; q = integrate(q, dt v)  (controller.cpp:250-256): on the device
                 a_tsid_ = MatrixXd(B, nv);
-                MatrixXd vnew(B, nv);
                 for (int i = 0; i < B; ++i)
-                    for (int j = 0; j < nv; ++j) {
-                        a_tsid_(i, j) = x_[(size_t)i * n + j];
-                        vnew(i, j) = dq(i, j) + dt_ * a_tsid_(i, j);
-                    }
-                MatrixXd qnew = q;
-                for (int i = 0; i < B; ++i) _integrate(q.row(i), vnew.row(i), qnew.row(i), q.cols, nv);
+                    for (int j = 0; j < nv; ++j) a_tsid_(i, j) = x_[(size_t)i * n + j];
+                MatrixXd vnew(B, nv);
+                MatrixXd qnew(B, q.cols);
+                IWBC_ASSERT(q.cols == (floating_base_ ? nv + 1 : nv), "q must hold ", floating_base_ ? nv + 1 : nv, " entries per instance");
+                if (wbcqp_integrate_host(handle_, B, nv, floating_base_ ? 1 : 0, dt_, q.data.data(), dq.data.data(), x_.data(), n,
+                                         status_.data(), qnew.data.data(), vnew.data.data(), nullptr) != WBCQP_OK)
+                    IWBC_ERROR(wbcqp_last_error(handle_));
                 v_tsid_ = vnew;
                 q_tsid_ = qnew;
                 t_ += dt_;
@@ -205,45 +205,6 @@ namespace inria_wbc {
                         for (int m = 0; m < 12; ++m) f(i, m) = x_[(size_t)i * n + nv + 12 * c + m];
                     activated_contacts_forces_[st.contacts()[c].name] = f;
                 }
-            }
-
-            // semi-implicit Euler on SE(3) x R^na: what pinocchio::integrate does for a free-flyer + revolute joints
-            void _integrate(const double* q, const double* v, double* qout, int nq, int nv) const
-            {
-                if (!floating_base_) {
-                    for (int j = 0; j < nv; ++j) qout[j] = q[j] + dt_ * v[j];
-                    return;
-                }
-                // q = [p(3), quat(x,y,z,w), joints]; v = [v_lin (body frame), w (body frame), joint rates]
-                const double wx = v[3] * dt_, wy = v[4] * dt_, wz = v[5] * dt_;
-                const double vx = v[0] * dt_, vy = v[1] * dt_, vz = v[2] * dt_;
-                const double th2 = wx * wx + wy * wy + wz * wz, th = std::sqrt(th2);
-                // exp6: rotation increment (quaternion) and translation increment V(w) v
-                double a, b, c;
-                if (th < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0; }
-                else { a = std::sin(th) / th; b = (1.0 - std::cos(th)) / th2; c = (1.0 - a) / th2; }
-                const double cx = wy * vz - wz * vy, cy = wz * vx - wx * vz, cz = wx * vy - wy * vx;              // w x v
-                const double ccx = wy * cz - wz * cy, ccy = wz * cx - wx * cz, ccz = wx * cy - wy * cx;            // w x (w x v)
-                const double tx = vx + b * cx + c * ccx, ty = vy + b * cy + c * ccy, tz = vz + b * cz + c * ccz;
-                const double half = 0.5 * th, sh = (th < 1e-8) ? 0.5 - th2 / 48.0 : std::sin(half) / th;
-                const double dqx = wx * sh, dqy = wy * sh, dqz = wz * sh, dqw = std::cos(half);
-                const double qx = q[3], qy = q[4], qz = q[5], qw = q[6];
-                // p += R(q) t
-                const double r00 = 1 - 2 * (qy * qy + qz * qz), r01 = 2 * (qx * qy - qz * qw), r02 = 2 * (qx * qz + qy * qw);
-                const double r10 = 2 * (qx * qy + qz * qw), r11 = 1 - 2 * (qx * qx + qz * qz), r12 = 2 * (qy * qz - qx * qw);
-                const double r20 = 2 * (qx * qz - qy * qw), r21 = 2 * (qy * qz + qx * qw), r22 = 1 - 2 * (qx * qx + qy * qy);
-                qout[0] = q[0] + r00 * tx + r01 * ty + r02 * tz;
-                qout[1] = q[1] + r10 * tx + r11 * ty + r12 * tz;
-                qout[2] = q[2] + r20 * tx + r21 * ty + r22 * tz;
-                // quat = q * dq, renormalised
-                double nx = qw * dqx + qx * dqw + qy * dqz - qz * dqy;
-                double ny = qw * dqy - qx * dqz + qy * dqw + qz * dqx;
-                double nz = qw * dqz + qx * dqy - qy * dqx + qz * dqw;
-                double nw = qw * dqw - qx * dqx - qy * dqy - qz * dqz;
-                const double nn = std::sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
-                qout[3] = nx / nn; qout[4] = ny / nn; qout[5] = nz / nn; qout[6] = nw / nn;
-                for (int j = 6; j < nv; ++j) qout[j + 1] = q[j + 1] + dt_ * v[j];
-                (void)nq;
             }
 
             bool verbose_ = false;

@@ -528,6 +528,63 @@ int wbcqp_debug_set_stamp_buffer(wbcqp_handle* h, void* dev_ptr)
 #endif
 }
 
+int wbcqp_integrate(wbcqp_handle* h, int batch, int nv, int floating_base, double dt, const void* q, const void* dq, const void* x,
+                    int ldx, const int32_t* status, void* q_next, void* v_next, void* q_solver, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (batch < 0 || nv <= 0 || ldx < nv) return fail(h, WBCQP_ERR_INVALID, "bad batch / nv / ldx");
+    if (floating_base && nv < 6) return fail(h, WBCQP_ERR_INVALID, "a floating base needs nv >= 6");
+    if (batch == 0) return WBCQP_OK;
+    if (!q || !dq || !x || !q_next || !v_next) return fail(h, WBCQP_ERR_INVALID, "q / dq / x / q_next / v_next is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const dim3 grid((batch + 3) / 4), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (h->dtype == WBCQP_F64)
+        hipLaunchKernelGGL(integrate_kernel<double>, grid, block, 0, st, batch, nv, floating_base ? 1 : 0, dt,
+                           static_cast<const double*>(q), static_cast<const double*>(dq), static_cast<const double*>(x), ldx, status,
+                           static_cast<double*>(q_next), static_cast<double*>(v_next), static_cast<double*>(q_solver));
+    else
+        hipLaunchKernelGGL(integrate_kernel<float>, grid, block, 0, st, batch, nv, floating_base ? 1 : 0, dt,
+                           static_cast<const float*>(q), static_cast<const float*>(dq), static_cast<const float*>(x), ldx, status,
+                           static_cast<float*>(q_next), static_cast<float*>(v_next), static_cast<float*>(q_solver));
+    HIP_TRY(h, hipGetLastError());
+    return WBCQP_OK;
+}
+
+int wbcqp_integrate_host(wbcqp_handle* h, int batch, int nv, int floating_base, double dt, const void* q, const void* dq,
+                         const void* x, int ldx, const int32_t* status, void* q_next, void* v_next, void* q_solver)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (batch < 0 || nv <= 0 || ldx < nv) return fail(h, WBCQP_ERR_INVALID, "bad batch / nv / ldx");
+    if (batch == 0) return WBCQP_OK;
+    if (!q || !dq || !x || !q_next || !v_next) return fail(h, WBCQP_ERR_INVALID, "q / dq / x / q_next / v_next is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t es = (h->dtype == WBCQP_F64) ? 8 : 4;
+    const int nq = floating_base ? nv + 1 : nv;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t bq = al((size_t)batch * nq * es), bv = al((size_t)batch * nv * es), bx = al((size_t)batch * ldx * es),
+                 bs = al((size_t)batch * 4);
+    int rc = ensure(h, h->stage_in, bq + bv + bx + bs + 256);
+    if (rc != WBCQP_OK) return rc;
+    rc = ensure(h, h->stage_out, bq + 2 * bv + 256);
+    if (rc != WBCQP_OK) return rc;
+    char* din = static_cast<char*>(h->stage_in.dev);
+    char* dout = static_cast<char*>(h->stage_out.dev);
+    HIP_TRY(h, hipMemcpy(din, q, (size_t)batch * nq * es, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(din + bq, dq, (size_t)batch * nv * es, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(din + bq + bv, x, (size_t)batch * ldx * es, hipMemcpyHostToDevice));
+    if (status) HIP_TRY(h, hipMemcpy(din + bq + bv + bx, status, (size_t)batch * 4, hipMemcpyHostToDevice));
+    rc = wbcqp_integrate(h, batch, nv, floating_base, dt, din, din + bq, din + bq + bv, ldx,
+                         status ? reinterpret_cast<const int32_t*>(din + bq + bv + bx) : nullptr, dout, dout + bq,
+                         q_solver ? dout + bq + bv : nullptr, nullptr);
+    if (rc != WBCQP_OK) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(q_next, dout, (size_t)batch * nq * es, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(v_next, dout + bq, (size_t)batch * nv * es, hipMemcpyDeviceToHost));
+    if (q_solver) HIP_TRY(h, hipMemcpy(q_solver, dout + bq + bv, (size_t)batch * nv * es, hipMemcpyDeviceToHost));
+    return WBCQP_OK;
+}
+
 int wbcqp_sync(wbcqp_handle* h, void* stream)
 {
     if (!h) return WBCQP_ERR_INVALID;

@@ -194,6 +194,20 @@ def tick_single(st, inputs: Dict[str, np.ndarray], index: int = 0):
     return dict(x=x, tau=tau[:st.na], lam=lam[:q].copy(), active=act[:q].copy(), status=out.status, iters=out.iters, fval=out.fval)
 
 
+def integrate(floating_base: bool, dt: float, q: np.ndarray, dq: np.ndarray, dv: np.ndarray):
+    """State integration after the path (controller.cpp:250-272) for every row. Returns dict(q_next, v_next, q_solver)."""
+    q = np.ascontiguousarray(q, np.float64); dq = np.ascontiguousarray(dq, np.float64); dv = np.ascontiguousarray(dv, np.float64)
+    B, nv = dq.shape
+    nq = nv + 1 if floating_base else nv
+    assert q.shape == (B, nq) and dv.shape == (B, nv)
+    qn = np.zeros((B, nq)); vn = np.zeros((B, nv)); qs = np.zeros((B, nq - 1 if floating_base else nq))
+    f = lib().wbco_integrate
+    f.restype = None
+    for i in range(B):
+        f(C.c_int(1 if floating_base else 0), C.c_int(nv), C.c_double(dt), _dp(q[i]), _dp(dq[i]), _dp(dv[i]), _dp(qn[i]), _dp(vn[i]), _dp(qs[i]))
+    return dict(q_next=qn, v_next=vn, q_solver=qs)
+
+
 # ---------------------------------------------------------------------------------------------
 # Independent checker (numpy only; shares no code with wbc_oracle.c)
 # ---------------------------------------------------------------------------------------------

@@ -716,3 +716,116 @@ int wbco_tick_batch(const wbco_structure* st, int batch, const wbco_batch_inputs
     free(jobs);
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * After the path: state integration (controller.cpp:250-272), see wbc_oracle.h
+ * ------------------------------------------------------------------------------------------------ */
+static void quat_to_rot(const double* qt /* x y z w */, double R[9])
+{
+    /* Eigen::Quaternion::toRotationMatrix */
+    const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+static void rot_to_quat(const double R[9], double* qt /* x y z w */)
+{
+    /* Eigen quaternionbase_assign_impl<Matrix3> (Ken Shoemake) */
+    double t = R[0] + R[4] + R[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        qt[3] = 0.5 * t;
+        t = 0.5 / t;
+        qt[0] = (R[7] - R[5]) * t;
+        qt[1] = (R[2] - R[6]) * t;
+        qt[2] = (R[3] - R[1]) * t;
+    }
+    else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        qt[i] = 0.5 * t;
+        t = 0.5 / t;
+        qt[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+        qt[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        qt[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+}
+
+void wbco_integrate(int floating_base, int nv, double dt, const double* q, const double* dq, const double* dv,
+                    double* q_next, double* v_next, double* q_solver)
+{
+    for (int j = 0; j < nv; ++j) v_next[j] = dq[j] + dt * dv[j]; /* controller.cpp:254 */
+    if (!floating_base) {
+        for (int j = 0; j < nv; ++j) q_next[j] = q[j] + dt * v_next[j]; /* revolute joints: q + v */
+        if (q_solver)
+            for (int j = 0; j < nv; ++j) q_solver[j] = q_next[j]; /* controller.cpp:273 */
+        return;
+    }
+    /* free flyer: M1 = M0 * exp6(dt v) */
+    const double v[3] = {dt * v_next[0], dt * v_next[1], dt * v_next[2]};
+    const double w[3] = {dt * v_next[3], dt * v_next[4], dt * v_next[5]};
+    const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double t = sqrt(t2);
+    double ct, alpha_v, alpha_wxv, alpha_w;
+    const double wv = w[0] * v[0] + w[1] * v[1] + w[2] * v[2];
+    if (t > 1e-4) {
+        ct = cos(t);
+        const double st = sin(t), inv_t2 = 1.0 / t2;
+        alpha_wxv = (1.0 - ct) * inv_t2;
+        alpha_v = st / t;
+        alpha_w = (1.0 - alpha_v) * inv_t2 * wv;
+    }
+    else {
+        alpha_wxv = 0.5 - t2 / 24.0;
+        alpha_v = 1.0 - t2 / 6.0;
+        alpha_w = (1.0 / 6.0 - t2 / 120.0) * wv;
+        ct = 1.0 - t2 / 2.0;
+    }
+    const double c[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
+    double tr[3], E[9];
+    for (int i = 0; i < 3; ++i) tr[i] = alpha_v * v[i] + alpha_w * w[i] + alpha_wxv * c[i];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) E[3 * i + j] = alpha_wxv * w[i] * w[j];
+    E[0] += ct; E[4] += ct; E[8] += ct;
+    E[1] -= alpha_v * w[2]; E[3] += alpha_v * w[2];
+    E[2] += alpha_v * w[1]; E[6] -= alpha_v * w[1];
+    E[5] -= alpha_v * w[0]; E[7] += alpha_v * w[0];
+    double R0[9], R1[9];
+    quat_to_rot(q + 3, R0);
+    for (int i = 0; i < 3; ++i) {
+        q_next[i] = q[i] + R0[3 * i] * tr[0] + R0[3 * i + 1] * tr[1] + R0[3 * i + 2] * tr[2];
+        for (int j = 0; j < 3; ++j) R1[3 * i + j] = R0[3 * i] * E[j] + R0[3 * i + 1] * E[3 + j] + R0[3 * i + 2] * E[6 + j];
+    }
+    double qt[4];
+    rot_to_quat(R1, qt);
+    const double dotp = qt[0] * q[3] + qt[1] * q[4] + qt[2] * q[5] + qt[3] * q[6];
+    if (dotp < 0.0)
+        for (int i = 0; i < 4; ++i) qt[i] = -qt[i]; /* continuity with the previous quaternion */
+    const double N2 = qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2] + qt[3] * qt[3];
+    const double alpha = (3.0 - N2) / 2.0; /* firstOrderNormalize */
+    for (int i = 0; i < 4; ++i) q_next[3 + i] = qt[i] * alpha;
+    for (int j = 6; j < nv; ++j) q_next[j + 1] = q[j + 1] + dt * v_next[j];
+    if (q_solver) {
+        /* Eigen::AngleAxisd(quaternion): controller.cpp:263-265 */
+        const double* u = q_next + 3;
+        double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        double angle = 0.0, ax[3] = {1.0, 0.0, 0.0};
+        if (n != 0.0) {
+            angle = 2.0 * atan2(n, fabs(u[3]));
+            if (u[3] < 0.0) n = -n;
+            ax[0] = u[0] / n; ax[1] = u[1] / n; ax[2] = u[2] / n;
+        }
+        for (int i = 0; i < 3; ++i) q_solver[i] = q_next[i];
+        for (int i = 0; i < 3; ++i) q_solver[3 + i] = angle * ax[i];
+        for (int j = 6; j < nv; ++j) q_solver[j] = q_next[j + 1];
+    }
+}

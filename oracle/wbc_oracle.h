@@ -134,6 +134,17 @@ typedef struct {
 int wbco_tick_batch(const wbco_structure* st, int batch, const wbco_batch_inputs* in,
                     const wbco_batch_outputs* out, int nthreads);
 
+/* After the path: what Controller::_solve does with an optimal solution,
+ * src/controllers/controller.cpp:250-272:  v = dq + dt dv;  q = pinocchio::integrate(model, q, dt v);  and, for a
+ * floating base, the repack of the base orientation from quaternion to angle * axis.  The model is a free-flyer root
+ * (q = [p, quat(x,y,z,w)], v = [v_lin, w] in the body frame) followed by revolute joints, or revolute joints only.
+ * pinocchio is not in the reference tree: its SE(3) integration (exp6, M0 * exp6, rotation -> quaternion, sign
+ * continuity, first-order normalisation) and Eigen's quaternion -> angle-axis are restated from their published
+ * algorithms [UPSTREAM-RECALL]; parity unpinned like the rest of this file.
+ * nq = nv + 1 for a floating base, else nq = nv.  q_solver has nq - 1 (floating base) or nq entries; may be NULL. */
+void wbco_integrate(int floating_base, int nv, double dt, const double* q, const double* dq, const double* dv,
+                    double* q_next, double* v_next, double* q_solver);
+
 #ifdef __cplusplus
 }
 #endif

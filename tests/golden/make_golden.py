@@ -41,5 +41,33 @@ def main():
         print("wrote", path, "iters", out["iters"].tolist())
 
 
+def main_after_path():
+    """State integration after the path: q, dq, dv -> q_next, v_next, q_solver by the oracle,
+    accepted after the independent scipy check of tests/test_oracle.py holds for the same draw."""
+    from scipy.spatial.transform import Rotation as Rot
+    os.makedirs(os.path.join(HERE, "after_path"), exist_ok=True)
+    for tag, floating, nv in (("talos", True, 50), ("franka", False, 9)):
+        rng = np.random.default_rng(77 + nv)
+        B, dt = 16, 1e-3
+        nq = nv + 1 if floating else nv
+        q = rng.normal(size=(B, nq))
+        if floating:
+            q[:, 3:7] = Rot.random(B, random_state=3).as_quat()
+            q[12:, 3:7] = np.array([0.0, 1.0, 0.0, 0.0])  # half turns: trace <= 0 branch
+        dq = rng.normal(size=(B, nv))
+        dv = 5.0 * rng.normal(size=(B, nv))
+        if floating:
+            dq[:4, 3:6] = 0.0
+            dv[:4, 3:6] = 0.0  # small-angle branch of exp6
+        o = oracle.integrate(floating, dt, q, dq, dv)
+        if floating:
+            rv = Rot.from_quat(o["q_next"][:, 3:7]).as_rotvec()
+            assert np.abs(o["q_solver"][:, 3:6] - rv).max() < 1e-13
+        path = os.path.join(HERE, "after_path", "integrate_%s.npz" % tag)
+        np.savez_compressed(path, floating_base=floating, dt=dt, q=q, dq=dq, dv=dv, **o)
+        print("wrote", path)
+
+
 if __name__ == "__main__":
     main()
+    main_after_path()

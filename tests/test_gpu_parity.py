@@ -198,3 +198,68 @@ def test_longest_first_schedule_changes_nothing_but_the_order():
     for o in sched:
         for k in ("x", "tau", "status", "iters"):
             assert np.array_equal(o[k], plain[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("floating_base", [True, False])
+def test_integrate_parity(floating_base):
+    """wbcqp_integrate (state integration after the path, controller.cpp:250-272) against the oracle; instances whose
+    status is not OPTIMAL keep their state."""
+    import torch
+    from inria_wbc_amd import capi
+    from scipy.spatial.transform import Rotation as Rot
+    from oracle import oracle
+    oracle.build()
+    rng = np.random.default_rng(23)
+    B, nv, dt, ldx = 333, (50 if floating_base else 9), 1e-3, 80
+    nq = nv + 1 if floating_base else nv
+    q = rng.normal(size=(B, nq))
+    if floating_base:
+        q[:, 3:7] = Rot.random(B, random_state=7).as_quat()
+    dq = rng.normal(size=(B, nv))
+    x = 5.0 * rng.normal(size=(B, ldx))
+    if floating_base:
+        dq[:16, 3:6] = 0.0
+        x[:16, 3:6] = 0.0
+        q[16:24, 3:7] = np.array([1.0, 0.0, 0.0, 0.0])  # half turn: the trace <= 0 branch of rotation -> quaternion
+    status = np.zeros(B, np.int32)
+    status[5::17] = 1
+    ref = oracle.integrate(floating_base, dt, q, dq, x[:, :nv])
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dq_, q_, x_, st_ = t(dq), t(q), t(x), t(status)
+    qn = torch.zeros(B, nq, dtype=torch.float64, device=dev)
+    vn = torch.zeros(B, nv, dtype=torch.float64, device=dev)
+    qs = torch.zeros(B, nv, dtype=torch.float64, device=dev)
+    h = capi.Handle(0, capi.F64)
+    h.integrate(B, nv, floating_base, dt, q_, dq_, x_, ldx, st_, qn, vn, qs, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    qn, vn, qs = qn.cpu().numpy(), vn.cpu().numpy(), qs.cpu().numpy()
+    ok = status == 0
+    assert np.abs(vn[ok] - ref["v_next"][ok]).max() == 0.0
+    assert np.abs(qn[ok] - ref["q_next"][ok]).max() < 1e-13   # device and host libm differ in the last bits of sin/cos/atan2
+    assert np.abs(qs[ok] - ref["q_solver"][ok]).max() < 1e-12
+    assert np.array_equal(qn[~ok], q[~ok]) and np.array_equal(vn[~ok], dq[~ok])
+    h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["talos", "franka"])
+def test_integrate_golden_gpu(tag):
+    import os
+    import torch
+    from inria_wbc_amd import capi
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "after_path", "integrate_%s.npz" % tag))
+    fb, dt = bool(z["floating_base"]), float(z["dt"])
+    B, nv = z["dq"].shape
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    q, dq, dv = t(z["q"]), t(z["dq"]), t(z["dv"])
+    qn, vn, qs = torch.zeros_like(q), torch.zeros_like(dq), torch.zeros_like(dq)
+    h = capi.Handle(0, capi.F64)
+    h.integrate(B, nv, fb, dt, q, dq, dv, nv, None, qn, vn, qs, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.abs(vn.cpu().numpy() - z["v_next"]).max() == 0.0
+    assert np.abs(qn.cpu().numpy() - z["q_next"]).max() < 1e-13
+    assert np.abs(qs.cpu().numpy() - z["q_solver"]).max() < 1e-12
+    h.close()

@@ -135,3 +135,53 @@ def test_threads_agree(oracle_mod):
     b = oracle_mod.tick_batch(st, inputs, nthreads=4)
     for k in ("x", "tau", "status", "iters"):
         assert np.array_equal(a[k], b[k])
+
+
+def test_integrate_matches_an_independent_se3_restatement(oracle_mod):
+    oracle = oracle_mod
+    """oracle.integrate (controller.cpp:250-272 + pinocchio's free-flyer integrate) against scipy's rotations."""
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(11)
+    B, nv, dt = 48, 50, 1e-3
+    q = np.zeros((B, nv + 1))
+    q[:, :3] = rng.normal(size=(B, 3))
+    q[:, 3:7] = Rot.random(B, random_state=5).as_quat()
+    q[:, 7:] = rng.normal(size=(B, nv - 6))
+    dq = rng.normal(size=(B, nv))
+    dq[:8, 3:6] = 0.0  # small-angle branch of exp6
+    dv = 5.0 * rng.normal(size=(B, nv))
+    dv[:8, 3:6] = 0.0
+    o = oracle.integrate(True, dt, q, dq, dv)
+    v = dq + dt * dv
+    assert np.array_equal(o["v_next"], v)
+    R0 = Rot.from_quat(q[:, 3:7])
+    w, vl = v[:, 3:6] * dt, v[:, :3] * dt
+
+    def V(wi, vi):
+        t = np.linalg.norm(wi)
+        K = np.array([[0, -wi[2], wi[1]], [wi[2], 0, -wi[0]], [-wi[1], wi[0], 0]])
+        if t < 1e-12:
+            return vi
+        return (np.eye(3) + (1 - np.cos(t)) / t**2 * K + (t - np.sin(t)) / t**3 * K @ K) @ vi
+
+    p1 = q[:, :3] + np.stack([R0[i].apply(V(w[i], vl[i])) for i in range(B)])
+    q1 = (R0 * Rot.from_rotvec(w)).as_quat()
+    q1 *= np.sign((q1 * q[:, 3:7]).sum(1))[:, None]
+    assert np.abs(o["q_next"][:, :3] - p1).max() < 1e-14
+    assert np.abs(o["q_next"][:, 3:7] - q1).max() < 1e-14
+    assert np.abs(o["q_next"][:, 7:] - (q[:, 7:] + dt * v[:, 6:])).max() == 0.0
+    assert np.abs(o["q_solver"][:, 3:6] - Rot.from_quat(o["q_next"][:, 3:7]).as_rotvec()).max() < 1e-14
+    assert np.array_equal(o["q_solver"][:, :3], o["q_next"][:, :3]) and np.array_equal(o["q_solver"][:, 6:], o["q_next"][:, 7:])
+    # fixed base: plain Euler
+    o2 = oracle.integrate(False, dt, q[:, :9].copy(), dq[:, :9].copy(), dv[:, :9].copy())
+    assert np.array_equal(o2["q_next"], q[:, :9] + dt * (dq[:, :9] + dt * dv[:, :9]))
+    assert np.array_equal(o2["q_solver"], o2["q_next"])
+
+
+@pytest.mark.parametrize("tag", ["talos", "franka"])
+def test_integrate_golden(oracle_mod, tag):
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "after_path", "integrate_%s.npz" % tag))
+    o = oracle_mod.integrate(bool(z["floating_base"]), float(z["dt"]), z["q"], z["dq"], z["dv"])
+    for k in ("q_next", "v_next", "q_solver"):
+        assert np.abs(o[k] - z[k]).max() < 1e-15, k
