@@ -1866,6 +1866,8 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         const double *fmat = S.fric_mat, *flb = S.fric_lb, *fub = S.fric_ub;
         if (S.fric_lds && nc > 0) {
             double* tb = c.eqw;
+            // (fetching these early into registers and parking them across the equality phase was tried: a diagnostic
+            //  build then went wrong non-deterministically under the added register pressure -- not kept)
             for (int e = tid; e < nc * 204; e += kThreads) tb[e] = S.fric_mat[e];
             for (int e = tid; e < nc * 17; e += kThreads) {
                 tb[nc * 204 + e] = S.fric_lb[e];

@@ -263,3 +263,28 @@ def test_integrate_golden_gpu(tag):
     assert np.abs(qn.cpu().numpy() - z["q_next"]).max() < 1e-13
     assert np.abs(qs.cpu().numpy() - z["q_solver"]).max() < 1e-12
     h.close()
+
+
+@pytest.mark.gpu
+def test_diagnostic_build_is_a_canary(tmp_path):
+    """The -DWBCQP_STAMPS build runs the same algorithm under different register pressure and timing: its results must
+    be bitwise those of the product library, launch after launch (a latent race or an uninitialised read shows up here
+    first).  One process per library; the product path never loads the diagnostic one."""
+    import os
+    import subprocess
+    import sys
+    from inria_wbc_amd import build
+    build.build()
+    build.build_stamps()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name in ("libwbcqp.so", "libwbcqp_stamps.so"):
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "chk_lib.py"), name, path], cwd=root)
+        outs[name] = np.load(path)
+    prod, diag = outs["libwbcqp.so"], outs["libwbcqp_stamps.so"]
+    assert (prod["status_0"] == 0).all() and prod["iters_0"].max() > prod["iters_0"].min()
+    for rep in range(3):
+        for k in ("status", "iters", "x", "tau"):
+            assert np.array_equal(prod["%s_%d" % (k, rep)], prod["%s_0" % k]), ("product", k, rep)
+            assert np.array_equal(diag["%s_%d" % (k, rep)], prod["%s_0" % k]), ("diagnostic", k, rep)

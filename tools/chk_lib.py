@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Solves one seeded Talos batch with the named build of the library (libwbcqp.so or the diagnostic libwbcqp_stamps.so),
+three launches, and saves every launch's outputs.  Run once per library in separate processes: two builds of the same
+symbols must not share a process.      python tools/chk_lib.py <library file name> <out.npz>"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from inria_wbc_amd import capi, structure, synth
+    which, out_path = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else None)
+    capi.LIB_PATH = os.path.join(ROOT, "inria_wbc_amd", "lib", which)
+    lib = capi.load_library(capi.LIB_PATH)
+    st = structure.talos_structure()
+    B = 384
+    inputs = synth.generate(st, B, synth.SEED_BASE["talos"] + 4242, task_noise=2.0)
+    dev = torch.device("cuda", 0)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
+    saved = {}
+    for rep in range(3):
+        d_out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, st.na, dtype=torch.float64, device=dev),
+                     status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+        h = capi.Handle(0, capi.F64, flags=capi.FLAG_INDEX_ORDER)
+        h.set_structure(0, st)
+        if "stamps" in which:
+            dbg = torch.zeros(B, 24, dtype=torch.int64, device=dev)
+            lib.wbcqp_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
+            assert lib.wbcqp_debug_set_stamp_buffer(h._h, C.c_void_p(dbg.data_ptr())) == 0
+        h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for k, v in d_out.items():
+            saved["%s_%d" % (k, rep)] = v.cpu().numpy()
+        print(which, "launch", rep, "iters mean %.3f max %d, status != 0: %d" %
+              (saved["iters_%d" % rep].mean(), saved["iters_%d" % rep].max(), int((saved["status_%d" % rep] != 0).sum())))
+        h.close()
+    if out_path:
+        np.savez(out_path, **saved)
+
+
+if __name__ == "__main__":
+    main()
