@@ -79,9 +79,46 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    # The kernel-resource remarks are part of the build: a solve kernel that parks live registers in AGPRs or spills to
+    # scratch is refused.  Measured reason: with more than 256 live VGPRs the allocator split live ranges into AGPRs and
+    # ROCm 7.2's clang placed such copies at the head of a join block BEFORE the `s_or_b64 exec` that restores the lanes,
+    # i.e. under a partial EXEC mask -- values came back corrupted in the other lanes (non-deterministic results in the
+    # diagnostic build; tools/chk_lib.py, tests/test_gpu_parity.py::test_diagnostic_build_is_a_canary).
+    cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    usage = _resource_usage(proc.stdout)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout)
+        raise subprocess.CalledProcessError(proc.returncode, cmd)
+    for line in proc.stdout.splitlines():
+        if "remark:" not in line and "kernel-resource-usage" not in line and line.strip() and not line.lstrip().startswith(("|", "^")) \
+                and not line.strip()[:5].strip().isdigit():
+            print(line, file=sys.stderr)
+    for name, u in usage.items():
+        if "solve_kernel" in name and (u.get("AGPRs", 0) != 0 or u.get("ScratchSize [bytes/lane]", 0) != 0 or u.get("VGPRs Spill", 0) != 0):
+            raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, VGPR spills %s -- refuse to ship (see the comment in build.py)" %
+                               (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("VGPRs Spill")))
     os.replace(LIB + ".tmp", LIB)
     return LIB
+
+
+def _resource_usage(text: str) -> dict:
+    """{kernel name: {field: int}} from clang's -Rpass-analysis=kernel-resource-usage remarks."""
+    out, cur = {}, None
+    for line in text.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].split("[-Rpass", 1)[0].strip()
+        if body.startswith("Function Name:"):
+            cur = body.split(":", 1)[1].strip()
+            out[cur] = {}
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            try:
+                out[cur][k.strip()] = int(v.strip())
+            except ValueError:
+                pass
+    return out
 
 
 if __name__ == "__main__":

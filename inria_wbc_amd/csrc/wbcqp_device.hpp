@@ -1099,23 +1099,61 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, const double* Bm, double* vb
         else if (jl >= 0) {
             const double* vh = vbj + 40 * jh;
             double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+            // Left alone the scheduler hoists all forty 16-byte reads of the unrolled loops (160 VGPRs on top of the 120 the
+            // rows and columns hold) and the allocator then parks live values in AGPRs (see build.py).  Explicit software
+            // pipeline instead: groups of five reads, the next group in flight while this one multiplies.
+            double2v g0[5], g1[5];
+            auto ldg = [&](int grp, double2v (&g)[5]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 20; q += 2) {
-                const double2v va = ld2(vh + 2 * q), vb2 = ld2(vh + 2 * q + 2);
-                d0 = fma(va.x, jrow[2 * q], d0);
-                d1 = fma(va.y, jrow[2 * q + 1], d1);
-                d2 = fma(vb2.x, jrow[2 * q + 2], d2);
-                d3 = fma(vb2.y, jrow[2 * q + 3], d3);
-            }
+                for (int i = 0; i < 5; ++i) g[i] = ld2(vh + 10 * grp + 2 * i);
+            };
+            auto dotg = [&](int grp, const double2v (&g)[5]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    if (i & 1) {
+                        d2 = fma(g[i].x, jrow[10 * grp + 2 * i], d2);
+                        d3 = fma(g[i].y, jrow[10 * grp + 2 * i + 1], d3);
+                    }
+                    else {
+                        d0 = fma(g[i].x, jrow[10 * grp + 2 * i], d0);
+                        d1 = fma(g[i].y, jrow[10 * grp + 2 * i + 1], d1);
+                    }
+                }
+            };
+            ldg(0, g0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldg(1, g1);
+            dotg(0, g0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldg(2, g0);
+            dotg(1, g1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldg(3, g1);
+            dotg(2, g0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldg(0, g0); // first group of the update pass
+            dotg(3, g1);
             double dot = (d0 + d1) + (d2 + d3);
             dot += dpp_get<0xB1>(dot); // the other half of the row
             const double coef = dot * tj;
+            auto updg = [&](int grp, const double2v (&g)[5]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 20; ++q) {
-                const double2v va = ld2(vh + 2 * q);
-                jrow[2 * q] = fma(-coef, va.x, jrow[2 * q]);
-                jrow[2 * q + 1] = fma(-coef, va.y, jrow[2 * q + 1]);
-            }
+                for (int i = 0; i < 5; ++i) {
+                    jrow[10 * grp + 2 * i] = fma(-coef, g[i].x, jrow[10 * grp + 2 * i]);
+                    jrow[10 * grp + 2 * i + 1] = fma(-coef, g[i].y, jrow[10 * grp + 2 * i + 1]);
+                }
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            ldg(1, g1);
+            updg(0, g0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldg(2, g0);
+            updg(1, g1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldg(3, g1);
+            updg(2, g0);
+            __builtin_amdgcn_sched_barrier(0);
+            updg(3, g1);
         }
     }
     // R packed, 1/R(j,j); J rows back to LDS
