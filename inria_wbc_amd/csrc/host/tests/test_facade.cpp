@@ -6,7 +6,10 @@
 
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
 #include <inria_wbc/controllers/pos_tracker.hpp>
+#include <inria_wbc/trajs/loader.hpp>
 #include <inria_wbc/utils/timer.hpp>
+#include <cstdio>
+#include <fstream>
 
 static int failures = 0;
 #define UTEST_CHECK(cond)                                                              \
@@ -84,6 +87,28 @@ int main(int argc, char** argv)
         auto v = trajs::min_jerk_trajectory<trajs::d_order::FIRST>({0, 0, 0.9}, {0, 0, 0.7}, 1e-3, 2.0);
         UTEST_CHECK(p.size() == 2000 && std::fabs(p[1000][2] - 0.8) < 1e-12 && p[0][2] == 0.9);
         UTEST_CHECK(std::fabs(v[1000][2] - (-0.2 * 30.0 / 16.0 / 2.0)) < 1e-12);
+    }
+    // ---- trajectory files (loader.cpp:11-88): SE3 = 3 + 9 numbers, rotation column-major; line breaks carry no meaning ----
+    {
+        const std::string dir = argc > 2 ? std::string(argv[2]) : std::string("/tmp");
+        {
+            std::ofstream(dir + "/lh.csv") << "0.1 0.2 0.3  1 0 0 0 0 1 0 -1 0\n0.4 0.5 0.6\n 0 1 0 -1 0 0 0 0 1\n";
+            std::ofstream(dir + "/rh.csv") << "0 0 0 1 0 0 0 1 0 0 0 1 1 1 1 1 0 0 0 1 0 0 0 1";
+            std::ofstream(dir + "/com.csv") << "0 0 0.9\n0 0 0.8\n";
+            std::ofstream(dir + "/q.csv") << "1 2 3 4\n5 6 7 8\n";
+            std::ofstream(dir + "/refs.yaml") << "refs:\n  lh: lh.csv\n  rh: rh.csv\n  com: com.csv\n  posture:\n    posture: q.csv\n    size: 4\n";
+            std::ofstream(dir + "/short.csv") << "0 0 0 1 0 0 0 1 0 0 0 1";
+            std::ofstream(dir + "/bad.yaml") << "refs:\n  lh: lh.csv\n  rh: short.csv\n";
+        }
+        trajs::Loader ld(dir + "/refs.yaml");
+        UTEST_CHECK(ld.size() == 2 && ld.size_vec() == 2 && ld.has_com_refs() && ld.ref_names().size() == 2);
+        UTEST_CHECK(ld.ref_names_vec().size() == 1 && ld.ref_names_vec()[0] == "posture" && ld.task_ref_vec("posture", 1)[2] == 7.0);
+        UTEST_CHECK(ld.task_ref("lh", 1).translation[1] == 0.5 && ld.com_ref(1)[2] == 0.8);
+        // sample 0 of lh: columns (1,0,0), (0,0,1), (0,-1,0) => R(2,1) = 1, R(1,2) = -1
+        UTEST_CHECK(ld.task_ref("lh", 0).R(2, 1) == 1.0 && ld.task_ref("lh", 0).R(1, 2) == -1.0 && ld.task_ref("lh", 0).R(0, 0) == 1.0);
+        UTEST_CHECK(ld.task_ref("rh", 1).translation[0] == 1.0);
+        UTEST_CHECK_EXCEPTION(trajs::Loader(dir + "/bad.yaml"), "wrong number of rows");
+        UTEST_CHECK_EXCEPTION(trajs::Loader(dir + "/missing.yaml"), "");
     }
     // ---- timer ----
     {

@@ -15,9 +15,11 @@ def host_build(built_lib):
     return build.build_host()
 
 
-def test_facade_cpu_checks(host_build):
-    """factories, YAML subset, task stacks (SURVEY App. B sizes), solver-switch errors, min-jerk -- no GPU needed."""
-    r = subprocess.run([host_build["test_facade"], os.path.join(ROOT, "configs")], capture_output=True, text=True, timeout=120)
+def test_facade_cpu_checks(host_build, tmp_path):
+    """factories, YAML subset, task stacks (SURVEY App. B sizes), solver-switch errors, min-jerk, trajectory files -- no GPU
+    needed."""
+    r = subprocess.run([host_build["test_facade"], os.path.join(ROOT, "configs"), str(tmp_path)], capture_output=True, text=True,
+                       timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK (0 failures)" in r.stdout
 
