@@ -249,11 +249,11 @@ def main():
                 do = dict(x=torch.zeros(b, st.n, dtype=torch.float64, device=dev),
                           tau=torch.zeros(b, max(st.na, 1), dtype=torch.float64, device=dev),
                           status=torch.zeros(b, dtype=torch.int32, device=dev), iters=torch.zeros(b, dtype=torch.int32, device=dev))
-                for _ in range(2):
+                for _ in range(4):
                     h.solve_batch(0, b, di, do, stream=torch.cuda.current_stream().cuda_stream)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                nrep = 10
+                nrep = 20
                 for _ in range(nrep):
                     h.solve_batch(0, b, di, do, stream=torch.cuda.current_stream().cuda_stream)
                 torch.cuda.synchronize()
