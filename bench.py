@@ -11,8 +11,9 @@ Talos pos-tracker, batch 1024, fp64, one wavefront per QP, 1 x MI355X.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1: the batch shards embarrassingly -- every rank owns `--batch` QPs of the same seeded stream
-(weak scaling), no collective on the solve path; the optional exchange step of BASELINE config 4
-(all-gather of joint torques over RCCL/xGMI) runs after the solve inside the timed step.
+(weak scaling), no collective on the solve path (the QPs of a batch are independent).  `--allgather`
+adds the optional exchange step of BASELINE config 4 (all-gather of joint torques over RCCL/xGMI)
+after the solve inside the timed step.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -39,7 +40,9 @@ def parse():
     p.add_argument("--batch", type=int, default=1024, help="QPs per GPU per step")
     p.add_argument("--robot", default="talos", choices=["talos", "icub", "franka"])
     p.add_argument("--squat", action="store_true", help="CoM reference follows etc/talos/squat.yaml (BASELINE config 4)")
-    p.add_argument("--no-allgather", action="store_true")
+    p.add_argument("--allgather", action="store_true",
+                   help="N > 1: also all-gather the joint torques over RCCL inside every step (BASELINE config 4's optional\n"
+                        "exchange; the path itself has none -- the QPs of a batch are independent)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-compare", action="store_true", help="skip the extra index-order run reported beside `value`")
     p.add_argument("--index-order", action="store_true",
@@ -89,7 +92,7 @@ def main():
     h = capi.Handle(device=local_rank, dtype=capi.F64, flags=capi.FLAG_INDEX_ORDER if args.index_order else 0)
     h.set_structure(0, st)
     layout = capi.layout_of(st)
-    do_gather = distributed and not args.no_allgather
+    do_gather = distributed and args.allgather
     gather_state = {"ok": do_gather, "err": None}
 
     def step():
