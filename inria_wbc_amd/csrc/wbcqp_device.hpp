@@ -404,13 +404,6 @@ __device__ __forceinline__ double dot8(const double* a, int sa, const double* b,
     return (s0 + s1) + (s2 + s3);
 }
 
-// row sum over the 16 lanes of a DPP row (every lane of the row gets the total)
-__device__ __forceinline__ double row16_sum(double v)
-{
-    WBCQP_ROW_REDUCE(v, op_add)
-    return v;
-}
-
 // packed upper-triangular R with one spare slot per column (column j holds rows 0..j+1):
 __device__ __forceinline__ int roff(int j) { return (j * (j + 3)) >> 1; }
 // first structurally non-zero column / one past the last of row i: H is block diagonal (dv block, one 12x12 block per contact)
@@ -445,13 +438,6 @@ __device__ __forceinline__ void compute_d(Ctx& c, int k0, int k1)
     if (c.tid < n) c.d[c.tid] = c.part[c.tid] + c.part[128 + c.tid];
     bsync();
 }
-// d = sign * J[row, :]   (np = sign * e_row); ends with a barrier
-__device__ __forceinline__ void compute_d_unit(Ctx& c, int row, double sign)
-{
-    if (c.tid < c.n) c.d[c.tid] = sign * c.J[(size_t)row * c.ldj + c.tid];
-    bsync();
-}
-
 // r = R[:iq,:iq]^-1 d[:iq] for the rows rlo..iq-1 on ONE wave (update_r): column-oriented back substitution, the pivot
 // travels by readlane, 1/R(j,j) and the column entries of four steps are fetched ahead of the dependent chain.
 __device__ __forceinline__ void update_r_wave(Ctx& c, int rlo)
@@ -717,42 +703,6 @@ __device__ __forceinline__ void build_eq_row(Ctx& c, int i, int& k0, int& k1, do
     }
 }
 
-// Decodes CI row ip from its packed descriptor: builds np in LDS, returns support, ci0, and for bound rows the column
-// (unit_col < 0 if not a unit row)
-__device__ __forceinline__ void build_ineq_row(Ctx& c, int ip, int& k0, int& k1, double& ci0, int& unit_col, double& unit_sign)
-{
-    const DevStruct& S = *c.S;
-    const int nv = c.nv, k = c.k, nu = c.nu, tid = c.tid;
-    const int mt = c.meta[ip];
-    const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
-    const bool neg = (mt >> 2) & 1;
-    const double sg = neg ? -1.0 : 1.0;
-    unit_col = -1;
-    unit_sign = sg;
-    if (kind == INEQ_BOUNDS) {
-        if (tid == 0) c.np[col] = sg;
-        k0 = col;
-        k1 = col + 1;
-        ci0 = neg ? c.bub[rr] : -c.blb[rr];
-        unit_col = col;
-    }
-    else if (kind == INEQ_ACTUATION) {
-        const int row = nu + rr;
-        if (tid < nv) c.np[tid] = sg * c.M[row * c.ldm + tid];
-        else if (tid < nv + k) c.np[tid] = -sg * c.Jc[(tid - nv) * c.ldc + row];
-        k0 = 0;
-        k1 = c.n;
-        ci0 = neg ? c.tu[rr] : -c.tl[rr];
-    }
-    else {
-        const double* B = S.fric_mat + (ct * 17 + rr) * 12;
-        if (tid < 12) c.np[nv + 12 * ct + tid] = sg * B[tid];
-        k0 = nv + 12 * ct;
-        k1 = k0 + 12;
-        ci0 = neg ? S.fric_ub[ct * 17 + rr] : -S.fric_lb[ct * 17 + rr];
-    }
-}
-
 // What one thread keeps about the (at most two) rows of s it owns: rows tid and tid + 256
 struct OwnRows {
     int meta[2];
@@ -783,53 +733,6 @@ __device__ __forceinline__ void own_rows_init(Ctx& c, OwnRows& o, const double* 
             }
         }
     }
-}
-
-// tau' = M_a dv - J_a' f into c.part[0..na): 16 lanes (one DPP row) per actuated row, partial sums meet inside the row
-__device__ __forceinline__ void actuation_product(Ctx& c)
-{
-    const int nv = c.nv, nu = c.nu, n = c.n, na = c.na;
-    const int kc = c.tid & 15;
-    for (int r0 = 0; r0 < na; r0 += 16) {
-        const int rr = r0 + (c.tid >> 4);
-        const int row = nu + min(rr, na - 1);
-        const double* Mr = c.M + row * c.ldm;
-        double acc = 0.0;
-        for (int j = kc; j < nv; j += 16) acc = fma(Mr[j], c.x[j], acc);
-        for (int j = nv + ((kc - nv) & 15); j < n; j += 16) acc = fma(-c.Jc[(j - nv) * c.ldc + row], c.x[j], acc);
-        acc = row16_sum(acc);
-        if (kc == 0 && rr < na) c.part[rr] = acc;
-    }
-}
-
-// s = CI x + ci0 for the rows this thread owns (needs actuation_product + barrier first). Returns sum of min(s, 0).
-__device__ __forceinline__ double compute_s_owned(Ctx& c, const OwnRows& o)
-{
-    double psi = 0.0;
-#pragma unroll
-    for (int z2 = 0; z2 < 2; ++z2) {
-        const int mt = o.meta[z2];
-        if (mt >= 0) {
-            const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
-            const bool neg = (mt >> 2) & 1;
-            double v;
-            if (kind == INEQ_BOUNDS) v = neg ? -c.x[col] : c.x[col];
-            else if (kind == INEQ_ACTUATION) v = neg ? -c.part[rr] : c.part[rr];
-            else {
-                const double* f = c.x + c.nv + 12 * ct;
-                double a = 0.0;
-#pragma unroll
-                for (int m = 0; m < 12; ++m) a = fma(o.coef[z2][m], f[m], a);
-                v = a;
-            }
-            v += o.ci0[z2];
-            const int i = c.tid + z2 * kThreads;
-            c.s[i] = v;
-            c.iaexcl[i] = 1;
-            psi += fmin(0.0, v);
-        }
-    }
-    return psi;
 }
 
 // tau' = M_a xn - J_a' fn with xn = x + t z formed on the fly (t = 0: xn = x exactly), four lanes per actuated row,
@@ -915,7 +818,6 @@ __device__ __forceinline__ void own_rows_eval(Ctx& c, const OwnRows& o, const do
     }
 }
 
-// global -> LDS copy, all 256 threads, 4 loads in flight per thread
 // R rounds of 256 elements into registers; indices are clamped instead of masked so that the loads stay unconditional
 // (a predicated load becomes an exec-mask branch and splits the block the scheduler works in).  len >= 1.
 template <typename TI, int R>
@@ -933,21 +835,6 @@ __device__ __forceinline__ void st_regs(double* dst, int len, int tid, const TI 
         if (e < len) dst[e] = (double)v[u];
     }
 }
-
-template <typename TI>
-__device__ __forceinline__ void copy_in(const TI* __restrict__ src, double* dst, int len, int tid)
-{
-    int e = tid;
-    for (; e + 3 * kThreads < len; e += 4 * kThreads) {
-        TI v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = src[e + u * kThreads];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) dst[e + u * kThreads] = (double)v[u];
-    }
-    for (; e < len; e += kThreads) dst[e] = (double)src[e];
-}
-
 
 // sum over the 8 lanes of an aligned lane group (every lane of the group gets the total)
 __device__ __forceinline__ double grp8_sum(double v)
