@@ -169,6 +169,10 @@ def main():
                            "iters_hist": np.bincount(np.minimum(iters, 15), minlength=16).tolist(),
                            "status_optimal": int((status == 0).sum()), "batch": int(B)},
         }
+        flops = st.flops_estimate(float(iters.mean()))
+        result["fp64"] = {"flops_per_qp": flops, "achieved_TFLOPs": flops * B / kern_avg_s / 1e12,
+                          "note": "analytic useful flops (Structure.flops_estimate) at the batch's mean iteration count; the path is a "
+                                  "chain of dependent operations, see DESIGN.md section 4"}
         if gather_state["err"]:
             result["config"]["allgather_error"] = gather_state["err"]
         if world == 1 and args.robot == "talos":

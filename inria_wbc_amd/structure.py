@@ -198,6 +198,19 @@ class Structure:
             "w": self.n_tasks,
         }
 
+    def flops_estimate(self, iters: float = 0.0) -> float:
+        """Analytic count of the fp64 flops one QP needs on the blocked path (multiply and add counted separately):
+        assembly, elimination H -> J, x0, B = J'N, Householder QR, J Q, and `iters` active-set iterations."""
+        nv, n, m, k = self.nv, self.n, self.neq, self.k
+        asm = self.n_dense * nv * (nv + 1)
+        elim = 4.0 * nv ** 3 / 3.0 + self.nc * 4.0 * 12 ** 3 / 3.0
+        x0 = 2.0 * (nv * nv + self.nc * 144)
+        b = m * (nv * (nv + 1) + self.nc * 12 * 13)
+        qr = 2.0 * n * m * m - 2.0 * m ** 3 / 3.0
+        jq = 4.0 * n * n * m
+        per_iter = 2.0 * (n * n + n * (n - m) + n * (n - m)) + 2.0 * self.na * n + 24.0 * 17 * 2 * self.nc
+        return asm + elim + x0 + b + qr + jq + iters * per_iter
+
     def algorithmic_bytes(self, itemsize: int = 8) -> int:
         """Compact-boundary bytes per QP: inputs + x + tau + status/iters."""
         n_in = sum(self.field_lengths().values())
