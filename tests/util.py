@@ -22,13 +22,33 @@ def load_golden():
     return cases
 
 
+TOL_RAW_FORCE = 1e-4  # contact-point forces: their internal-force null space is held by the 1e-8 regulariser only
+
+
 def assert_parity(st, got, ref, tol=TOL_F64, what=""):
-    """got/ref: dicts with x, tau, status, iters ([B, ...])."""
+    """got/ref: dicts with x, tau, status, iters ([B, ...]).  dv, the contact wrenches T f and tau must agree to `tol`
+    (relative to max(1, |.|inf)); the raw contact-point forces f only to TOL_RAW_FORCE: H_ff = w F'F + 1e-8 I has rank-6
+    F'F, so six directions of f per contact are conditioned like 1e12 (seen: |df| 1.6e-3 on |f| 215 with dv, T f and tau
+    equal to 1e-9, tools/stress_parity.py)."""
     assert np.array_equal(got["status"], ref["status"]), (what, got["status"], ref["status"])
     ok = ref["status"] == 0
-    xs = np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
-    ex = np.abs(got["x"] - ref["x"]).max(axis=1) / xs
-    assert (ex[ok] <= tol).all(), (what, "x", ex.max(), int(ex.argmax()))
+    nv = st.nv
+    gx, rx = np.asarray(got["x"]), np.asarray(ref["x"])
+    xs = np.maximum(1.0, np.abs(rx).max(axis=1))
+    ev = np.abs(gx[:, :nv] - rx[:, :nv]).max(axis=1) / xs
+    assert (ev[ok] <= tol).all(), (what, "dv", ev.max(), int(ev.argmax()))
+    ex = ev.copy()
+    if st.nc:
+        T = np.asarray(st.force_gen()).reshape(st.nc, 6, 12)
+        gf = gx[:, nv:].reshape(-1, st.nc, 12)
+        rf = rx[:, nv:].reshape(-1, st.nc, 12)
+        gw, rw = np.einsum("cij,bcj->bci", T, gf), np.einsum("cij,bcj->bci", T, rf)
+        ws = np.maximum(1.0, np.abs(rw).reshape(len(rx), -1).max(axis=1))
+        ew = np.abs(gw - rw).reshape(len(rx), -1).max(axis=1) / ws
+        assert (ew[ok] <= tol).all(), (what, "contact wrench", ew.max(), int(ew.argmax()))
+        ef = np.abs(gf - rf).reshape(len(rx), -1).max(axis=1) / xs
+        assert (ef[ok] <= TOL_RAW_FORCE).all(), (what, "raw contact forces", ef.max(), int(ef.argmax()))
+        ex = np.maximum(ev, ew)
     if st.na:
         ts = np.maximum(1.0, np.abs(ref["tau"]).max(axis=1))
         et = np.abs(got["tau"] - ref["tau"]).max(axis=1) / ts
