@@ -15,7 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwbcqp.so")
 SOURCES = ["wbcqp_api.hip"]
-HEADERS = ["wbcqp_device.hpp", os.path.join("..", "..", "include", "wbcqp.h")]
+HEADERS = ["wbcqp_device.hpp", "wbcqp_types.hpp", "wbcqp_prims.hpp", "wbcqp_factor.hpp", "wbcqp_equality.hpp", "wbcqp_activeset.hpp",
+           "wbcqp_integrate.hpp", os.path.join("..", "..", "include", "wbcqp.h")]
 ARCH = "gfx950"
 
 

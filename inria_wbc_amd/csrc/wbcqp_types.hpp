@@ -1,0 +1,88 @@
+// wbcqp_types.hpp -- constants and the structures shared by the host API and the kernels: LDS slot map, the
+// per-structure description that travels by value with every launch, per-group launch arguments.
+#pragma once
+
+#include <stdint.h>
+
+namespace wbcqp {
+constexpr int kWave = 64;
+constexpr int kThreads = 256; // threads per QP
+constexpr int kWaves = kThreads / kWave;
+constexpr int kMaxBlocks = 16;
+constexpr int kMaxGroups = 8;
+
+// All small per-QP vectors live at FIXED offsets (multiples of kSlot doubles) from one LDS base, so that the compiler
+// addresses them with immediates instead of keeping ~40 wave-uniform pointers alive in SGPRs (they spilled).
+// Limits that make this legal are checked on the host: n <= 126, n_tasks, n_dense, n_bound, na, 6 nc <= 128,
+// level-1 rows <= 256, one-sided inequality rows <= 512.
+constexpr int kSlot = 128;
+enum VecSlot {
+    V_H = 0, V_X, V_NP, V_D, V_Z, V_XOLD, V_R, V_U, V_UOLD, V_Q, V_G, V_W, V_WROW, V_BLB, V_BUB, V_TL, V_TU, V_BC,
+    V_RDINV, V_DINV, V_RED,
+    V_PRM,              // 2 slots
+    V_B1 = V_PRM + 2,   // 2 slots
+    V_S = V_B1 + 2,     // 4 slots
+    V_STASH = V_S + 4,  // 2 slots
+    V_PART = V_STASH + 2, // 5 slots
+    V_COUNT = V_PART + 5
+};
+constexpr int kIntA = 0, kIntAold = 128, kIntGskip = 256, kIntIai = 384, kIntIaexcl = 896, kIntMeta = 1408, kIntCount = 1920;
+// packed row descriptor: bits 0-1 kind, bit 2 negated copy (-A row), bits 3-10 local row, bits 11-14 contact, bits 15-22 column
+__host__ __device__ inline int row_meta_pack(int kind, int neg, int rr, int ct, int col) { return kind | (neg << 2) | (rr << 3) | (ct << 11) | (col << 15); }
+
+enum { INEQ_BOUNDS = 0, INEQ_ACTUATION = 1, INEQ_FORCE = 2 };
+enum { HQP_UNKNOWN = -1, HQP_OPTIMAL = 0, HQP_INFEASIBLE = 1, HQP_UNBOUNDED = 2, HQP_MAX_ITER = 3, HQP_ERROR = 4 };
+
+// Constant structure of a task stack, resident in device memory (one per slot).
+// inequality blocks in task-stack order (host side only: the device works from the packed row descriptors)
+struct HostBlocks {
+    int n_blocks;
+    int blk_kind[kMaxBlocks], blk_arg[kMaxBlocks], blk_off[kMaxBlocks], blk_rows[kMaxBlocks];
+};
+
+struct DevStruct {
+    int nv, na, nc, k, n, nu;
+    int n_dense, n_tasks, n_sel, n_bound, act_bounds;
+    int neq, nin2, r1;
+    int max_iter;
+    double hessian_reg;
+    const int *dense_row_task, *sel_col, *sel_task, *forcereg_task, *bound_col;
+    const double *force_gen; // [nc][6][12]
+    const double *ftf;       // [nc][12][12]  F'F,  F = diag(w_f) T
+    const double *ft;        // [nc][12][6]   F'
+    const double *fric_mat, *fric_lb, *fric_ub;
+    const int* rowmeta;      // [nin2] packed descriptor of every one-sided inequality row (see row_meta_*)
+    const unsigned* mpack;   // [nv(nv+1)/2] packed-M element e=(i,j) -> LDS offsets (i ldm + j) | (j ldm + i) << 16
+    const unsigned* apack;   // [n_dense nv] task-row element (r, col) -> offset r 64 + (col & 15) 4 + (col >> 4) in the staged rows
+    // LDS layout: leading dimensions and element offsets (in doubles)
+    int ldj, ldm, ldc, ldb;
+    int o_J, o_R, o_M, o_Jc, o_Ac, o_vec, o_eqw, o_eqt;
+    int o_int; // int area (fixed slots, see kInt*)
+    int fric_lds; // 1: the friction tables (238 doubles per contact) fit the equality-phase scratch, which is free in the inequality loop
+    int lds_doubles;
+};
+
+template <typename TI>
+struct GroupArgs {
+    DevStruct st; // by value: the sizes, offsets and table pointers arrive with the kernel arguments, not behind a pointer
+    const TI *M, *h, *A, *b1, *Ac, *bc, *blb, *bub, *tlb, *tub, *w;
+    TI *x, *tau, *objective;
+    int *status, *iters, *n_active;
+    long long* dbg; // per-QP phase cycle counters, only written by the WBCQP_STAMPS diagnostic build
+    int count;
+};
+
+template <typename TI>
+struct GroupTable {
+    int n;
+    const int* order; // launch order -> QP index (longest-first schedule of the previous launch of this shape), or null
+    GroupArgs<TI> g[kMaxGroups];
+};
+
+// iteration counts of the launch just finished, for the schedule of the next one
+struct ScheduleArgs {
+    int n;
+    const int* iters[kMaxGroups];
+    int count[kMaxGroups];
+};
+} // namespace wbcqp
