@@ -57,7 +57,7 @@ class _BatchOutputs(C.Structure):
 def build(force: bool = False) -> str:
     """Compile oracle/wbc_oracle.c with the committed Makefile (gcc)."""
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("wbc_oracle.c", "wbc_oracle.h", "Makefile")):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("wbc_oracle.c", "wbc_oracle.h", "rbd_oracle.c", "rbd_oracle.h", "Makefile")):
         subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
