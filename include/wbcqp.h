@@ -211,6 +211,82 @@ int wbcqp_integrate_host(wbcqp_handle* handle, int batch, int nv, int floating_b
                          const void* q, const void* dq, const void* x, int ldx, const int32_t* status,
                          void* q_next, void* v_next, void* q_solver);
 
+/* ---- Before the path: from the robot state to the rows of the QP -------------------------
+ * What the upstream half of tsid_->computeProblemData (controller.cpp:244) produces: pinocchio's rigid-body terms (call
+ * set of RobotModel::update, src/utils/robot_model.cpp:83-113) and every task's compute() (example_project/src/tsid/
+ * ex_task.cpp:175-247, src/tsid/task-momentum-equality.cpp:144-173, src/tsid/task-self-collision.cpp:84-203, gains and
+ * masks of src/controllers/tasks.cpp:38-404).  The kinematic tree and the task bindings are DATA (no URDF / YAML parser
+ * behind this boundary). */
+typedef enum { WBCQP_J_FREEFLYER = 0, WBCQP_J_RX = 1, WBCQP_J_RY = 2, WBCQP_J_RZ = 3, WBCQP_J_PX = 4, WBCQP_J_PY = 5, WBCQP_J_PZ = 6 } wbcqp_joint_type;
+typedef enum { WBCQP_T_SE3 = 0, WBCQP_T_COM = 1, WBCQP_T_MOMENTUM = 2, WBCQP_T_SELFCOLLISION = 3 } wbcqp_task_kind;
+
+/* A kinematic tree (what pinocchio::Model holds).  Bodies are numbered depth-first (parent[i] < i and every subtree is a
+ * contiguous index range, as pinocchio numbers joints); body 0 hangs on the world by a free-flyer (floating_base: q =
+ * [p, quat(x,y,z,w)], v = [linear, angular] in the body frame) or by its own joint.  nq = nbody + 6 / nbody,
+ * nv = nbody + 5 / nbody.  Placements are 12 doubles: rotation row-major (9), translation (3).  HOST pointers. */
+typedef struct {
+    int32_t nbody, floating_base;
+    const int32_t* parent;         /* [nbody], -1 for body 0 */
+    const int32_t* jtype;          /* [nbody] wbcqp_joint_type */
+    const double* placement;       /* [nbody][12] joint frame in the parent's joint frame */
+    const double* inertia;         /* [nbody][10] mass, centre of mass (3), inertia at the com: xx xy xz yy yz zz */
+    double gravity[3];             /* pinocchio's default (0, 0, -9.81) */
+    int32_t nframe;
+    const int32_t* frame_body;     /* [nframe] */
+    const double* frame_placement; /* [nframe][12] frame in its body's joint frame */
+    const double* q_lb;            /* [na] position limits of the actuated joints (tasks.cpp:291-292) */
+    const double* q_ub;            /* [na] */
+    const double* dq_max;          /* [na] velocity limits (tasks.cpp:287); acceleration limit = dq_max / dt (:288) */
+} wbcqp_model;
+
+/* One level-1 task that yields dense rows, in the order of the addMotionTask calls (= file order of tasks.yaml, with the
+ * self-collision tasks last as in the shipped stacks): its rows are consecutive in wbcqp_inputs.A / b1. */
+typedef struct {
+    int32_t kind;    /* wbcqp_task_kind */
+    int32_t frame;   /* tracked frame (SE3, self-collision) */
+    int32_t mask;    /* bit i = row i kept (tasks.cpp:27-35 convert_mask: character i of the yaml string) */
+    double kp, kd;
+    int32_t ref;     /* offset of the task's reference inside one instance's reference vector:
+                        SE3: placement 12 (translation, rotation COLUMN-major: tsid SE3ToVector, src/trajs/loader.cpp:11-53),
+                             velocity 6, acceleration 6 (world-oriented);  CoM: pos 3, vel 3, acc 3;
+                             momentum: reference 6, its derivative 6;  self-collision: none */
+    int32_t n_avoided;              /* self-collision */
+    const int32_t* avoided_frame;   /* [n_avoided] */
+    const double* avoided_r0;       /* [n_avoided] */
+    double radius, margin, m;       /* self-collision (tasks.cpp:380-383) */
+} wbcqp_task;
+
+typedef struct {
+    int32_t n_task;
+    const wbcqp_task* task;
+    double posture_kp, posture_kd;  /* the structure's selection rows (tasks.cpp:181-224) */
+    int32_t posture_ref;            /* offset of the na reference positions */
+    int32_t n_contact;              /* must equal the structure's nc */
+    const int32_t* contact_frame;   /* [n_contact] */
+    const double* contact_kp;       /* [n_contact] (tasks.cpp:359-360) */
+    const double* contact_kd;
+    const int32_t* contact_ref;     /* [n_contact] offset of the 12-number reference placement (tasks.cpp:361-362) */
+    int32_t bounds;                 /* 1: the structure's n_bound = na joint-bounds rows are computed (tasks.cpp:274-300) */
+    double dt;                      /* CONTROLLER.dt */
+    int32_t nref;                   /* reference doubles per instance */
+} wbcqp_taskmap;
+
+typedef struct {
+    const void* q;    /* [batch][nq] */
+    const void* v;    /* [batch][nv] */
+    const void* ref;  /* [batch][nref] */
+} wbcqp_state;
+
+/* Binds a tree and its task bindings to a slot that already holds the matching structure (same nv, na, nc, n_dense,
+ * n_sel, n_bound). */
+int wbcqp_set_model(wbcqp_handle* handle, int slot, const wbcqp_model* model, const wbcqp_taskmap* map);
+/* Writes the M, h, A, b1, Ac, bc, blb, bub arrays of `rows` (DEVICE pointers, the layout wbcqp_solve_batch reads; tlb, tub
+ * and w are not touched: constant limits and weights) for `batch` instances.  Asynchronous on `stream`. */
+int wbcqp_problem_data(wbcqp_handle* handle, int slot, int batch, const wbcqp_state* state, const wbcqp_inputs* rows,
+                       void* stream);
+/* Same with HOST pointers; blocks until done. */
+int wbcqp_problem_data_host(wbcqp_handle* handle, int slot, int batch, const wbcqp_state* state, const wbcqp_inputs* rows);
+
 int wbcqp_sync(wbcqp_handle* handle, void* stream);
 
 #ifdef __cplusplus

@@ -16,7 +16,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwbcqp.so")
 SOURCES = ["wbcqp_api.hip"]
 HEADERS = ["wbcqp_device.hpp", "wbcqp_types.hpp", "wbcqp_prims.hpp", "wbcqp_factor.hpp", "wbcqp_equality.hpp", "wbcqp_activeset.hpp",
-           "wbcqp_integrate.hpp", os.path.join("..", "..", "include", "wbcqp.h")]
+           "wbcqp_integrate.hpp", "wbcqp_terms.hpp", os.path.join("..", "..", "include", "wbcqp.h")]
 ARCH = "gfx950"
 
 

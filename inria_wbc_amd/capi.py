@@ -24,7 +24,9 @@ FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
 # every symbol include/wbcqp.h declares
 EXPORTS = ("wbcqp_version", "wbcqp_last_error", "wbcqp_create", "wbcqp_destroy", "wbcqp_set_structure",
            "wbcqp_layout_of", "wbcqp_solve_batch", "wbcqp_solve_batch_host", "wbcqp_solve_ragged",
-           "wbcqp_allgather_tau", "wbcqp_integrate", "wbcqp_integrate_host", "wbcqp_sync")
+           "wbcqp_allgather_tau", "wbcqp_integrate", "wbcqp_integrate_host", "wbcqp_set_model", "wbcqp_problem_data",
+           "wbcqp_problem_data_host", "wbcqp_sync")
+ROW_FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub")  # what wbcqp_problem_data writes
 
 c_i32_p = C.POINTER(C.c_int32)
 c_f64_p = C.POINTER(C.c_double)
@@ -72,6 +74,28 @@ class CGroup(C.Structure):
     _fields_ = [("slot", C.c_int32), ("batch", C.c_int32), ("inp", CInputs), ("out", COutputs)]
 
 
+class CModel(C.Structure):
+    _fields_ = [("nbody", C.c_int32), ("floating_base", C.c_int32), ("parent", c_i32_p), ("jtype", c_i32_p), ("placement", c_f64_p),
+                ("inertia", c_f64_p), ("gravity", C.c_double * 3), ("nframe", C.c_int32), ("frame_body", c_i32_p),
+                ("frame_placement", c_f64_p), ("q_lb", c_f64_p), ("q_ub", c_f64_p), ("dq_max", c_f64_p)]
+
+
+class CTask(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("frame", C.c_int32), ("mask", C.c_int32), ("kp", C.c_double), ("kd", C.c_double), ("ref", C.c_int32),
+                ("n_avoided", C.c_int32), ("avoided_frame", c_i32_p), ("avoided_r0", c_f64_p), ("radius", C.c_double),
+                ("margin", C.c_double), ("m", C.c_double)]
+
+
+class CTaskMap(C.Structure):
+    _fields_ = [("n_task", C.c_int32), ("task", C.POINTER(CTask)), ("posture_kp", C.c_double), ("posture_kd", C.c_double),
+                ("posture_ref", C.c_int32), ("n_contact", C.c_int32), ("contact_frame", c_i32_p), ("contact_kp", c_f64_p),
+                ("contact_kd", c_f64_p), ("contact_ref", c_i32_p), ("bounds", C.c_int32), ("dt", C.c_double), ("nref", C.c_int32)]
+
+
+class CState(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("v", C.c_void_p), ("ref", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -101,8 +125,53 @@ def load_library(path: Optional[str] = None):
     lib.wbcqp_sync.argtypes = [C.c_void_p, C.c_void_p]
     lib.wbcqp_integrate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.wbcqp_set_model.argtypes = [C.c_void_p, C.c_int, C.POINTER(CModel), C.POINTER(CTaskMap)]
+    lib.wbcqp_problem_data.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CState), C.POINTER(CInputs), C.c_void_p]
+    lib.wbcqp_problem_data_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CState), C.POINTER(CInputs)]
     _lib = lib
     return lib
+
+
+class ModelBuffers:
+    """Host-side wbcqp_model + wbcqp_taskmap built from a `model.Model` and a `model.TaskMap`; keeps the arrays alive."""
+
+    def __init__(self, model, tm):
+        self._keep = []
+
+        def keep(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            if a.size == 0:
+                a = np.zeros(1, dtype=dtype)
+            self._keep.append(a)
+            return a
+
+        ip = lambda a: keep(a, np.int32).ctypes.data_as(c_i32_p)
+        dp = lambda a: keep(a, np.float64).ctypes.data_as(c_f64_p)
+        m = CModel()
+        m.nbody, m.floating_base = model.nbody, int(model.floating_base)
+        m.parent, m.jtype = ip(model.parent), ip(model.jtype)
+        m.placement, m.inertia = dp(model.placement), dp(model.inertia)
+        m.gravity[:] = model.gravity
+        m.nframe = model.nframe
+        m.frame_body, m.frame_placement = ip(model.frame_body), dp(model.frame_placement)
+        m.q_lb, m.q_ub, m.dq_max = dp(model.q_lb), dp(model.q_ub), dp(model.dq_max)
+        tasks = (CTask * max(1, len(tm.blocks)))()
+        for i, b in enumerate(tm.blocks):
+            t = tasks[i]
+            t.kind, t.frame, t.mask, t.kp, t.kd, t.ref = b.kind, b.frame, b.mask, b.kp, b.kd, b.ref
+            t.n_avoided = len(b.avoided)
+            t.avoided_frame = ip([f for f, _ in b.avoided])
+            t.avoided_r0 = dp([r for _, r in b.avoided])
+            t.radius, t.margin, t.m = b.radius, b.margin, b.m
+        self._tasks = tasks
+        k = CTaskMap()
+        k.n_task = len(tm.blocks)
+        k.task = C.cast(tasks, C.POINTER(CTask))
+        k.posture_kp, k.posture_kd, k.posture_ref = tm.posture_kp, tm.posture_kd, tm.posture_ref
+        k.n_contact = tm.ncontact
+        k.contact_frame, k.contact_kp, k.contact_kd, k.contact_ref = ip(tm.contact_frame), dp(tm.contact_kp), dp(tm.contact_kd), ip(tm.contact_ref)
+        k.bounds, k.dt, k.nref = int(tm.n_bound > 0), tm.dt, tm.nref
+        self.model, self.taskmap = m, k
 
 
 class StructureBuffers:
@@ -232,6 +301,41 @@ class Handle:
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(self.lib.wbcqp_integrate(self._h, batch, nv, 1 if floating_base else 0, float(dt), ptr(q), ptr(dq), ptr(x), ldx,
                                              ptr(status), ptr(q_next), ptr(v_next), ptr(q_solver), C.c_void_p(stream)))
+
+    def set_model(self, slot: int, model, tm):
+        """Binds a kinematic tree and its task bindings to a slot that holds the matching structure (wbcqp_set_model)."""
+        mb = ModelBuffers(model, tm)
+        self._check(self.lib.wbcqp_set_model(self._h, slot, C.byref(mb.model), C.byref(mb.taskmap)))
+        self._models = getattr(self, "_models", {})
+        self._models[slot] = (model, tm)
+
+    def problem_data(self, slot: int, batch: int, state: Dict[str, "object"], rows: Dict[str, "object"], stream: int = 0):
+        """q, v, ref -> M, h, A, b1, Ac, bc, blb, bub on device tensors (wbcqp_problem_data)."""
+        st = self._structs[slot]
+        L = st.field_lengths()
+        cs = CState(state["q"].data_ptr(), state["v"].data_ptr(), state["ref"].data_ptr() if state.get("ref") is not None else None)
+        cin = CInputs()
+        for k in FIELDS:
+            t = rows.get(k)
+            if k not in ROW_FIELDS or L[k] == 0 or t is None:
+                setattr(cin, k, None)
+                continue
+            assert t.is_cuda and t.is_contiguous() and t.numel() == batch * L[k], (k, tuple(t.shape), batch, L[k])
+            setattr(cin, k, t.data_ptr())
+        self._check(self.lib.wbcqp_problem_data(self._h, slot, batch, C.byref(cs), C.byref(cin), C.c_void_p(stream)))
+
+    def problem_data_host(self, slot: int, q: np.ndarray, v: np.ndarray, ref: np.ndarray) -> Dict[str, np.ndarray]:
+        st = self._structs[slot]
+        L = st.field_lengths()
+        q, v, ref = (np.ascontiguousarray(a, dtype=self.np_dtype) for a in (q, v, ref))
+        batch = q.shape[0]
+        out = {k: np.zeros((batch, max(L[k], 1)), self.np_dtype) for k in ROW_FIELDS}
+        cs = CState(q.ctypes.data, v.ctypes.data, ref.ctypes.data)
+        cin = CInputs()
+        for k in FIELDS:
+            setattr(cin, k, out[k].ctypes.data if k in ROW_FIELDS and L[k] else None)
+        self._check(self.lib.wbcqp_problem_data_host(self._h, slot, batch, C.byref(cs), C.byref(cin)))
+        return {k: a[:, :L[k]] for k, a in out.items()}
 
     def sync(self, stream: int = 0):
         self._check(self.lib.wbcqp_sync(self._h, C.c_void_p(stream)))

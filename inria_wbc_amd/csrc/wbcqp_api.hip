@@ -5,11 +5,14 @@
 // solver_->solve) plus the decode at :250-251.  There is no CPU path in this library: without a
 // gfx950 device wbcqp_create fails with WBCQP_ERR_NO_DEVICE.
 #include "wbcqp_device.hpp"
+#include "wbcqp_terms.hpp"
 
 #include "../../include/wbcqp.h"
 
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -27,6 +30,9 @@ struct Slot {
     DevStruct host{};           // sizes, LDS layout and device pointers of the tables: travels by value with every launch
     std::vector<void*> allocs;  // device arrays owned by this slot
     wbcqp_layout layout{};
+    bool has_model = false;     // wbcqp_set_model: tree + task bindings for wbcqp_problem_data
+    TermsDev terms{};
+    std::vector<void*> model_allocs;
 };
 
 struct Staging {
@@ -170,11 +176,19 @@ int upload(wbcqp_handle* h, Slot& s, const T* src, size_t count, const T** dst)
     return WBCQP_OK;
 }
 
+void release_model(Slot& s)
+{
+    for (void* p : s.model_allocs) (void)hipFree(p);
+    s.model_allocs.clear();
+    s.has_model = false;
+}
+
 void release(Slot& s)
 {
     for (void* p : s.allocs) (void)hipFree(p);
     s.allocs.clear();
     s.set = false;
+    release_model(s);
 }
 
 template <typename TI>
@@ -582,6 +596,251 @@ int wbcqp_integrate_host(wbcqp_handle* h, int batch, int nv, int floating_base, 
     HIP_TRY(h, hipMemcpy(q_next, dout, (size_t)batch * nq * es, hipMemcpyDeviceToHost));
     HIP_TRY(h, hipMemcpy(v_next, dout + bq, (size_t)batch * nv * es, hipMemcpyDeviceToHost));
     if (q_solver) HIP_TRY(h, hipMemcpy(q_solver, dout + bq + bv, (size_t)batch * nv * es, hipMemcpyDeviceToHost));
+    return WBCQP_OK;
+}
+
+int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcqp_taskmap* tm)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES || !h->slots[slot].set) return fail(h, WBCQP_ERR_INVALID, "slot has no structure");
+    if (!md || !tm) return fail(h, WBCQP_ERR_INVALID, "model / taskmap is NULL");
+    Slot& s = h->slots[slot];
+    const DevStruct& D = s.host;
+    const int nb = md->nbody, fb = md->floating_base ? 1 : 0;
+    if (nb <= 0 || !md->parent || !md->jtype || !md->placement || !md->inertia) return fail(h, WBCQP_ERR_INVALID, "empty model");
+    if (nb > kWave) return fail(h, WBCQP_ERR_UNSUPPORTED, "more than 64 bodies (one lane per body)");
+    const int nv = nb + (fb ? 5 : 0), nq = nb + (fb ? 6 : 0), na = nv - (fb ? 6 : 0);
+    if (nv != D.nv || na != D.na) return fail(h, WBCQP_ERR_INVALID, "model and structure disagree on nv / na");
+    if (tm->n_contact != D.nc) return fail(h, WBCQP_ERR_INVALID, "taskmap and structure disagree on the number of contacts");
+    if ((tm->bounds ? na : 0) != D.n_bound) return fail(h, WBCQP_ERR_INVALID, "taskmap and structure disagree on the bounds rows");
+    if (tm->n_task < 0 || (tm->n_task > 0 && !tm->task) || tm->nref < 0 || !(tm->dt > 0.0)) return fail(h, WBCQP_ERR_INVALID, "bad taskmap");
+    // tree: parents first, depth-first numbering (a subtree is a contiguous range)
+    std::vector<int> depth(nb, 0), last(nb), idxq(nb), idxv(nb), bodyof(nv), kof(nv);
+    for (int i = 0; i < nb; ++i) {
+        last[i] = i;
+        if (i == 0 ? md->parent[0] != -1 : (md->parent[i] < 0 || md->parent[i] >= i)) return fail(h, WBCQP_ERR_INVALID, "parent[i] must be in [0, i), -1 for body 0");
+        const int jt = md->jtype[i];
+        if (jt < WBCQP_J_FREEFLYER || jt > WBCQP_J_PZ || ((jt == WBCQP_J_FREEFLYER) != (fb && i == 0)))
+            return fail(h, WBCQP_ERR_INVALID, "joint type out of range, or a free-flyer that is not body 0 of a floating-base model");
+        if (i) depth[i] = depth[md->parent[i]] + 1;
+        idxq[i] = fb ? (i == 0 ? 0 : 6 + i) : i;
+        idxv[i] = fb ? (i == 0 ? 0 : 5 + i) : i;
+    }
+    for (int i = nb - 1; i > 0; --i) last[md->parent[i]] = std::max(last[md->parent[i]], last[i]);
+    for (int i = 1; i < nb; ++i) {
+        // depth-first: the parent of i is the body just before it or one of that body's ancestors
+        bool on_path = false;
+        for (int b = i - 1; b >= 0 && !on_path; b = md->parent[b]) on_path = (b == md->parent[i]);
+        if (!on_path) return fail(h, WBCQP_ERR_INVALID, "bodies are not numbered depth-first");
+    }
+    int maxdepth = 0;
+    for (int i = 0; i < nb; ++i) {
+        maxdepth = std::max(maxdepth, depth[i]);
+        const int cnt = (md->jtype[i] == WBCQP_J_FREEFLYER) ? 6 : 1;
+        for (int k = 0; k < cnt; ++k) { bodyof[idxv[i] + k] = i; kof[idxv[i] + k] = k; }
+    }
+    auto frame_ok = [&](int f) { return f >= 0 && f < md->nframe && md->frame_body[f] >= 0 && md->frame_body[f] < nb; };
+    // tasks -> law lanes (SE3 blocks then contacts), self-collision pairs, blocks
+    std::vector<int> law_body, law_mask, law_row, law_ref, law_va, law_contact, pair_block, pair_bt, pair_ba;
+    std::vector<int> blk_kind, blk_mask, blk_row, blk_ref, blk_law, blk_pair0, blk_npair;
+    std::vector<double> law_place, law_kp, law_kd, pair_pt, pair_pa, pair_par, blk_kp, blk_kd;
+    auto popc = [](int m, int bits) { int c = 0; for (int i = 0; i < bits; ++i) c += (m >> i) & 1; return c; };
+    int row = 0;
+    for (int t = 0; t < tm->n_task; ++t) {
+        const wbcqp_task& K = tm->task[t];
+        blk_kind.push_back(K.kind); blk_mask.push_back(K.mask); blk_row.push_back(row); blk_ref.push_back(K.ref);
+        blk_kp.push_back(K.kp); blk_kd.push_back(K.kd);
+        blk_law.push_back(-1); blk_pair0.push_back((int)pair_block.size()); blk_npair.push_back(0);
+        int need = 0;
+        if (K.kind == WBCQP_T_SE3) {
+            if (!frame_ok(K.frame)) return fail(h, WBCQP_ERR_INVALID, "SE3 task tracks a frame that does not exist");
+            blk_law.back() = (int)law_body.size();
+            law_body.push_back(md->frame_body[K.frame]); law_mask.push_back(K.mask & 63); law_row.push_back(row);
+            law_ref.push_back(K.ref); law_va.push_back(1); law_contact.push_back(-1);
+            law_kp.push_back(K.kp); law_kd.push_back(K.kd);
+            law_place.insert(law_place.end(), md->frame_placement + 12 * K.frame, md->frame_placement + 12 * K.frame + 12);
+            row += popc(K.mask, 6); need = 24;
+        }
+        else if (K.kind == WBCQP_T_COM) { row += popc(K.mask, 3); need = 9; blk_mask.back() = K.mask & 7; }
+        else if (K.kind == WBCQP_T_MOMENTUM) { row += popc(K.mask, 6); need = 12; blk_mask.back() = K.mask & 63; }
+        else if (K.kind == WBCQP_T_SELFCOLLISION) {
+            if (!frame_ok(K.frame) || K.n_avoided < 0 || (K.n_avoided > 0 && (!K.avoided_frame || !K.avoided_r0)))
+                return fail(h, WBCQP_ERR_INVALID, "bad self-collision task");
+            if (!(K.m > 0.0) || !(K.margin > 0.0)) return fail(h, WBCQP_ERR_INVALID, "self-collision needs m > 0 and margin > 0");
+            // constants of the 5PL repulsor (task-self-collision.cpp:147-149)
+            const double k5 = -std::log(std::pow(-1e-5 + 1., -1. / K.m) - 1.) / K.margin;
+            const double s_p = -1. / k5 * std::log(-1 + std::pow(2, 1. / K.m));
+            for (int a = 0; a < K.n_avoided; ++a) {
+                const int fa = K.avoided_frame[a];
+                if (!frame_ok(fa)) return fail(h, WBCQP_ERR_INVALID, "self-collision task avoids a frame that does not exist");
+                pair_block.push_back(t); pair_bt.push_back(md->frame_body[K.frame]); pair_ba.push_back(md->frame_body[fa]);
+                pair_pt.insert(pair_pt.end(), md->frame_placement + 12 * K.frame, md->frame_placement + 12 * K.frame + 12);
+                pair_pa.insert(pair_pa.end(), md->frame_placement + 12 * fa, md->frame_placement + 12 * fa + 12);
+                const double par[6] = {K.avoided_r0[a] + K.radius, k5, s_p, K.m, K.kp, K.kd};
+                pair_par.insert(pair_par.end(), par, par + 6);
+            }
+            blk_npair.back() = K.n_avoided;
+            row += 1;
+        }
+        else return fail(h, WBCQP_ERR_INVALID, "unknown task kind");
+        if (need && (K.ref < 0 || K.ref + need > tm->nref)) return fail(h, WBCQP_ERR_INVALID, "a task reference lies outside the reference vector");
+    }
+    if (row != D.n_dense) return fail(h, WBCQP_ERR_INVALID, "the tasks' rows do not add up to the structure's n_dense");
+    for (int c = 0; c < tm->n_contact; ++c) {
+        const int f = tm->contact_frame[c];
+        if (!frame_ok(f)) return fail(h, WBCQP_ERR_INVALID, "contact frame does not exist");
+        if (tm->contact_ref[c] < 0 || tm->contact_ref[c] + 12 > tm->nref) return fail(h, WBCQP_ERR_INVALID, "a contact reference lies outside the reference vector");
+        law_body.push_back(md->frame_body[f]); law_mask.push_back(63); law_row.push_back(0); law_ref.push_back(tm->contact_ref[c]);
+        law_va.push_back(0); law_contact.push_back(c); law_kp.push_back(tm->contact_kp[c]); law_kd.push_back(tm->contact_kd[c]);
+        law_place.insert(law_place.end(), md->frame_placement + 12 * f, md->frame_placement + 12 * f + 12);
+    }
+    if ((int)law_body.size() > kWave || (int)blk_kind.size() > kWave) return fail(h, WBCQP_ERR_UNSUPPORTED, "more than 64 framed tasks (one lane per task)");
+    if (D.n_sel > 0 && (tm->posture_ref < 0 || tm->posture_ref + na > tm->nref)) return fail(h, WBCQP_ERR_INVALID, "the posture reference lies outside the reference vector");
+    if (D.n_bound > 0 && (!md->q_lb || !md->q_ub || !md->dq_max)) return fail(h, WBCQP_ERR_INVALID, "bounds need q_lb / q_ub / dq_max");
+
+    TermsDev T{};
+    T.nb = nb; T.nq = nq; T.nv = nv; T.na = na; T.floating_base = fb; T.maxdepth = maxdepth;
+    T.nlaw = (int)law_body.size(); T.npair = (int)pair_block.size(); T.nblock = (int)blk_kind.size(); T.nc = D.nc;
+    T.n_dense = D.n_dense; T.n_sel = D.n_sel; T.n_bound = D.n_bound; T.r1 = D.r1; T.nref = tm->nref;
+    T.posture_ref = tm->posture_ref; T.posture_kp = tm->posture_kp; T.posture_kd = tm->posture_kd; T.dt = tm->dt;
+    for (int k = 0; k < 3; ++k) T.g[k] = md->gravity[k];
+    std::vector<int> ipool;
+    std::vector<double> dpool;
+    auto puti = [&](const int* a, size_t n) { int at = (int)ipool.size(); ipool.insert(ipool.end(), a, a + n); ipool.push_back(0); return at; };
+    auto putd = [&](const double* a, size_t n) { int at = (int)dpool.size(); dpool.insert(dpool.end(), a, a + n); dpool.push_back(0.0); return at; };
+    std::vector<int> sel(D.n_sel);
+    // the structure's selection columns live on the device already; the host copy comes from the posture convention
+    // (tasks.cpp:197-217: the actuated joints, in order) -- checked against n_sel
+    if (D.n_sel != 0 && D.n_sel != na) return fail(h, WBCQP_ERR_UNSUPPORTED, "a posture task over a subset of the actuated joints");
+    for (int r = 0; r < D.n_sel; ++r) sel[r] = nv - na + r;
+    T.i_parent = puti(md->parent, nb); T.i_jtype = puti(md->jtype, nb); T.i_depth = puti(depth.data(), nb); T.i_last = puti(last.data(), nb);
+    T.i_idxq = puti(idxq.data(), nb); T.i_idxv = puti(idxv.data(), nb); T.i_bodyof = puti(bodyof.data(), nv); T.i_kof = puti(kof.data(), nv);
+    T.i_law_body = puti(law_body.data(), law_body.size()); T.i_law_mask = puti(law_mask.data(), law_mask.size());
+    T.i_law_row = puti(law_row.data(), law_row.size()); T.i_law_ref = puti(law_ref.data(), law_ref.size());
+    T.i_law_va = puti(law_va.data(), law_va.size()); T.i_law_contact = puti(law_contact.data(), law_contact.size());
+    T.i_pair_block = puti(pair_block.data(), pair_block.size()); T.i_pair_bt = puti(pair_bt.data(), pair_bt.size());
+    T.i_pair_ba = puti(pair_ba.data(), pair_ba.size());
+    T.i_blk_kind = puti(blk_kind.data(), blk_kind.size()); T.i_blk_mask = puti(blk_mask.data(), blk_mask.size());
+    T.i_blk_row = puti(blk_row.data(), blk_row.size()); T.i_blk_ref = puti(blk_ref.data(), blk_ref.size());
+    T.i_blk_law = puti(blk_law.data(), blk_law.size()); T.i_blk_pair0 = puti(blk_pair0.data(), blk_pair0.size());
+    T.i_blk_npair = puti(blk_npair.data(), blk_npair.size()); T.i_sel_col = puti(sel.data(), sel.size());
+    T.d_place = putd(md->placement, (size_t)nb * 12); T.d_inertia = putd(md->inertia, (size_t)nb * 10);
+    T.d_law_place = putd(law_place.data(), law_place.size()); T.d_law_kp = putd(law_kp.data(), law_kp.size());
+    T.d_law_kd = putd(law_kd.data(), law_kd.size());
+    T.d_pair_pt = putd(pair_pt.data(), pair_pt.size()); T.d_pair_pa = putd(pair_pa.data(), pair_pa.size());
+    T.d_pair_par = putd(pair_par.data(), pair_par.size());
+    T.d_blk_kp = putd(blk_kp.data(), blk_kp.size()); T.d_blk_kd = putd(blk_kd.data(), blk_kd.size());
+    T.d_qlb = putd(md->q_lb, D.n_bound ? na : 0); T.d_qub = putd(md->q_ub, D.n_bound ? na : 0); T.d_dqmax = putd(md->dq_max, D.n_bound ? na : 0);
+    int o = 0;
+    auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; };
+    T.o_state = take(nq + nv + tm->nref);
+    T.o_kin = take(nb * kKinStride);
+    T.o_scan = take((nb + 1) * kScanStride);
+    T.o_F = take(nv * kFStride);
+    T.o_law = take(T.nlaw * kLawStride);
+    T.o_pair = take(T.npair * kPairStride);
+    T.o_b1 = take(D.r1);
+    T.o_bc = take(6 * D.nc);
+    T.lds_doubles = o;
+    if ((size_t)o * 8 > 160 * 1024) return fail(h, WBCQP_ERR_UNSUPPORTED, "the working set of one instance exceeds the LDS");
+    HIP_TRY(h, hipSetDevice(h->device));
+    release_model(s);
+    void *di = nullptr, *dd = nullptr;
+    HIP_TRY(h, hipMalloc(&di, ipool.size() * sizeof(int)));
+    s.model_allocs.push_back(di);
+    HIP_TRY(h, hipMalloc(&dd, dpool.size() * sizeof(double)));
+    s.model_allocs.push_back(dd);
+    HIP_TRY(h, hipMemcpy(di, ipool.data(), ipool.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(dd, dpool.data(), dpool.size() * sizeof(double), hipMemcpyHostToDevice));
+    T.ipool = static_cast<const int*>(di);
+    T.dpool = static_cast<const double*>(dd);
+    if (o * 8 > 64 * 1024) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&terms_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, o * 8));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&terms_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, o * 8));
+    }
+    s.terms = T;
+    s.has_model = true;
+    return WBCQP_OK;
+}
+
+int wbcqp_problem_data(wbcqp_handle* h, int slot, int batch, const wbcqp_state* st, const wbcqp_inputs* rows, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES || !h->slots[slot].set || !h->slots[slot].has_model)
+        return fail(h, WBCQP_ERR_INVALID, "slot has no model (wbcqp_set_model)");
+    if (batch < 0) return fail(h, WBCQP_ERR_INVALID, "negative batch");
+    if (batch == 0) return WBCQP_OK;
+    const Slot& s = h->slots[slot];
+    const wbcqp_layout& L = s.layout;
+    if (!st || !rows || !st->q || !st->v || (s.terms.nref > 0 && !st->ref)) return fail(h, WBCQP_ERR_INVALID, "state arrays q / v / ref are required");
+    if (!rows->M || !rows->h || (L.len_A && !rows->A) || (L.len_b1 && !rows->b1) || (L.len_Ac && !rows->Ac) || (L.len_bc && !rows->bc) ||
+        (L.len_blb && (!rows->blb || !rows->bub)))
+        return fail(h, WBCQP_ERR_INVALID, "row arrays M, h, A, b1, Ac, bc, blb, bub are required");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t sm = static_cast<hipStream_t>(stream);
+    const int lds = s.terms.lds_doubles * 8;
+    if (h->dtype == WBCQP_F64) {
+        TermsArgs<double> a{};
+        a.T = s.terms; a.batch = batch;
+        a.q = static_cast<const double*>(st->q); a.v = static_cast<const double*>(st->v); a.ref = static_cast<const double*>(st->ref);
+        a.M = (double*)rows->M; a.h = (double*)rows->h; a.A = (double*)rows->A; a.b1 = (double*)rows->b1; a.Ac = (double*)rows->Ac;
+        a.bc = (double*)rows->bc; a.blb = (double*)rows->blb; a.bub = (double*)rows->bub;
+        hipLaunchKernelGGL(terms_kernel<double>, dim3(batch), dim3(kWave), lds, sm, a);
+    }
+    else {
+        TermsArgs<float> a{};
+        a.T = s.terms; a.batch = batch;
+        a.q = static_cast<const float*>(st->q); a.v = static_cast<const float*>(st->v); a.ref = static_cast<const float*>(st->ref);
+        a.M = (float*)rows->M; a.h = (float*)rows->h; a.A = (float*)rows->A; a.b1 = (float*)rows->b1; a.Ac = (float*)rows->Ac;
+        a.bc = (float*)rows->bc; a.blb = (float*)rows->blb; a.bub = (float*)rows->bub;
+        hipLaunchKernelGGL(terms_kernel<float>, dim3(batch), dim3(kWave), lds, sm, a);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return WBCQP_OK;
+}
+
+int wbcqp_problem_data_host(wbcqp_handle* h, int slot, int batch, const wbcqp_state* st, const wbcqp_inputs* rows)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES || !h->slots[slot].set || !h->slots[slot].has_model)
+        return fail(h, WBCQP_ERR_INVALID, "slot has no model (wbcqp_set_model)");
+    if (batch < 0) return fail(h, WBCQP_ERR_INVALID, "negative batch");
+    if (batch == 0) return WBCQP_OK;
+    if (!st || !rows) return fail(h, WBCQP_ERR_INVALID, "state / rows is NULL");
+    const Slot& s = h->slots[slot];
+    const wbcqp_layout& L = s.layout;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t es = (h->dtype == WBCQP_F64) ? 8 : 4;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int ilen[3] = {s.terms.nq, s.terms.nv, s.terms.nref};
+    const void* isrc[3] = {st->q, st->v, st->ref};
+    size_t ioff[3], in_bytes = 0;
+    for (int f = 0; f < 3; ++f) { ioff[f] = in_bytes; in_bytes += al((size_t)ilen[f] * batch * es); }
+    const int olen[8] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub};
+    void* odst[8] = {(void*)rows->M, (void*)rows->h, (void*)rows->A, (void*)rows->b1, (void*)rows->Ac, (void*)rows->bc, (void*)rows->blb, (void*)rows->bub};
+    size_t ooff[8], out_bytes = 0;
+    for (int f = 0; f < 8; ++f) { ooff[f] = out_bytes; out_bytes += al((size_t)olen[f] * batch * es); }
+    int rc = ensure(h, h->stage_in, in_bytes + 256);
+    if (rc != WBCQP_OK) return rc;
+    rc = ensure(h, h->stage_out, out_bytes + 256);
+    if (rc != WBCQP_OK) return rc;
+    char* din = static_cast<char*>(h->stage_in.dev);
+    char* dout = static_cast<char*>(h->stage_out.dev);
+    for (int f = 0; f < 3; ++f) {
+        if (ilen[f] > 0 && !isrc[f]) return fail(h, WBCQP_ERR_INVALID, "state arrays q / v / ref are required");
+        if (ilen[f] > 0) HIP_TRY(h, hipMemcpy(din + ioff[f], isrc[f], (size_t)ilen[f] * batch * es, hipMemcpyHostToDevice));
+    }
+    wbcqp_state ds = {din + ioff[0], din + ioff[1], din + ioff[2]};
+    wbcqp_inputs dr{};
+    dr.M = dout + ooff[0]; dr.h = dout + ooff[1]; dr.A = dout + ooff[2]; dr.b1 = dout + ooff[3]; dr.Ac = dout + ooff[4];
+    dr.bc = dout + ooff[5]; dr.blb = dout + ooff[6]; dr.bub = dout + ooff[7];
+    rc = wbcqp_problem_data(h, slot, batch, &ds, &dr, nullptr);
+    if (rc != WBCQP_OK) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    for (int f = 0; f < 8; ++f) {
+        if (olen[f] > 0 && !odst[f]) return fail(h, WBCQP_ERR_INVALID, "row arrays M, h, A, b1, Ac, bc, blb, bub are required");
+        if (olen[f] > 0) HIP_TRY(h, hipMemcpy(odst[f], dout + ooff[f], (size_t)olen[f] * batch * es, hipMemcpyDeviceToHost));
+    }
     return WBCQP_OK;
 }
 

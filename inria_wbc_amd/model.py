@@ -557,3 +557,48 @@ def sample_states(model: Model, tm: TaskMap, batch: int, seed: int, q_noise: flo
             f = tm.contact_frame[c]
             r[tm.contact_ref[c]:tm.contact_ref[c] + 12] = se3_ref(Rf0[f], pf0[f])
     return dict(q=q, v=v, ref=ref)
+
+
+def random_stack(model: Model, seed: int) -> Tuple[Structure, List[dict]]:
+    """A task stack over `model`'s frames that uses every kind of task with random masks and gains (stress input for the
+    parity tests; not a shipped inria_wbc stack)."""
+    from . import structure as S
+    rng = np.random.default_rng(seed)
+    fr = lambda: model.frame_names[int(rng.integers(0, model.nframe))]
+    mask = lambda n: "".join("1" if (rng.random() < 0.7 or i == k) else "0" for k in [int(rng.integers(0, n))] for i in range(n))
+    stack: List[dict] = []
+    dense = []
+    for t in range(4):
+        mk = mask(6)
+        stack.append(dict(name="se3_%d" % t, type="se3", tracked=fr(), kp=float(rng.uniform(1, 50)), mask=mk))
+        dense.append(("se3_%d" % t, mk.count("1"), float(rng.uniform(1, 100))))
+    mk = mask(3)
+    stack.append(dict(name="com", type="com", kp=30.0, mask=mk))
+    dense.append(("com", mk.count("1"), 1000.0))
+    stack.append(dict(name="posture", type="posture", kp=10.0))
+    dense.append(("__posture__", "posture", 0.5))
+    mk = mask(6)
+    stack.append(dict(name="momentum", type="momentum", kp=20.0, mask=mk))
+    dense.append(("momentum", mk.count("1"), 10.0))
+    stack.append(dict(name="bounds", type="bounds"))
+    contacts = []
+    if model.floating_base:
+        pts = S.contact6d_points(lxn=0.06, lyn=0.045, lxp=0.14, lyp=0.045, lz=0.065)
+        for c in range(2):
+            contacts.append(S.Contact("contact_%d" % c, pts, (0.0, 0.0, 1.0), 0.4, 5.0, 1200.0))
+            stack.append(dict(name="contact_%d" % c, type="contact", joint=fr(), kp=30.0))
+        dense.append(("__contacts__",))
+    sc = []
+    for t in range(3):
+        av = {}
+        tracked = fr()
+        while len(av) < 1 + 2 * t:
+            f = fr()
+            if f != tracked:
+                av[f] = float(rng.uniform(0.05, 0.3))
+        stack.append(dict(name="sc_%d" % t, type="self-collision", tracked=tracked, radius=float(rng.uniform(0.05, 0.2)), avoided=av,
+                          kp=50.0, kd=250.0, margin=0.02 + 0.1 * t, m=0.2 + 0.3 * t))
+        sc.append(("sc_%d" % t, 500.0))
+    level0 = [(S.INEQ_BOUNDS, 0)] + [(S.INEQ_FORCE, c) for c in range(len(contacts))]
+    st = S._mk("stack_" + model.name, model.nv, model.na, contacts, dense, None, sc, True, False, level0)
+    return st, stack

@@ -1,0 +1,161 @@
+"""GPU parity of the step before the path (wbcqp_problem_data: rigid-body terms + task laws)
+against oracle/rbd_oracle.c, through the C ABI.
+
+Tolerance: floating point, two different formulations (world-frame prefix sums on the device, pinocchio-style local
+recursions in the oracle): every array must agree to TOL_ROWS relative to its own largest entry (at least 1)."""
+import numpy as np
+import pytest
+
+from inria_wbc_amd import capi, structure
+from inria_wbc_amd import model as mdl
+from tests.util import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+TOL_ROWS = 1e-10
+
+
+def _cases():
+    def talos():
+        m = mdl.talos_like()
+        st = structure.talos_structure()
+        return m, st, mdl.build_taskmap(m, st, mdl.talos_stack())
+
+    def franka():
+        m = mdl.franka_like()
+        st = structure.franka_structure()
+        return m, st, mdl.build_taskmap(m, st, mdl.franka_stack())
+
+    def tree(seed, nb, fb):
+        def f():
+            m = mdl.random_tree(seed, nb, fb, nframe=12)
+            st, stack = mdl.random_stack(m, seed + 100)
+            return m, st, mdl.build_taskmap(m, st, stack, dt=2e-3)
+        return f
+
+    return {"talos": talos, "franka": franka, "tree_fb": tree(21, 30, True), "tree_fixed": tree(22, 19, False), "tree_big": tree(23, 62, False)}
+
+
+CASES = _cases()
+
+
+@pytest.fixture(scope="module")
+def rbd():
+    from oracle import rbd as r
+    return r
+
+
+@pytest.fixture(scope="module")
+def handle():
+    h = capi.Handle(0, capi.F64)
+    yield h
+    h.close()
+
+
+def _compare(dev, ora, tol=TOL_ROWS):
+    worst = {}
+    for k in capi.ROW_FIELDS:
+        if ora[k].size == 0:
+            continue
+        scale = max(1.0, np.abs(ora[k]).max())
+        worst[k] = np.abs(dev[k] - ora[k]).max() / scale
+        assert worst[k] <= tol, (k, worst)
+    return worst
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_problem_data_parity(handle, rbd, name):
+    m, st, tm = CASES[name]()
+    handle.set_structure(3, st)
+    handle.set_model(3, m, tm)
+    big = dict(q_noise=0.3, v_noise=0.5, ref_noise=0.2) if name.startswith("tree") else {}
+    s = mdl.sample_states(m, tm, 48, 31_000, **big)
+    dev = handle.problem_data_host(3, s["q"], s["v"], s["ref"])
+    ora = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"], n_threads=8)
+    _compare(dev, ora)
+
+
+def test_problem_data_far_from_the_origin(handle, rbd):
+    """The device works about the floating base: a robot 1 km away must give the same rows as the oracle's absolute arithmetic
+    (up to what the oracle itself loses there)."""
+    m, st, tm = CASES["talos"]()
+    handle.set_structure(3, st)
+    handle.set_model(3, m, tm)
+    s = mdl.sample_states(m, tm, 8, 32_000)
+    shift = np.array([1000.0, -500.0, 20.0])
+    s["q"][:, 0:3] += shift
+    for b in tm.blocks:
+        if b.kind in (mdl.T_SE3, mdl.T_COM):
+            s["ref"][:, b.ref:b.ref + 3] += shift
+    for c in range(tm.ncontact):
+        s["ref"][:, tm.contact_ref[c]:tm.contact_ref[c] + 3] += shift
+    dev = handle.problem_data_host(3, s["q"], s["v"], s["ref"])
+    ora = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"])
+    _compare(dev, ora, tol=1e-7)  # the oracle's own cancellation at |p| = 1e3 (M, h through 1e6-sized intermediate moments)
+
+
+def test_problem_data_then_solve_matches_oracle_pipeline(handle, rbd):
+    """State -> rows -> QP -> torques, all on the device, against oracle rows -> oracle tick."""
+    import torch
+    from oracle import oracle as orc
+    m, st, tm = CASES["talos"]()
+    handle.set_structure(2, st)
+    handle.set_model(2, m, tm)
+    B = 96
+    s = mdl.sample_states(m, tm, B, 33_000, q_noise=0.01, v_noise=0.05, ref_noise=0.01)
+    dev = torch.device("cuda", 0)
+    L = st.field_lengths()
+    state = {k: torch.from_numpy(s[k]).to(dev) for k in ("q", "v", "ref")}
+    rows = {k: torch.zeros(B, L[k], dtype=torch.float64, device=dev) for k in capi.ROW_FIELDS}
+    rows["tlb"] = torch.from_numpy(np.tile(-m.tau_max, (B, 1))).to(dev)
+    rows["tub"] = torch.from_numpy(np.tile(m.tau_max, (B, 1))).to(dev)
+    rows["w"] = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev)
+    out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, st.na, dtype=torch.float64, device=dev),
+               status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+    stream = torch.cuda.current_stream().cuda_stream
+    handle.problem_data(2, B, state, rows, stream=stream)
+    handle.solve_batch(2, B, rows, out, stream=stream)
+    torch.cuda.synchronize()
+    ora_rows = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"], n_threads=8)
+    ora_in = dict(ora_rows, tlb=np.tile(-m.tau_max, (B, 1)), tub=np.tile(m.tau_max, (B, 1)), w=np.tile(st.default_weights, (B, 1)))
+    ref = orc.tick_batch(st, ora_in, nthreads=8)
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    assert (ref["status"] == 0).all()
+    assert_parity(st, got, ref)
+
+
+def test_set_model_rejects_mismatches(handle):
+    m, st, tm = CASES["talos"]()
+    handle.set_structure(4, structure.icub_structure())
+    with pytest.raises(capi.WbcqpError):
+        handle.set_model(4, m, tm)  # nv / na of another robot
+    handle.set_structure(4, st)
+    bad = mdl.talos_like()
+    bad.parent = bad.parent.copy()
+    bad.parent[20] = 3  # breaks the depth-first numbering
+    with pytest.raises(capi.WbcqpError):
+        handle.set_model(4, bad, tm)
+    tm2 = mdl.build_taskmap(m, st, mdl.talos_stack())
+    tm2.blocks[0].ref = tm2.nref  # reference outside the vector
+    with pytest.raises(capi.WbcqpError):
+        handle.set_model(4, m, tm2)
+    h2 = capi.Handle(0, capi.F64)
+    h2.set_structure(0, st)
+    with pytest.raises(capi.WbcqpError):
+        h2.problem_data_host(0, np.zeros((1, m.nq)), np.zeros((1, m.nv)), np.zeros((1, tm.nref)))  # no model bound
+    h2.close()
+
+
+def test_problem_data_f32_boundary(rbd):
+    m, st, tm = CASES["talos"]()
+    h = capi.Handle(0, capi.F32)
+    h.set_structure(0, st)
+    h.set_model(0, m, tm)
+    s = mdl.sample_states(m, tm, 16, 34_000)
+    s32 = {k: v.astype(np.float32) for k, v in s.items()}
+    dev = h.problem_data_host(0, s32["q"], s32["v"], s32["ref"])
+    ora = rbd.task_rows(m, tm, st, s32["q"].astype(np.float64), s32["v"].astype(np.float64), s32["ref"].astype(np.float64))
+    for k in capi.ROW_FIELDS:
+        scale = max(1.0, np.abs(ora[k]).max())
+        assert np.abs(dev[k].astype(np.float64) - ora[k]).max() / scale < 1e-6, k
+    h.close()
