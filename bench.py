@@ -54,6 +54,71 @@ def parse():
     return p.parse_args()
 
 
+
+def before_path(h, st, dev, B, torch, cpu_baseline=True):
+    """Before the path, outside `value`: the rows kernel (q, v, references -> QP record) on a
+    Talos-like tree, alone and chained with the solve and the state integration (one whole control tick on the device)."""
+    from inria_wbc_amd import capi
+    from inria_wbc_amd import model as mdl
+    m = mdl.talos_like()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    h.set_structure(1, st)
+    h.set_model(1, m, tm)
+    s = mdl.sample_states(m, tm, B, 9_000_000, q_noise=0.01, v_noise=0.05, ref_noise=0.01)
+    L = st.field_lengths()
+    state = {k: torch.from_numpy(s[k]).to(dev) for k in ("q", "v", "ref")}
+    rows = {k: torch.zeros(B, L[k], dtype=torch.float64, device=dev) for k in capi.ROW_FIELDS}
+    rows["tlb"] = torch.from_numpy(np.tile(-m.tau_max, (B, 1))).to(dev)
+    rows["tub"] = torch.from_numpy(np.tile(m.tau_max, (B, 1))).to(dev)
+    rows["w"] = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev)
+    out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, st.na, dtype=torch.float64, device=dev),
+               status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+    qn, vn = torch.zeros_like(state["q"]), torch.zeros_like(state["v"])
+    sp = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        h.problem_data(1, B, state, rows, stream=sp)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        h.problem_data(1, B, state, rows, stream=sp)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 50 * 1e3
+    nbytes = B * tm.algorithmic_bytes(m, st)
+    res = {"kernel": "wbcqp::terms_kernel<double>", "us_per_launch": us, "bytes_per_launch": nbytes,
+           "achieved_GBps": nbytes / (us * 1e-6) / 1e9, "frac_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "instances_per_s": B / (us * 1e-6), "model": "talos_like (45 bodies, nv 50), etc/talos/tasks.yaml stack"}
+
+    def tick():
+        h.problem_data(1, B, state, rows, stream=sp)
+        h.solve_batch(1, B, rows, out, stream=sp)
+        h.integrate(B, st.nv, True, tm.dt, state["q"], state["v"], out["x"], st.n, out["status"], qn, vn, None, stream=sp)
+
+    for _ in range(4):
+        tick()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        tick()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    it = out["iters"].cpu().numpy()
+    res["whole_tick"] = {"ticks_per_s": B / (ms * 1e-3), "ms_per_batch": ms, "iters_mean": float(it.mean()),
+                         "status_optimal": int((out["status"] == 0).sum().item()),
+                         "note": "rows kernel + solve kernel + integrate kernel on the same stream, states around the reference posture"}
+    if cpu_baseline:
+        from oracle import rbd
+        ns = min(B, 128)
+        t1 = time.perf_counter()
+        ora = rbd.task_rows(m, tm, st, s["q"][:ns], s["v"][:ns], s["ref"][:ns], n_threads=1)
+        dt1 = time.perf_counter() - t1
+        got = {k: rows[k][:ns].cpu().numpy() for k in capi.ROW_FIELDS}
+        res["cpu_port"] = {"instances_per_s": ns / dt1, "cores": 1, "sample": "%d instances, oracle/rbd_oracle.c" % ns}
+        res["parity"] = {k: float(np.abs(got[k] - ora[k]).max() / max(1.0, np.abs(ora[k]).max())) for k in capi.ROW_FIELDS}
+    return res
+
 def main():
     args = parse()
     import torch
@@ -196,6 +261,8 @@ def main():
             ibytes = B * (8 * (2 * nq + 4 * nvv) + 4)  # q, dq, dv in; q_next, v_next, q_solver out; status
             result["after_path"] = {"kernel": "wbcqp::integrate_kernel<double>", "us_per_launch": us, "bytes_per_launch": ibytes,
                                     "achieved_GBps": ibytes / (us * 1e-6) / 1e9, "bound": "hbm (launch-latency sized at this batch)"}
+        if world == 1 and args.robot == "talos":
+            result["before_path"] = before_path(h, st, dev, B, torch, not args.no_cpu_baseline)
         if world == 1 and not args.index_order and not args.no_compare:
             # the same K steps with the launch in plain index order (WBCQP_FLAG_INDEX_ORDER), reported beside `value`
             h2 = capi.Handle(device=local_rank, dtype=capi.F64, flags=capi.FLAG_INDEX_ORDER)

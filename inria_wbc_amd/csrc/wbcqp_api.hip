@@ -700,6 +700,16 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
 
     TermsDev T{};
     T.nb = nb; T.nq = nq; T.nv = nv; T.na = na; T.floating_base = fb; T.maxdepth = maxdepth;
+    int nrounds = 0;
+    while ((1 << nrounds) < maxdepth + 1) ++nrounds;
+    T.nrounds = nrounds; // <= 6 for 64 bodies
+    std::vector<int> anc((size_t)std::max(nrounds, 1) * nb, -1);
+    for (int i = 0; i < nb; ++i) anc[i] = md->parent[i];
+    for (int r = 1; r < nrounds; ++r)
+        for (int i = 0; i < nb; ++i) {
+            const int a = anc[(size_t)(r - 1) * nb + i];
+            anc[(size_t)r * nb + i] = (a >= 0) ? anc[(size_t)(r - 1) * nb + a] : -1;
+        }
     T.nlaw = (int)law_body.size(); T.npair = (int)pair_block.size(); T.nblock = (int)blk_kind.size(); T.nc = D.nc;
     T.n_dense = D.n_dense; T.n_sel = D.n_sel; T.n_bound = D.n_bound; T.r1 = D.r1; T.nref = tm->nref;
     T.posture_ref = tm->posture_ref; T.posture_kp = tm->posture_kp; T.posture_kd = tm->posture_kd; T.dt = tm->dt;
@@ -714,6 +724,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     if (D.n_sel != 0 && D.n_sel != na) return fail(h, WBCQP_ERR_UNSUPPORTED, "a posture task over a subset of the actuated joints");
     for (int r = 0; r < D.n_sel; ++r) sel[r] = nv - na + r;
     T.i_parent = puti(md->parent, nb); T.i_jtype = puti(md->jtype, nb); T.i_depth = puti(depth.data(), nb); T.i_last = puti(last.data(), nb);
+    T.i_anc = puti(anc.data(), (size_t)nrounds * nb);
     T.i_idxq = puti(idxq.data(), nb); T.i_idxv = puti(idxv.data(), nb); T.i_bodyof = puti(bodyof.data(), nv); T.i_kof = puti(kof.data(), nv);
     T.i_law_body = puti(law_body.data(), law_body.size()); T.i_law_mask = puti(law_mask.data(), law_mask.size());
     T.i_law_row = puti(law_row.data(), law_row.size()); T.i_law_ref = puti(law_ref.data(), law_ref.size());
@@ -736,7 +747,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     T.o_state = take(nq + nv + tm->nref);
     T.o_kin = take(nb * kKinStride);
     T.o_scan = take((nb + 1) * kScanStride);
-    T.o_F = take(nv * kFStride);
+    T.o_F = take(8); // momentum totals
     T.o_law = take(T.nlaw * kLawStride);
     T.o_pair = take(T.npair * kPairStride);
     T.o_b1 = take(D.r1);
@@ -781,19 +792,19 @@ int wbcqp_problem_data(wbcqp_handle* h, int slot, int batch, const wbcqp_state* 
     const int lds = s.terms.lds_doubles * 8;
     if (h->dtype == WBCQP_F64) {
         TermsArgs<double> a{};
-        a.T = s.terms; a.batch = batch;
+        a.T = s.terms; a.batch = batch; a.dbg = h->dbg;
         a.q = static_cast<const double*>(st->q); a.v = static_cast<const double*>(st->v); a.ref = static_cast<const double*>(st->ref);
         a.M = (double*)rows->M; a.h = (double*)rows->h; a.A = (double*)rows->A; a.b1 = (double*)rows->b1; a.Ac = (double*)rows->Ac;
         a.bc = (double*)rows->bc; a.blb = (double*)rows->blb; a.bub = (double*)rows->bub;
-        hipLaunchKernelGGL(terms_kernel<double>, dim3(batch), dim3(kWave), lds, sm, a);
+        hipLaunchKernelGGL(terms_kernel<double>, dim3(batch), dim3(kTermsThreads), lds, sm, a);
     }
     else {
         TermsArgs<float> a{};
-        a.T = s.terms; a.batch = batch;
+        a.T = s.terms; a.batch = batch; a.dbg = h->dbg;
         a.q = static_cast<const float*>(st->q); a.v = static_cast<const float*>(st->v); a.ref = static_cast<const float*>(st->ref);
         a.M = (float*)rows->M; a.h = (float*)rows->h; a.A = (float*)rows->A; a.b1 = (float*)rows->b1; a.Ac = (float*)rows->Ac;
         a.bc = (float*)rows->bc; a.blb = (float*)rows->blb; a.bub = (float*)rows->bub;
-        hipLaunchKernelGGL(terms_kernel<float>, dim3(batch), dim3(kWave), lds, sm, a);
+        hipLaunchKernelGGL(terms_kernel<float>, dim3(batch), dim3(kTermsThreads), lds, sm, a);
     }
     HIP_TRY(h, hipGetLastError());
     return WBCQP_OK;

@@ -13,7 +13,7 @@
 // Then a spatial quantity of a subtree is a plain sum over its bodies, bodies are numbered depth-first so a subtree is a
 // contiguous lane range, and every composite (inertia for CRBA, bias force for the non-linear effects, momentum) is one
 // wave-wide prefix sum and a difference of two entries:
-//   lanes = bodies:   joint transform, placement / velocity / bias acceleration down the tree (one step per depth level),
+//   (wave 0) lanes = bodies:   joint transform, placement / velocity / bias acceleration down the tree (one step per depth level),
 //                     world inertia, momentum, bias force, prefix sums
 //   lanes = tasks:    frame placement, velocity, classical acceleration, SE(3) error (log3), right-hand sides
 //   lanes = pairs:    self-collision repulsors (one lane per tracked / avoided pair)
@@ -37,7 +37,7 @@ constexpr int kPairStride = 7;  // per self-collision pair: grad (3), rhs share,
 
 // Constant tables of one (model, task map), resident in device memory; offsets index the two pools.
 struct TermsDev {
-    int nb, nq, nv, na, floating_base, maxdepth;
+    int nb, nq, nv, na, floating_base, maxdepth, nrounds;
     int nlaw, npair, nblock, nc, n_dense, n_sel, n_bound, r1, nref;
     int posture_ref;
     double posture_kp, posture_kd, dt;
@@ -46,6 +46,7 @@ struct TermsDev {
     const double* dpool;
     // int pool offsets
     int i_parent, i_jtype, i_depth, i_last, i_idxq, i_idxv; // [nb]
+    int i_anc;                                              // [nrounds][nb] 2^r-th ancestor, -1 beyond the root
     int i_bodyof, i_kof;                                    // [nv]
     int i_law_body, i_law_mask, i_law_row, i_law_ref, i_law_va, i_law_contact; // [nlaw]
     int i_pair_block, i_pair_bt, i_pair_ba;                 // [npair]
@@ -68,6 +69,7 @@ struct TermsArgs {
     const TI *q, *v, *ref;
     TI *M, *h, *A, *b1, *Ac, *bc, *blb, *bub;
     int batch;
+    long long* dbg; // per-instance phase cycle counters, only written by the WBCQP_STAMPS diagnostic build
 };
 
 #ifdef __HIPCC__
@@ -145,13 +147,47 @@ __device__ __forceinline__ void frame_kin(const double* kin_b, const double* pla
     f.a = mtv(f.R, oa + cross(oal, f.p)) + cross(f.w, f.v);
 }
 
+#ifdef WBCQP_STAMPS
+#define TSTAMP(i) { const long long now_ = clock64(); tacc_[i] += now_ - tprev_; tprev_ = now_; }
+#else
+#define TSTAMP(i)
+#endif
+
+// inclusive prefix sum over the 64 lanes: four DPP row shifts inside each row of 16, then the row totals by readlane
+__device__ __forceinline__ double scan_incl_dpp(double v, int lane)
+{
+    v += dpp_get<0x111>(v);
+    v += dpp_get<0x112>(v);
+    v += dpp_get<0x114>(v);
+    v += dpp_get<0x118>(v);
+    const double t0 = bcast_lane(v, 15), t1 = bcast_lane(v, 31), t2 = bcast_lane(v, 47);
+    const int row = lane >> 4;
+    const double add = (row == 0) ? 0.0 : (row == 1) ? t0 : (row == 2) ? (t0 + t1) : ((t0 + t1) + t2);
+    return v + add;
+}
+__device__ __forceinline__ int rl(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+constexpr int kTermsThreads = 256; // four wavefronts per instance: one runs the tree, all four share the rows
+
+// One workgroup of four wavefronts per instance.
+//   phase 1  wave 0: joint transforms and the sweep down the tree;  wave 3 meanwhile: posture right-hand side, joint bounds
+//   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames and their laws;  wave 2: self-collision pairs
+//   phase 3  every wave: S_j and F_j of its lanes' columns (registers), then a quarter of the output rows each -- rows of M,
+//            Jacobian rows of the framed tasks, CoM / momentum / self-collision rows
 template <typename TI>
-__global__ __launch_bounds__(kWave) void terms_kernel(const TermsArgs<TI> args)
+__global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs<TI> args)
 {
     extern __shared__ double lds[];
     const TermsDev& T = args.T;
-    const int inst = blockIdx.x, lane = threadIdx.x;
+    const int inst = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1);
+    // no rotation of the roles: the hardware itself starts co-resident workgroups on different SIMDs (measured with
+    // tools/ubench/wave_placement.hip: wave 0 of the four workgroups of a CU lands on SIMD 2, 1, 3, 0), so their tree waves
+    // already sit on four different SIMDs
+    const int wave = tid >> 6;
     if (inst >= args.batch) return;
+#ifdef WBCQP_STAMPS
+    long long tacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
+#endif
     const int nb = T.nb, nq = T.nq, nv = T.nv, na = T.na;
     const int* ip = T.ipool;
     const double* dp = T.dpool;
@@ -160,279 +196,367 @@ __global__ __launch_bounds__(kWave) void terms_kernel(const TermsArgs<TI> args)
     double* ref = v + nv;
     double* kin = lds + T.o_kin;
     double* scan = lds + T.o_scan;
-    double* Fl = lds + T.o_F;
     double* law = lds + T.o_law;
     double* pair = lds + T.o_pair;
     double* b1s = lds + T.o_b1;
     double* bcs = lds + T.o_bc;
+    double* tots = lds + T.o_F; // totals of the momentum (6 doubles)
 
     // ---- state and references into LDS ----------------------------------------------------------------------------
     {
         const TI* gq = args.q + (size_t)inst * nq;
         const TI* gv = args.v + (size_t)inst * nv;
         const TI* gr = args.ref + (size_t)inst * T.nref;
-        for (int i = lane; i < nq; i += kWave) q[i] = (double)gq[i];
-        for (int i = lane; i < nv; i += kWave) v[i] = (double)gv[i];
-        for (int i = lane; i < T.nref; i += kWave) ref[i] = (double)gr[i];
-        for (int i = lane; i < T.r1; i += kWave) b1s[i] = 0.0;
+        // one pass: every thread fetches its elements of the three arrays before any of them is stored
+        const int n1 = nq, n2 = nq + nv, n3 = nq + nv + T.nref;
+        TI buf[2];
+        int idx[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * kTermsThreads;
+            idx[u] = e;
+            const int ec = min(e, n3 - 1);
+            buf[u] = (ec < n1) ? gq[ec] : (ec < n2) ? gv[ec - n1] : gr[ec - n2];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (idx[u] < n3) q[idx[u]] = (double)buf[u];
+        for (int e = tid + 2 * kTermsThreads; e < n3; e += kTermsThreads)
+            q[e] = (double)((e < n1) ? gq[e] : (e < n2) ? gv[e - n1] : gr[e - n2]);
+        for (int i = tid; i < T.r1; i += kTermsThreads) b1s[i] = 0.0;
     }
     __syncthreads();
+    TSTAMP(0)
     const V3 p0 = T.floating_base ? ld3(q) : V3{0.0, 0.0, 0.0}; // the origin everything below is expressed about
 
-    // ---- lanes = bodies: joint transform ---------------------------------------------------------------------------
-    const bool body = lane < nb;
-    const int bi = body ? lane : 0;
-    const int jt = ip[T.i_jtype + bi], par = ip[T.i_parent + bi], dep = body ? ip[T.i_depth + bi] : -1;
-    const int iq = ip[T.i_idxq + bi], iv = ip[T.i_idxv + bi];
-    double Rl[9];
-    V3 pl;
-    {
-        const double* P = dp + T.d_place + 12 * bi;
-        if (jt == J_FREEFLYER) {
-            const double x = q[3], y = q[4], z = q[5], w = q[6];
-            const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-            const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
-                         tzz = tz * z;
-            Rl[0] = 1 - (tyy + tzz); Rl[1] = txy - twz; Rl[2] = txz + twy;
-            Rl[3] = txy + twz; Rl[4] = 1 - (txx + tzz); Rl[5] = tyz - twx;
-            Rl[6] = txz - twy; Rl[7] = tyz + twx; Rl[8] = 1 - (txx + tyy);
-            pl = {0.0, 0.0, 0.0};
-        }
-        else if (jt <= J_RZ) {
-            double s, c;
-            sincos(q[iq], &s, &c);
-            // P.R * Rot(axis): the axis column stays, the other two mix
-            const int a = jt - J_RX, b = (a + 1) % 3, d = (a + 2) % 3;
+    if (wave == 0) {
+        // ---- lanes = bodies: joint transform ----------------------------------------------------------------------
+        const bool body = lane < nb;
+        const int bi = body ? lane : 0;
+        const int jt = ip[T.i_jtype + bi];
+        const int iq = ip[T.i_idxq + bi], iv = ip[T.i_idxv + bi];
+        double Yb[10]; // this body's inertia: fetched now, used after the sweep
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double pa = P[3 * r + a], pb = P[3 * r + b], pd = P[3 * r + d];
-                Rl[3 * r + a] = pa;
-                Rl[3 * r + b] = c * pb + s * pd;
-                Rl[3 * r + d] = c * pd - s * pb;
-            }
-            pl = ld3(P + 9);
-        }
-        else {
-#pragma unroll
-            for (int r = 0; r < 9; ++r) Rl[r] = P[r];
-            pl = ld3(P + 9) + q[iq] * col(P, jt - J_PX);
-        }
-    }
-    // ---- down the tree, one depth level per step: placement, velocity, bias acceleration (world-aligned, about p0) ----
-    double R[9];
-    V3 p = {0, 0, 0}, ov = {0, 0, 0}, ow = {0, 0, 0}, oa = {0, 0, 0}, oal = {0, 0, 0};
-    for (int d = 0; d <= T.maxdepth; ++d) {
-        if (dep == d) {
-            V3 pv = {0, 0, 0}, pw = {0, 0, 0}, pa = {0, 0, 0}, pal = {0, 0, 0};
-            if (par >= 0) {
-                const double* K = kin + kKinStride * par;
-                mm(K, Rl, R);
-                p = mv(K, pl) + ld3(K + 9);
-                pv = ld3(K + 12); pw = ld3(K + 15); pa = ld3(K + 18); pal = ld3(K + 21);
-            }
-            else {
-#pragma unroll
-                for (int r = 0; r < 9; ++r) R[r] = Rl[r];
-                p = pl;
-            }
-            V3 jv, jw; // the joint's own velocity, world-aligned
+        for (int r = 0; r < 10; ++r) Yb[r] = dp[T.d_inertia + 10 * bi + r];
+        double Rl[9];
+        V3 pl, vJ, wJ; // joint placement in the parent, joint velocity in the joint's own axes
+        {
+            const double* P = dp + T.d_place + 12 * bi;
             if (jt == J_FREEFLYER) {
-                jw = mv(R, ld3(v + 3));
-                jv = mv(R, ld3(v)) + cross(p, jw);
-            }
-            else if (jt <= J_RZ) {
-                jw = v[iv] * col(R, jt - J_RX);
-                jv = cross(p, jw);
+                const double x = q[3], y = q[4], z = q[5], w = q[6];
+                const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+                const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+                             tyz = tz * y, tzz = tz * z;
+                Rl[0] = 1 - (tyy + tzz); Rl[1] = txy - twz; Rl[2] = txz + twy;
+                Rl[3] = txy + twz; Rl[4] = 1 - (txx + tzz); Rl[5] = tyz - twx;
+                Rl[6] = txz - twy; Rl[7] = tyz + twx; Rl[8] = 1 - (txx + tyy);
+                pl = {0.0, 0.0, 0.0};
+                vJ = ld3(v); wJ = ld3(v + 3);
             }
             else {
-                jw = {0, 0, 0};
-                jv = v[iv] * col(R, jt - J_PX);
+                const int a = (jt <= J_RZ) ? jt - J_RX : jt - J_PX;
+                const double qd = v[iv];
+                const V3 e = {a == 0 ? qd : 0.0, a == 1 ? qd : 0.0, a == 2 ? qd : 0.0};
+                if (jt <= J_RZ) {
+                    double sn, cs;
+                    sincos(q[iq], &sn, &cs);
+                    // P.R * Rot(axis): the axis column stays, the other two mix
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const double c0 = P[3 * r], c1 = P[3 * r + 1], c2 = P[3 * r + 2];
+                        const double pa = (a == 0) ? c0 : (a == 1) ? c1 : c2;
+                        const double pb = (a == 0) ? c1 : (a == 1) ? c2 : c0;
+                        const double pd = (a == 0) ? c2 : (a == 1) ? c0 : c1;
+                        const double nb_ = cs * pb + sn * pd, nd_ = cs * pd - sn * pb;
+                        Rl[3 * r] = (a == 0) ? pa : (a == 1) ? nd_ : nb_;
+                        Rl[3 * r + 1] = (a == 0) ? nb_ : (a == 1) ? pa : nd_;
+                        Rl[3 * r + 2] = (a == 0) ? nd_ : (a == 1) ? nb_ : pa;
+                    }
+                    pl = ld3(P + 9);
+                    vJ = {0.0, 0.0, 0.0}; wJ = e;
+                }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) Rl[r] = P[r];
+                    const V3 ax = {a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0};
+                    pl = ld3(P + 9) + q[iq] * mv(P, ax);
+                    vJ = e; wJ = {0.0, 0.0, 0.0};
+                }
             }
-            ov = pv + jv;
-            ow = pw + jw;
-            // a = a_parent + v x vJ (motion cross product)
-            oa = pa + cross(ow, jv) + cross(ov, jw);
-            oal = pal + cross(ow, jw);
+        }
+        TSTAMP(1)
+        // ---- down the tree by ancestor doubling: after round r every body holds the composition over its 2^(r+1) nearest
+        //      ancestors-and-self, so ceil(log2(depth + 1)) rounds give placements, then velocities, then bias accelerations
+        //      (a path sum each) -- rigid transforms compose associatively, so the order of the products is free ------------
+        int anc[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) anc[r] = (r < T.nrounds) ? ip[T.i_anc + r * nb + bi] : -1;
+        double R[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) R[r] = Rl[r];
+        V3 p = pl;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (r < T.nrounds) {
+                const int src = anc[r] >= 0 ? anc[r] : lane;
+                double Ra[9], Rn[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Ra[k] = __shfl(R[k], src, kWave);
+                const V3 pa = {__shfl(p.x, src, kWave), __shfl(p.y, src, kWave), __shfl(p.z, src, kWave)};
+                if (anc[r] >= 0) {
+                    mm(Ra, R, Rn);
+                    p = mv(Ra, p) + pa;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+                }
+            }
+        }
+        const V3 jw = mv(R, wJ);               // the joint's own velocity, world-aligned
+        const V3 jv = mv(R, vJ) + cross(p, jw);
+        V3 ov = jv, ow = jw;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (r < T.nrounds) {
+                const int src = anc[r] >= 0 ? anc[r] : lane;
+                const V3 a = {__shfl(ov.x, src, kWave), __shfl(ov.y, src, kWave), __shfl(ov.z, src, kWave)};
+                const V3 b = {__shfl(ow.x, src, kWave), __shfl(ow.y, src, kWave), __shfl(ow.z, src, kWave)};
+                if (anc[r] >= 0) { ov = ov + a; ow = ow + b; }
+            }
+        }
+        // a = a_parent + v x vJ (motion cross product): a path sum of the bias terms
+        V3 oa = cross(ow, jv) + cross(ov, jw), oal = cross(ow, jw);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (r < T.nrounds) {
+                const int src = anc[r] >= 0 ? anc[r] : lane;
+                const V3 a = {__shfl(oa.x, src, kWave), __shfl(oa.y, src, kWave), __shfl(oa.z, src, kWave)};
+                const V3 b = {__shfl(oal.x, src, kWave), __shfl(oal.y, src, kWave), __shfl(oal.z, src, kWave)};
+                if (anc[r] >= 0) { oa = oa + a; oal = oal + b; }
+            }
+        }
+        if (body) {
             double* K = kin + kKinStride * lane;
 #pragma unroll
             for (int r = 0; r < 9; ++r) K[r] = R[r];
             st3(K + 9, p); st3(K + 12, ov); st3(K + 15, ow); st3(K + 18, oa); st3(K + 21, oal);
         }
-        __syncthreads();
-    }
-    // ---- world inertia about the origin, momentum, bias force; prefix sums over the depth-first order ----------------
-    double sc[16];
-    double hm[6];
-    {
-        const double* Y = dp + T.d_inertia + 10 * bi;
-        const double m = body ? Y[0] : 0.0;
-        const V3 cw = mv(R, ld3(Y + 1)) + p;
-        // R I_c R'
-        const double Ic[9] = {Y[4], Y[5], Y[6], Y[5], Y[7], Y[8], Y[6], Y[8], Y[9]};
-        double RI[9], Iw[9], Rt[9];
-        mm(R, Ic, RI);
+        TSTAMP(2)
+        // ---- phase 2 on this wave: world inertia about the origin, momentum, bias force; prefix sums ---------------
+        __syncthreads(); // barrier 1: kin is complete
+        double sc[16];
+        double hm[6];
+        {
+            const double* Y = Yb;
+            const double m = body ? Y[0] : 0.0;
+            const V3 cw = mv(R, ld3(Y + 1)) + p;
+            const double Ic[9] = {Y[4], Y[5], Y[6], Y[5], Y[7], Y[8], Y[6], Y[8], Y[9]};
+            double RI[9], Iw[9], Rt[9];
+            mm(R, Ic, RI);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) Rt[3 * i + j] = R[3 * j + i];
-        mm(RI, Rt, Iw);
-        const double c2 = dot(cw, cw);
-        const V3 hc = m * cw;
-        double Io[6] = {Iw[0] + m * (c2 - cw.x * cw.x), Iw[1] - m * cw.x * cw.y, Iw[2] - m * cw.x * cw.z,
-                        Iw[4] + m * (c2 - cw.y * cw.y), Iw[5] - m * cw.y * cw.z, Iw[8] + m * (c2 - cw.z * cw.z)};
-        if (!body) {
+                for (int j = 0; j < 3; ++j) Rt[3 * i + j] = R[3 * j + i];
+            mm(RI, Rt, Iw);
+            const double c2 = dot(cw, cw);
+            const V3 hc = m * cw;
+            const double Io[6] = {Iw[0] + m * (c2 - cw.x * cw.x), Iw[1] - m * cw.x * cw.y, Iw[2] - m * cw.x * cw.z,
+                                  Iw[4] + m * (c2 - cw.y * cw.y), Iw[5] - m * cw.y * cw.z, Iw[8] + m * (c2 - cw.z * cw.z)};
+            // momentum h = Y v, bias force f = Y a + v x* h
+            const V3 hl = m * ov + cross(ow, hc);
+            const V3 ha = symv(Io, ow) + cross(hc, ov);
+            const V3 fl = m * oa + cross(oal, hc) + cross(ow, hl);
+            const V3 fa = symv(Io, oal) + cross(hc, oa) + cross(ow, ha) + cross(ov, hl);
+            sc[0] = m; sc[1] = hc.x; sc[2] = hc.y; sc[3] = hc.z;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) Io[r] = 0.0;
+            for (int r = 0; r < 6; ++r) sc[4 + r] = Io[r];
+            sc[10] = fl.x; sc[11] = fl.y; sc[12] = fl.z; sc[13] = fa.x; sc[14] = fa.y; sc[15] = fa.z;
+            hm[0] = hl.x; hm[1] = hl.y; hm[2] = hl.z; hm[3] = ha.x; hm[4] = ha.y; hm[5] = ha.z;
+            if (!body) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 0.0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) hm[r] = 0.0;
+            }
         }
-        // momentum h = Y v, bias force f = Y a + v x* h
-        const V3 hl = m * ov + cross(ow, hc);
-        const V3 ha = symv(Io, ow) + cross(hc, ov);
-        const V3 fl = m * oa + cross(oal, hc) + cross(ow, hl);
-        const V3 fa = symv(Io, oal) + cross(hc, oa) + cross(ow, ha) + cross(ov, hl);
-        sc[0] = m; sc[1] = hc.x; sc[2] = hc.y; sc[3] = hc.z;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) sc[4 + r] = Io[r];
-        sc[10] = fl.x; sc[11] = fl.y; sc[12] = fl.z; sc[13] = fa.x; sc[14] = fa.y; sc[15] = fa.z;
-        hm[0] = hl.x; hm[1] = hl.y; hm[2] = hl.z; hm[3] = ha.x; hm[4] = ha.y; hm[5] = ha.z;
-        if (!body) {
+        for (int r = 0; r < 16; ++r) sc[r] = scan_incl_dpp(sc[r], lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.0;
+        for (int r = 0; r < 6; ++r) hm[r] = wave_sum(hm[r]);
+        // entry 0 of the table is the empty prefix, entry i + 1 the sum over bodies 0..i
+        if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) hm[r] = 0.0;
+            for (int r = 0; r < 16; ++r) scan[r] = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) tots[r] = hm[r];
+        }
+        if (body) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scan[kScanStride * (lane + 1) + r] = sc[r];
+        }
+        TSTAMP(3)
+    }
+    else if (wave == 3) {
+        // ---- phase 1 beside the tree sweep: what needs the state only -------------------------------------------------
+        // posture: a_des = -Kp (q_a - ref) - Kd v_a (tsid TaskJointPosture; tasks.cpp:203-217)
+        for (int r = lane; r < T.n_sel; r += kWave) {
+            const int c = ip[T.i_sel_col + r], ja = c - (nv - na);
+            b1s[T.n_dense + r] = -T.posture_kp * (q[nq - na + ja] - ref[T.posture_ref + ja]) - T.posture_kd * v[c];
+        }
+        // joint bounds: tsid TaskJointPosVelAccBounds::computeAccLimits [UPSTREAM-RECALL, as oracle/rbd_oracle.c]
+        for (int j = lane; j < T.n_bound; j += kWave) {
+            const double dt = T.dt, qj = q[nq - na + j], dq = v[nv - na + j];
+            const double qmin = dp[T.d_qlb + j], qmax = dp[T.d_qub + j], dqmax = dp[T.d_dqmax + j], ddqmax = dqmax / dt;
+            const double two_dt_sq = 2.0 / (dt * dt), mdq_dt = -dq / dt;
+            const double max_q3 = two_dt_sq * (qmax - qj - dt * dq), min_q3 = two_dt_sq * (qmin - qj - dt * dq);
+            double lb_pos, ub_pos;
+            if (dq <= 0.0) {
+                ub_pos = max_q3;
+                if (min_q3 < mdq_dt) lb_pos = min_q3;
+                else if (qj != qmin) lb_pos = fmax(dq * dq / (2.0 * (qj - qmin)), mdq_dt);
+                else lb_pos = 1e6;
+            }
+            else {
+                lb_pos = min_q3;
+                if (max_q3 > mdq_dt) ub_pos = max_q3;
+                else if (qj != qmax) ub_pos = fmin(-dq * dq / (2.0 * (qmax - qj)), mdq_dt);
+                else ub_pos = -1e6;
+            }
+            const double lb_vel = (-dqmax - dq) / dt, ub_vel = (dqmax - dq) / dt;
+            const double dt_dq = dt * dq, two_a = 2.0 * dt * dt, dt_ddq_dt = ddqmax * dt * dt;
+            const double b_1 = 2.0 * dt_dq + dt_ddq_dt, b_2 = 2.0 * dt_dq - dt_ddq_dt;
+            const double c_1 = dq * dq - 2.0 * ddqmax * (qmax - (qj + dt_dq)), c_2 = dq * dq - 2.0 * ddqmax * ((qj + dt_dq) - qmin);
+            const double delta_1 = b_1 * b_1 - 2.0 * two_a * c_1, delta_2 = b_2 * b_2 - 2.0 * two_a * c_2;
+            const double ub_via = delta_1 >= 0.0 ? (-b_1 + sqrt(delta_1)) / two_a : mdq_dt;
+            const double lb_via = delta_2 >= 0.0 ? (-b_2 - sqrt(delta_2)) / two_a : mdq_dt;
+            double lb = fmax(fmax(lb_pos, lb_via), fmax(lb_vel, -ddqmax));
+            double ub = fmin(fmin(ub_pos, ub_via), fmin(ub_vel, ddqmax));
+            if (ub < lb) {
+                if (ub == ub_pos) lb = ub;
+                else ub = lb;
+            }
+            args.blb[(size_t)inst * T.n_bound + j] = (TI)lb;
+            args.bub[(size_t)inst * T.n_bound + j] = (TI)ub;
+        }
+        __syncthreads(); // barrier 1
+    }
+    else if (wave == 1) {
+        // ---- lanes = tasks with a frame (SE(3) blocks, then contacts): the law of ex_task.cpp:175-247, local frame ---------
+        // constant tables first: they travel while the tree wave works
+        const int ll = min(lane, max(T.nlaw - 1, 0));
+        const int l_body = ip[T.i_law_body + ll], l_ref = ip[T.i_law_ref + ll], l_va = ip[T.i_law_va + ll];
+        const int l_mask = ip[T.i_law_mask + ll], l_ct = ip[T.i_law_contact + ll], l_row = ip[T.i_law_row + ll];
+        const double l_kp = dp[T.d_law_kp + ll], l_kd = dp[T.d_law_kd + ll];
+        double l_place[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) l_place[r] = dp[T.d_law_place + 12 * ll + r];
+        __syncthreads(); // barrier 1: kin is complete
+        {
+            if (lane < T.nlaw) {
+                FrameKin f;
+                frame_kin(kin + kKinStride * l_body, l_place, f);
+                double* Lw = law + kLawStride * lane;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) Lw[r] = f.R[r];
+                st3(Lw + 9, f.p);
+                const double* rf = ref + l_ref;
+                // errorInSE3: M_err = oMf^-1 M_ref -> (translation, log3(rotation)); the reference rotation is column-major
+                const V3 pe = mtv(f.R, (ld3(rf) - p0) - f.p);
+                double Rr[9], Re[9], Rft[9];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { Rr[3 * i + j] = rf[3 + 3 * j + i]; Rft[3 * i + j] = f.R[3 * j + i]; }
+                mm(Rft, Rr, Re);
+                const V3 we = log3(Re);
+                V3 vr = {0, 0, 0}, wr = {0, 0, 0}, ar = {0, 0, 0}, alr = {0, 0, 0};
+                if (l_va) { // wMl^-1 v_ref, wMl^-1 a_ref (:201,208)
+                    vr = mtv(f.R, ld3(rf + 12)); wr = mtv(f.R, ld3(rf + 15));
+                    ar = mtv(f.R, ld3(rf + 18)); alr = mtv(f.R, ld3(rf + 21));
+                }
+                const double kp = l_kp, kd = l_kd;
+                const V3 rl_ = (kp * pe + kd * (vr - f.v) + ar) - f.a;
+                const V3 ra = (kp * we + kd * (wr - f.w) + alr) - f.al;
+                const double rhs[6] = {rl_.x, rl_.y, rl_.z, ra.x, ra.y, ra.z};
+                const int mask = l_mask, ct = l_ct;
+                double* out = (ct >= 0) ? bcs + 6 * ct : b1s + l_row;
+                int o = 0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if ((mask >> i) & 1) out[o++] = rhs[i];
+            }
+            TSTAMP(4)
         }
     }
+    else {
+        {
+            // ---- lanes = self-collision pairs (task-self-collision.cpp:84-203, 5PL repulsor :147-156) ---------------------
+            // the first 64 pairs' constants are fetched before the barrier, later chunks (if any) inside the loop
+            int bt, ba;
+            double ppt[12], ppa[12], ppar[6];
+            auto fetch = [&](int s) {
+                const int sc_ = min(s, max(T.npair - 1, 0));
+                bt = ip[T.i_pair_bt + sc_]; ba = ip[T.i_pair_ba + sc_];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = scan_incl(sc[r], lane);
+                for (int r = 0; r < 12; ++r) { ppt[r] = dp[T.d_pair_pt + 12 * sc_ + r]; ppa[r] = dp[T.d_pair_pa + 12 * sc_ + r]; }
 #pragma unroll
-    for (int r = 0; r < 6; ++r) hm[r] = wave_sum(hm[r]);
-    // entry 0 of the table is the empty prefix, entry i + 1 the sum over bodies 0..i
-    if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) scan[r] = 0.0;
+                for (int r = 0; r < 6; ++r) ppar[r] = dp[T.d_pair_par + 6 * sc_ + r];
+            };
+            fetch(lane);
+            __syncthreads(); // barrier 1: kin is complete
+            for (int s0 = 0; s0 < T.npair; s0 += kWave) {
+                const int s = s0 + lane;
+                if (s0 > 0) fetch(s);
+                if (s < T.npair) {
+                    FrameKin ft, fa;
+                    frame_kin(kin + kKinStride * bt, ppt, ft);
+                    frame_kin(kin + kKinStride * ba, ppa, fa);
+                    const double aa = ppar[0], k5 = ppar[1], s_p = ppar[2], mm_ = ppar[3], kp = ppar[4], kd = ppar[5];
+                    const V3 diff = ft.p - fa.p;
+                    const V3 drift = ft.a - fa.a; // each in its own frame's axes, as the reference subtracts them (:92,131-133)
+                    // J v for the WORLD Jacobians = difference of the bodies' spatial velocities at the true world origin
+                    const double* Kt = kin + kKinStride * bt;
+                    const double* Ka = kin + kKinStride * ba;
+                    const V3 Jv = (ld3(Kt + 12) + cross(p0, ld3(Kt + 15))) - (ld3(Ka + 12) + cross(p0, ld3(Ka + 15)));
+                    const double sn = dot(diff, diff), norm = sqrt(sn);
+                    const double x = k5 * (norm - aa + s_p);
+                    const double e_p = exp(-x), e1 = e_p + 1.0;
+                    const double pw1 = pow(e1, -mm_ - 1.0);         // (1 + e)^(-m-1); the two neighbouring powers follow from it
+                    const double C = 1.0 - pw1 * e1;
+                    const double gscale = -1.0 / norm * k5 * mm_ * e_p * pw1;
+                    const double hh = 1.0 / sn * k5 * k5 * (-mm_ - 1.0) * mm_ * (e_p * e_p) * (pw1 / e1)
+                        + 1.0 / sn * k5 * k5 * mm_ * e_p * pw1 + 1.0 / (norm * sqrt(norm)) * k5 * mm_ * e_p * pw1;
+                    const double dJv = dot(diff, Jv);
+                    const double quad = hh * dJv * dJv + gscale * dot(Jv, Jv); // Hess = hh diff diff' + gscale I (:156)
+                    const V3 gd = gscale * diff;
+                    const double g2 = dot(gd, kd * Jv - drift);
+                    double* Pw = pair + kPairStride * s;
+                    st3(Pw, gd);
+                    Pw[3] = -(quad + g2 + kp * C);
+                    Pw[4] = (double)bt;
+                    Pw[5] = (double)ba;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // self-collision right-hand side: the sum over the pairs of a block
+            if (lane < T.nblock && ip[T.i_blk_kind + lane] == T_SELFCOLLISION) {
+                double B = 0.0;
+                const int s0 = ip[T.i_blk_pair0 + lane], ns = ip[T.i_blk_npair + lane];
+                for (int s = s0; s < s0 + ns; ++s) B += pair[kPairStride * s + 3];
+                b1s[ip[T.i_blk_row + lane]] = B;
+            }
+            TSTAMP(5)
+        }
     }
-    if (body) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) scan[kScanStride * (lane + 1) + r] = sc[r];
-    }
-    __syncthreads();
-    // totals: mass, centre of mass (about p0), its velocity and bias acceleration, centroidal momentum and its bias rate
+    __syncthreads(); // barrier 2: scan table, task frames, pairs, right-hand sides of the framed tasks
+    TSTAMP(6)
+
+    // ---- phase 3: lanes = velocity coordinates, on every wave -----------------------------------------------------------
     const double* tot = scan + kScanStride * nb;
     const double mass = tot[0], imass = 1.0 / mass;
     const V3 com = imass * ld3(tot + 1);
-    const V3 htl = {hm[0], hm[1], hm[2]}, hta = {hm[3], hm[4], hm[5]};
-    const V3 vcom = imass * htl, acom = imass * ld3(tot + 10);
-    const V3 Lang = hta - cross(com, htl);                    // angular momentum about the com
-    const V3 dLang = ld3(tot + 13) - cross(com, ld3(tot + 10)); // its rate at ddq = 0
-
-    // ---- lanes = tasks with a frame (SE(3) blocks, then contacts): the law of ex_task.cpp:175-247, local frame ---------
-    if (lane < T.nlaw) {
-        FrameKin f;
-        frame_kin(kin + kKinStride * ip[T.i_law_body + lane], dp + T.d_law_place + 12 * lane, f);
-        double* Lw = law + kLawStride * lane;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) Lw[r] = f.R[r];
-        st3(Lw + 9, f.p);
-        const double* rf = ref + ip[T.i_law_ref + lane];
-        // errorInSE3: M_err = oMf^-1 M_ref -> (translation, log3(rotation)); the reference rotation is column-major
-        const V3 pe = mtv(f.R, (ld3(rf) - p0) - f.p);
-        double Rr[9], Re[9], Rft[9];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { Rr[3 * i + j] = rf[3 + 3 * j + i]; Rft[3 * i + j] = f.R[3 * j + i]; }
-        mm(Rft, Rr, Re);
-        const V3 we = log3(Re);
-        V3 vr = {0, 0, 0}, wr = {0, 0, 0}, ar = {0, 0, 0}, alr = {0, 0, 0};
-        if (ip[T.i_law_va + lane]) { // wMl^-1 v_ref, wMl^-1 a_ref (:201,208)
-            vr = mtv(f.R, ld3(rf + 12)); wr = mtv(f.R, ld3(rf + 15));
-            ar = mtv(f.R, ld3(rf + 18)); alr = mtv(f.R, ld3(rf + 21));
-        }
-        const double kp = dp[T.d_law_kp + lane], kd = dp[T.d_law_kd + lane];
-        const V3 rl = (kp * pe + kd * (vr - f.v) + ar) - f.a;
-        const V3 ra = (kp * we + kd * (wr - f.w) + alr) - f.al;
-        const double rhs[6] = {rl.x, rl.y, rl.z, ra.x, ra.y, ra.z};
-        const int mask = ip[T.i_law_mask + lane], ct = ip[T.i_law_contact + lane];
-        double* out = (ct >= 0) ? bcs + 6 * ct : b1s + ip[T.i_law_row + lane];
-        int o = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if ((mask >> i) & 1) out[o++] = rhs[i];
-    }
-    // ---- lanes = self-collision pairs (task-self-collision.cpp:84-203, 5PL repulsor :147-156) -------------------------
-    for (int s0 = 0; s0 < T.npair; s0 += kWave) {
-        const int s = s0 + lane;
-        if (s < T.npair) {
-            const int bt = ip[T.i_pair_bt + s], ba = ip[T.i_pair_ba + s];
-            FrameKin ft, fa;
-            frame_kin(kin + kKinStride * bt, dp + T.d_pair_pt + 12 * s, ft);
-            frame_kin(kin + kKinStride * ba, dp + T.d_pair_pa + 12 * s, fa);
-            const double* par_ = dp + T.d_pair_par + 6 * s;
-            const double aa = par_[0], k5 = par_[1], s_p = par_[2], mm_ = par_[3], kp = par_[4], kd = par_[5];
-            const V3 diff = ft.p - fa.p;
-            const V3 drift = ft.a - fa.a; // each in its own frame's axes, as the reference subtracts them (:92,131-133)
-            // J v for the WORLD Jacobians = difference of the bodies' spatial velocities at the true world origin
-            const double* Kt = kin + kKinStride * bt;
-            const double* Ka = kin + kKinStride * ba;
-            const V3 Jv = (ld3(Kt + 12) + cross(p0, ld3(Kt + 15))) - (ld3(Ka + 12) + cross(p0, ld3(Ka + 15)));
-            const double sn = dot(diff, diff), norm = sqrt(sn);
-            const double x = k5 * (norm - aa + s_p);
-            const double e_p = exp(-x);
-            const double pw1 = pow(e_p + 1.0, -mm_ - 1.0);
-            const double C = 1.0 - pow(1.0 + e_p, -mm_);
-            const double gscale = -1.0 / norm * k5 * mm_ * e_p * pw1;
-            const double hh = 1.0 / sn * k5 * k5 * (-mm_ - 1.0) * mm_ * exp(-2.0 * x) * pow(e_p + 1.0, -mm_ - 2.0)
-                + 1.0 / sn * k5 * k5 * mm_ * e_p * pw1 + 1.0 / pow(norm, 1.5) * k5 * mm_ * e_p * pw1;
-            const double dJv = dot(diff, Jv);
-            const double quad = hh * dJv * dJv + gscale * dot(Jv, Jv); // Hess = hh diff diff' + gscale I (:156)
-            const V3 gd = gscale * diff;
-            const double g2 = dot(gd, kd * Jv - drift);
-            double* Pw = pair + kPairStride * s;
-            st3(Pw, gd);
-            Pw[3] = -(quad + g2 + kp * C);
-            Pw[4] = (double)bt;
-            Pw[5] = (double)ba;
-        }
-    }
-    // posture: a_des = -Kp (q_a - ref) - Kd v_a (tsid TaskJointPosture; tasks.cpp:203-217)
-    for (int r = lane; r < T.n_sel; r += kWave) {
-        const int c = ip[T.i_sel_col + r], ja = c - (nv - na);
-        b1s[T.n_dense + r] = -T.posture_kp * (q[nq - na + ja] - ref[T.posture_ref + ja]) - T.posture_kd * v[c];
-    }
-    // CoM and momentum right-hand sides (tsid TaskComEquality; task-momentum-equality.cpp:151-165)
-    if (lane == 0) {
-        for (int t = 0; t < T.nblock; ++t) {
-            const int kind = ip[T.i_blk_kind + t];
-            if (kind != T_COM && kind != T_MOMENTUM) continue;
-            const int mask = ip[T.i_blk_mask + t];
-            const double* rf = ref + ip[T.i_blk_ref + t];
-            const double kp = dp[T.d_blk_kp + t], kd = dp[T.d_blk_kd + t];
-            double* out = b1s + ip[T.i_blk_row + t];
-            int o = 0;
-            if (kind == T_COM) {
-                const V3 e = com - (ld3(rf) - p0);
-                const V3 r = (-kp * e - kd * (vcom - ld3(rf + 3)) + ld3(rf + 6)) - acom;
-                const double rr[3] = {r.x, r.y, r.z};
-                for (int i = 0; i < 3; ++i)
-                    if ((mask >> i) & 1) out[o++] = rr[i];
-            }
-            else {
-                const double L[6] = {htl.x, htl.y, htl.z, Lang.x, Lang.y, Lang.z};
-                const double dL[6] = {tot[10], tot[11], tot[12], dLang.x, dLang.y, dLang.z};
-                for (int i = 0; i < 6; ++i)
-                    if ((mask >> i) & 1) out[o++] = (-kp * (L[i] - rf[i]) + rf[6 + i]) - dL[i];
-            }
-        }
-    }
-    __syncthreads();
-    // self-collision right-hand side: the sum over the pairs of a block
-    if (lane < T.nblock && ip[T.i_blk_kind + lane] == T_SELFCOLLISION) {
-        double B = 0.0;
-        const int s0 = ip[T.i_blk_pair0 + lane], ns = ip[T.i_blk_npair + lane];
-        for (int s = s0; s < s0 + ns; ++s) B += pair[kPairStride * s + 3];
-        b1s[ip[T.i_blk_row + lane]] = B;
-    }
-
-    // ---- lanes = velocity coordinates --------------------------------------------------------------------------------
+    const V3 htl = ld3(tots), hta = ld3(tots + 3);
     const bool colv = lane < nv;
     const int cj = colv ? lane : 0;
     const int bj = ip[T.i_bodyof + cj], kj = ip[T.i_kof + cj];
@@ -441,13 +565,14 @@ __global__ __launch_bounds__(kWave) void terms_kernel(const TermsArgs<TI> args)
     {
         const double* K = kin + kKinStride * bj;
         const int jtj = ip[T.i_jtype + bj];
+        // the column of the joint's motion subspace in its own axes, then oMi.act(.)
+        const int a = (jtj == J_FREEFLYER) ? (kj % 3) : (jtj <= J_RZ) ? jtj - J_RX : jtj - J_PX;
+        const bool ang = (jtj == J_FREEFLYER) ? (kj >= 3) : (jtj <= J_RZ);
+        const V3 ax = col(K, 0), ay = col(K, 1), az = col(K, 2);
+        const V3 wa = (a == 0) ? ax : (a == 1) ? ay : az; // world direction of the axis
         const V3 pj = ld3(K + 9);
-        if (jtj == J_FREEFLYER) {
-            if (kj < 3) { Sv = col(K, kj); Sw = {0, 0, 0}; }
-            else { Sw = col(K, kj - 3); Sv = cross(pj, Sw); }
-        }
-        else if (jtj <= J_RZ) { Sw = col(K, jtj - J_RX); Sv = cross(pj, Sw); }
-        else { Sv = col(K, jtj - J_PX); Sw = {0, 0, 0}; }
+        if (ang) { Sw = wa; Sv = cross(pj, wa); }
+        else { Sv = wa; Sw = {0, 0, 0}; }
     }
     V3 Fv, Fw;
     {
@@ -460,113 +585,133 @@ __global__ __launch_bounds__(kWave) void terms_kernel(const TermsArgs<TI> args)
         const V3 hc = {Y[1], Y[2], Y[3]};
         Fv = Y[0] * Sv + cross(Sw, hc);
         Fw = symv(Y + 4, Sw) + cross(hc, Sv);
-        if (colv) { st3(Fl + kFStride * lane, Fv); st3(Fl + kFStride * lane + 3, Fw); }
         // non-linear effects: bias force of the subtree + its weight, projected on the joint axis
-        const V3 gvec = {T.g[0], T.g[1], T.g[2]};
-        const V3 gl = ld3(Y + 10) - Y[0] * gvec;
-        const V3 ga = ld3(Y + 13) - cross(hc, gvec);
-        if (colv) args.h[(size_t)inst * nv + lane] = (TI)(dot(Sv, gl) + dot(Sw, ga));
-    }
-    __syncthreads();
-    // M, row by row into the packed lower triangle: M(i, j) = S_j . F_i for j an ancestor dof of i (crba)
-    {
-        TI* Mo = args.M + (size_t)inst * (nv * (nv + 1) / 2);
-        for (int i = 0; i < nv; ++i) {
-            const int b_i = ip[T.i_bodyof + i];
-            const double* F = Fl + kFStride * i;
-            const double val = dot(Sv, ld3(F)) + dot(Sw, ld3(F + 3));
-            if (lane <= i) Mo[i * (i + 1) / 2 + lane] = (TI)((bj <= b_i && b_i <= lastj) ? val : 0.0);
+        if (wave == 0) {
+            const V3 gvec = {T.g[0], T.g[1], T.g[2]};
+            const V3 gl = ld3(Y + 10) - Y[0] * gvec;
+            const V3 ga = ld3(Y + 13) - cross(hc, gvec);
+            if (colv) args.h[(size_t)inst * nv + lane] = (TI)(dot(Sv, gl) + dot(Sw, ga));
         }
     }
+    TSTAMP(7)
+    // M, row by row into the packed lower triangle: M(i, j) = S_j . F_i for j an ancestor dof of i (crba); F_i by readlane
+    {
+        TI* Mo = args.M + (size_t)inst * (nv * (nv + 1) / 2);
+        auto row = [&](int i, int ic) {
+            // ic = i clamped into [0, nv): a wave whose last step has no row left still reads valid lanes
+            const int b_i = rl(bj, ic);
+            const V3 fv = {bcast_lane(Fv.x, ic), bcast_lane(Fv.y, ic), bcast_lane(Fv.z, ic)};
+            const V3 fw = {bcast_lane(Fw.x, ic), bcast_lane(Fw.y, ic), bcast_lane(Fw.z, ic)};
+            const double val = dot(Sv, fv) + dot(Sw, fw);
+            if (i < nv && lane <= i) Mo[i * (i + 1) / 2 + lane] = (TI)((bj <= b_i && b_i <= lastj) ? val : 0.0);
+        };
+        for (int i = wave; i < nv; i += 2 * kWaves) { // two independent rows per trip
+            row(i, i);
+            row(i + kWaves, min(i + kWaves, nv - 1));
+        }
+    }
+    TSTAMP(8)
     // Jacobian rows of the tasks with a frame: local frame, rows picked by the mask (ex_task.cpp:233-236)
-    if (colv) {
-        TI* Ao = args.A + (size_t)inst * T.n_dense * nv;
+    TI* Ao = args.A + (size_t)inst * T.n_dense * nv;
+    {
         TI* Aco = args.Ac + (size_t)inst * T.nc * 6 * nv;
-        for (int l = 0; l < T.nlaw; ++l) {
+        // lane l holds the table entries of task l; the loop reads them back as uniform values
+        const int ll = min(lane, max(T.nlaw - 1, 0));
+        const int t_body = ip[T.i_law_body + ll], t_mask = ip[T.i_law_mask + ll], t_ct = ip[T.i_law_contact + ll], t_row = ip[T.i_law_row + ll];
+        for (int l = wave; l < T.nlaw; l += kWaves) {
             const double* Lw = law + kLawStride * l;
-            const int bl = ip[T.i_law_body + l], mask = ip[T.i_law_mask + l], ct = ip[T.i_law_contact + l];
+            const int bl = rl(t_body, l), mask = rl(t_mask, l), ct = rl(t_ct, l), row = rl(t_row, l);
             const bool sup = bj <= bl && bl <= lastj;
             const V3 pf = ld3(Lw + 9);
             const V3 jl = mtv(Lw, Sv + cross(Sw, pf)), ja = mtv(Lw, Sw);
             const double e[6] = {jl.x, jl.y, jl.z, ja.x, ja.y, ja.z};
-            TI* out = (ct >= 0) ? Aco + (size_t)ct * 6 * nv : Ao + (size_t)ip[T.i_law_row + l] * nv;
+            TI* out = (ct >= 0) ? Aco + (size_t)ct * 6 * nv : Ao + (size_t)row * nv;
             int o = 0;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
-                if ((mask >> i) & 1) { out[(size_t)o * nv + lane] = (TI)(sup ? e[i] : 0.0); ++o; }
+                if ((mask >> i) & 1) {
+                    if (colv) out[(size_t)o * nv + lane] = (TI)(sup ? e[i] : 0.0);
+                    ++o;
+                }
         }
-        // CoM, momentum and self-collision rows
+    }
+    TSTAMP(9)
+    // CoM, momentum and self-collision rows and the CoM / momentum right-hand sides, one block per wave in turn
+    {
+        const int tt = min(lane, max(T.nblock - 1, 0));
+        const int k_kind = ip[T.i_blk_kind + tt], k_mask = ip[T.i_blk_mask + tt], k_row = ip[T.i_blk_row + tt];
+        const int k_p0 = ip[T.i_blk_pair0 + tt], k_np = ip[T.i_blk_npair + tt], k_ref = ip[T.i_blk_ref + tt];
+        const double k_kp = dp[T.d_blk_kp + tt], k_kd = dp[T.d_blk_kd + tt];
         const V3 lt = Sv + cross(p0, Sw); // WORLD Jacobian column (linear part): about the true world origin
-        for (int t = 0; t < T.nblock; ++t) {
-            const int kind = ip[T.i_blk_kind + t];
+        for (int t = wave; t < T.nblock; t += kWaves) {
+            const int kind = rl(k_kind, t);
             if (kind == T_SE3) continue;
-            TI* out = Ao + (size_t)ip[T.i_blk_row + t] * nv;
-            const int mask = ip[T.i_blk_mask + t];
+            const int mask = rl(k_mask, t), row = rl(k_row, t);
+            TI* out = Ao + (size_t)row * nv;
             if (kind == T_COM) {
+                // tsid TaskComEquality: rows of Jcom; a_des = -Kp (com - ref) - Kd (vcom - vref) + aref, minus the drift
                 const double e[3] = {imass * Fv.x, imass * Fv.y, imass * Fv.z};
+                const double* rf = ref + rl(k_ref, t);
+                const double kp = bcast_lane(k_kp, t), kd = bcast_lane(k_kd, t);
+                const V3 vcom = imass * htl, acom = imass * ld3(tot + 10);
+                const V3 er = com - (ld3(rf) - p0);
+                const V3 r = (-kp * er - kd * (vcom - ld3(rf + 3)) + ld3(rf + 6)) - acom;
+                const double rr[3] = {r.x, r.y, r.z};
                 int o = 0;
                 for (int i = 0; i < 3; ++i)
-                    if ((mask >> i) & 1) { out[(size_t)o * nv + lane] = (TI)e[i]; ++o; }
+                    if ((mask >> i) & 1) {
+                        if (colv) out[(size_t)o * nv + lane] = (TI)e[i];
+                        if (lane == 0) b1s[row + o] = rr[i];
+                        ++o;
+                    }
             }
             else if (kind == T_MOMENTUM) {
+                // task-momentum-equality.cpp:151-165: rows of Ag; dL_des = -Kp (L - ref') + ref'', minus the drift
                 const V3 an = Fw - cross(com, Fv);
                 const double e[6] = {Fv.x, Fv.y, Fv.z, an.x, an.y, an.z};
+                const double* rf = ref + rl(k_ref, t);
+                const double kp = bcast_lane(k_kp, t);
+                const V3 Lang = hta - cross(com, htl);                      // angular momentum about the com
+                const V3 dLang = ld3(tot + 13) - cross(com, ld3(tot + 10)); // its rate at ddq = 0
+                const double L[6] = {htl.x, htl.y, htl.z, Lang.x, Lang.y, Lang.z};
+                const double dL[6] = {tot[10], tot[11], tot[12], dLang.x, dLang.y, dLang.z};
                 int o = 0;
                 for (int i = 0; i < 6; ++i)
-                    if ((mask >> i) & 1) { out[(size_t)o * nv + lane] = (TI)e[i]; ++o; }
+                    if ((mask >> i) & 1) {
+                        if (colv) out[(size_t)o * nv + lane] = (TI)e[i];
+                        if (lane == 0) b1s[row + o] = (-kp * (L[i] - rf[i]) + rf[6 + i]) - dL[i];
+                        ++o;
+                    }
             }
             else {
                 // A = sum grad_C' (J_tracked - J_avoided): the WORLD columns coincide wherever both frames hang on dof j
                 V3 acc = {0, 0, 0};
-                const int s0 = ip[T.i_blk_pair0 + t], ns = ip[T.i_blk_npair + t];
+                const int s0 = rl(k_p0, t), ns = rl(k_np, t);
+#pragma unroll 4
                 for (int s = s0; s < s0 + ns; ++s) {
                     const double* Pw = pair + kPairStride * s;
                     const int bt = (int)Pw[4], ba = (int)Pw[5];
                     const double sg = (double)((bj <= bt && bt <= lastj) ? 1 : 0) - (double)((bj <= ba && ba <= lastj) ? 1 : 0);
                     acc = acc + sg * ld3(Pw);
                 }
-                out[lane] = (TI)dot(acc, lt);
+                if (colv) out[lane] = (TI)dot(acc, lt);
             }
         }
     }
-    // joint bounds: tsid TaskJointPosVelAccBounds::computeAccLimits [UPSTREAM-RECALL, as oracle/rbd_oracle.c]
-    for (int j = lane; j < T.n_bound; j += kWave) {
-        const double dt = T.dt, qj = q[nq - na + j], dq = v[nv - na + j];
-        const double qmin = dp[T.d_qlb + j], qmax = dp[T.d_qub + j], dqmax = dp[T.d_dqmax + j], ddqmax = dqmax / dt;
-        const double two_dt_sq = 2.0 / (dt * dt), mdq_dt = -dq / dt;
-        const double max_q3 = two_dt_sq * (qmax - qj - dt * dq), min_q3 = two_dt_sq * (qmin - qj - dt * dq);
-        double lb_pos, ub_pos;
-        if (dq <= 0.0) {
-            ub_pos = max_q3;
-            if (min_q3 < mdq_dt) lb_pos = min_q3;
-            else if (qj != qmin) lb_pos = fmax(dq * dq / (2.0 * (qj - qmin)), mdq_dt);
-            else lb_pos = 1e6;
-        }
-        else {
-            lb_pos = min_q3;
-            if (max_q3 > mdq_dt) ub_pos = max_q3;
-            else if (qj != qmax) ub_pos = fmin(-dq * dq / (2.0 * (qmax - qj)), mdq_dt);
-            else ub_pos = -1e6;
-        }
-        const double lb_vel = (-dqmax - dq) / dt, ub_vel = (dqmax - dq) / dt;
-        const double dt_dq = dt * dq, two_a = 2.0 * dt * dt, dt_ddq_dt = ddqmax * dt * dt;
-        const double b_1 = 2.0 * dt_dq + dt_ddq_dt, b_2 = 2.0 * dt_dq - dt_ddq_dt;
-        const double c_1 = dq * dq - 2.0 * ddqmax * (qmax - (qj + dt_dq)), c_2 = dq * dq - 2.0 * ddqmax * ((qj + dt_dq) - qmin);
-        const double delta_1 = b_1 * b_1 - 2.0 * two_a * c_1, delta_2 = b_2 * b_2 - 2.0 * two_a * c_2;
-        const double ub_via = delta_1 >= 0.0 ? (-b_1 + sqrt(delta_1)) / two_a : mdq_dt;
-        const double lb_via = delta_2 >= 0.0 ? (-b_2 - sqrt(delta_2)) / two_a : mdq_dt;
-        double lb = fmax(fmax(lb_pos, lb_via), fmax(lb_vel, -ddqmax));
-        double ub = fmin(fmin(ub_pos, ub_via), fmin(ub_vel, ddqmax));
-        if (ub < lb) {
-            if (ub == ub_pos) lb = ub;
-            else ub = lb;
-        }
-        args.blb[(size_t)inst * T.n_bound + j] = (TI)lb;
-        args.bub[(size_t)inst * T.n_bound + j] = (TI)ub;
-    }
+    TSTAMP(10)
     __syncthreads();
-    for (int i = lane; i < T.r1; i += kWave) args.b1[(size_t)inst * T.r1 + i] = (TI)b1s[i];
-    for (int i = lane; i < 6 * T.nc; i += kWave) args.bc[(size_t)inst * 6 * T.nc + i] = (TI)bcs[i];
+    for (int i = tid; i < T.r1; i += kTermsThreads) args.b1[(size_t)inst * T.r1 + i] = (TI)b1s[i];
+    for (int i = tid; i < 6 * T.nc; i += kTermsThreads) args.bc[(size_t)inst * 6 * T.nc + i] = (TI)bcs[i];
+#ifdef WBCQP_STAMPS
+    TSTAMP(11)
+    // every wave accumulates its own phases; wave w writes the slots it owns (0: 0-3,6-11; 1: 4; 2: 5)
+    if (lane == 0 && args.dbg) {
+        long long* D = args.dbg + (size_t)inst * 24;
+        if (wave == 0) { for (int i = 0; i < 12; ++i) if (i != 4 && i != 5) D[i] = tacc_[i]; }
+        if (wave == 1) D[4] = tacc_[4];
+        if (wave == 2) D[5] = tacc_[5];
+    }
+#endif
 }
 
 #endif // __HIPCC__
