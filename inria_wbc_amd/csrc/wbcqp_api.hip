@@ -643,7 +643,15 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     // tasks -> law lanes (SE3 blocks then contacts), self-collision pairs, blocks
     std::vector<int> law_body, law_mask, law_row, law_ref, law_va, law_contact, pair_block, pair_bt, pair_ba;
     std::vector<int> blk_kind, blk_mask, blk_row, blk_ref, blk_law, blk_pair0, blk_npair;
-    std::vector<double> law_place, law_kp, law_kd, pair_pt, pair_pa, pair_par, blk_kp, blk_kd;
+    std::vector<double> law_place, law_kp, law_kd, scf_place, pair_par, blk_kp, blk_kd;
+    std::vector<int> scf_frame, scf_body, pair_ft, pair_fa;
+    auto scf_index = [&](int f) {
+        for (size_t k = 0; k < scf_frame.size(); ++k)
+            if (scf_frame[k] == f) return (int)k;
+        scf_frame.push_back(f); scf_body.push_back(md->frame_body[f]);
+        scf_place.insert(scf_place.end(), md->frame_placement + 12 * f, md->frame_placement + 12 * f + 12);
+        return (int)scf_frame.size() - 1;
+    };
     auto popc = [](int m, int bits) { int c = 0; for (int i = 0; i < bits; ++i) c += (m >> i) & 1; return c; };
     int row = 0;
     for (int t = 0; t < tm->n_task; ++t) {
@@ -674,8 +682,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
                 const int fa = K.avoided_frame[a];
                 if (!frame_ok(fa)) return fail(h, WBCQP_ERR_INVALID, "self-collision task avoids a frame that does not exist");
                 pair_block.push_back(t); pair_bt.push_back(md->frame_body[K.frame]); pair_ba.push_back(md->frame_body[fa]);
-                pair_pt.insert(pair_pt.end(), md->frame_placement + 12 * K.frame, md->frame_placement + 12 * K.frame + 12);
-                pair_pa.insert(pair_pa.end(), md->frame_placement + 12 * fa, md->frame_placement + 12 * fa + 12);
+                pair_ft.push_back(scf_index(K.frame)); pair_fa.push_back(scf_index(fa));
                 const double par[6] = {K.avoided_r0[a] + K.radius, k5, s_p, K.m, K.kp, K.kd};
                 pair_par.insert(pair_par.end(), par, par + 6);
             }
@@ -694,7 +701,8 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
         law_va.push_back(0); law_contact.push_back(c); law_kp.push_back(tm->contact_kp[c]); law_kd.push_back(tm->contact_kd[c]);
         law_place.insert(law_place.end(), md->frame_placement + 12 * f, md->frame_placement + 12 * f + 12);
     }
-    if ((int)law_body.size() > kWave || (int)blk_kind.size() > kWave) return fail(h, WBCQP_ERR_UNSUPPORTED, "more than 64 framed tasks (one lane per task)");
+    if ((int)law_body.size() > kWave || (int)blk_kind.size() > kWave || (int)scf_frame.size() > kWave)
+        return fail(h, WBCQP_ERR_UNSUPPORTED, "more than 64 framed tasks or self-collision frames (one lane each)");
     if (D.n_sel > 0 && (tm->posture_ref < 0 || tm->posture_ref + na > tm->nref)) return fail(h, WBCQP_ERR_INVALID, "the posture reference lies outside the reference vector");
     if (D.n_bound > 0 && (!md->q_lb || !md->q_ub || !md->dq_max)) return fail(h, WBCQP_ERR_INVALID, "bounds need q_lb / q_ub / dq_max");
 
@@ -710,7 +718,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
             const int a = anc[(size_t)(r - 1) * nb + i];
             anc[(size_t)r * nb + i] = (a >= 0) ? anc[(size_t)(r - 1) * nb + a] : -1;
         }
-    T.nlaw = (int)law_body.size(); T.npair = (int)pair_block.size(); T.nblock = (int)blk_kind.size(); T.nc = D.nc;
+    T.nlaw = (int)law_body.size(); T.npair = (int)pair_block.size(); T.nscf = (int)scf_frame.size(); T.nblock = (int)blk_kind.size(); T.nc = D.nc;
     T.n_dense = D.n_dense; T.n_sel = D.n_sel; T.n_bound = D.n_bound; T.r1 = D.r1; T.nref = tm->nref;
     T.posture_ref = tm->posture_ref; T.posture_kp = tm->posture_kp; T.posture_kd = tm->posture_kd; T.dt = tm->dt;
     for (int k = 0; k < 3; ++k) T.g[k] = md->gravity[k];
@@ -731,6 +739,8 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     T.i_law_va = puti(law_va.data(), law_va.size()); T.i_law_contact = puti(law_contact.data(), law_contact.size());
     T.i_pair_block = puti(pair_block.data(), pair_block.size()); T.i_pair_bt = puti(pair_bt.data(), pair_bt.size());
     T.i_pair_ba = puti(pair_ba.data(), pair_ba.size());
+    T.i_pair_ft = puti(pair_ft.data(), pair_ft.size()); T.i_pair_fa = puti(pair_fa.data(), pair_fa.size());
+    T.i_scf_body = puti(scf_body.data(), scf_body.size());
     T.i_blk_kind = puti(blk_kind.data(), blk_kind.size()); T.i_blk_mask = puti(blk_mask.data(), blk_mask.size());
     T.i_blk_row = puti(blk_row.data(), blk_row.size()); T.i_blk_ref = puti(blk_ref.data(), blk_ref.size());
     T.i_blk_law = puti(blk_law.data(), blk_law.size()); T.i_blk_pair0 = puti(blk_pair0.data(), blk_pair0.size());
@@ -738,7 +748,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     T.d_place = putd(md->placement, (size_t)nb * 12); T.d_inertia = putd(md->inertia, (size_t)nb * 10);
     T.d_law_place = putd(law_place.data(), law_place.size()); T.d_law_kp = putd(law_kp.data(), law_kp.size());
     T.d_law_kd = putd(law_kd.data(), law_kd.size());
-    T.d_pair_pt = putd(pair_pt.data(), pair_pt.size()); T.d_pair_pa = putd(pair_pa.data(), pair_pa.size());
+    T.d_scf_place = putd(scf_place.data(), scf_place.size());
     T.d_pair_par = putd(pair_par.data(), pair_par.size());
     T.d_blk_kp = putd(blk_kp.data(), blk_kp.size()); T.d_blk_kd = putd(blk_kd.data(), blk_kd.size());
     T.d_qlb = putd(md->q_lb, D.n_bound ? na : 0); T.d_qub = putd(md->q_ub, D.n_bound ? na : 0); T.d_dqmax = putd(md->dq_max, D.n_bound ? na : 0);
@@ -750,6 +760,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     T.o_F = take(8); // momentum totals
     T.o_law = take(T.nlaw * kLawStride);
     T.o_pair = take(T.npair * kPairStride);
+    T.o_scf = take(T.nscf * kScfStride);
     T.o_b1 = take(D.r1);
     T.o_bc = take(6 * D.nc);
     T.lds_doubles = o;

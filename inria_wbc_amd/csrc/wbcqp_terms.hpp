@@ -34,11 +34,12 @@ constexpr int kScanStride = 17; // per body: m, m c (3), inertia about the origi
 constexpr int kFStride = 7;
 constexpr int kLawStride = 13;  // per task frame: R (9) p (3)
 constexpr int kPairStride = 7;  // per self-collision pair: grad (3), rhs share, tracked body, avoided body
+constexpr int kScfStride = 7;   // per self-collision frame: position (3), classical linear acceleration in its own axes (3)
 
 // Constant tables of one (model, task map), resident in device memory; offsets index the two pools.
 struct TermsDev {
     int nb, nq, nv, na, floating_base, maxdepth, nrounds;
-    int nlaw, npair, nblock, nc, n_dense, n_sel, n_bound, r1, nref;
+    int nlaw, npair, nscf, nblock, nc, n_dense, n_sel, n_bound, r1, nref;
     int posture_ref;
     double posture_kp, posture_kd, dt;
     double g[3];
@@ -49,17 +50,18 @@ struct TermsDev {
     int i_anc;                                              // [nrounds][nb] 2^r-th ancestor, -1 beyond the root
     int i_bodyof, i_kof;                                    // [nv]
     int i_law_body, i_law_mask, i_law_row, i_law_ref, i_law_va, i_law_contact; // [nlaw]
-    int i_pair_block, i_pair_bt, i_pair_ba;                 // [npair]
+    int i_pair_block, i_pair_bt, i_pair_ba, i_pair_ft, i_pair_fa; // [npair] bodies and self-collision-frame indices
+    int i_scf_body;                                         // [nscf] distinct frames the self-collision tasks touch
     int i_blk_kind, i_blk_mask, i_blk_row, i_blk_ref, i_blk_law, i_blk_pair0, i_blk_npair; // [nblock]
     int i_sel_col;                                          // [n_sel]
     // double pool offsets
     int d_place, d_inertia;                                  // [nb][12], [nb][10]
     int d_law_place, d_law_kp, d_law_kd;                     // [nlaw][12], [nlaw], [nlaw]
-    int d_pair_pt, d_pair_pa, d_pair_par;                    // [npair][12], [npair][12], [npair][6]: aa, k, s_p, m, kp, kd
+    int d_scf_place, d_pair_par;                             // [nscf][12], [npair][6]: aa, k, s_p, m, kp, kd
     int d_blk_kp, d_blk_kd;                                  // [nblock]
     int d_qlb, d_qub, d_dqmax;                               // [na]
     // LDS layout (doubles)
-    int o_state, o_kin, o_scan, o_F, o_law, o_pair, o_b1, o_bc;
+    int o_state, o_kin, o_scan, o_F, o_law, o_pair, o_scf, o_b1, o_bc;
     int lds_doubles;
 };
 
@@ -490,26 +492,41 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     else {
         {
             // ---- lanes = self-collision pairs (task-self-collision.cpp:84-203, 5PL repulsor :147-156) ---------------------
-            // the first 64 pairs' constants are fetched before the barrier, later chunks (if any) inside the loop
-            int bt, ba;
-            double ppt[12], ppa[12], ppar[6];
+            // two passes on this wave: lanes = the distinct frames the tasks touch (placement, classical acceleration), then
+            // lanes = pairs.  The constants of both are fetched before the barrier.
+            double* scf = lds + T.o_scf;
+            const int fl = min(lane, max(T.nscf - 1, 0));
+            const int f_body = ip[T.i_scf_body + fl];
+            double f_place[12];
+#pragma unroll
+            for (int r = 0; r < 12; ++r) f_place[r] = dp[T.d_scf_place + 12 * fl + r];
+            int bt, ba, it, ia;
+            double ppar[6];
             auto fetch = [&](int s) {
                 const int sc_ = min(s, max(T.npair - 1, 0));
                 bt = ip[T.i_pair_bt + sc_]; ba = ip[T.i_pair_ba + sc_];
-#pragma unroll
-                for (int r = 0; r < 12; ++r) { ppt[r] = dp[T.d_pair_pt + 12 * sc_ + r]; ppa[r] = dp[T.d_pair_pa + 12 * sc_ + r]; }
+                it = ip[T.i_pair_ft + sc_]; ia = ip[T.i_pair_fa + sc_];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) ppar[r] = dp[T.d_pair_par + 6 * sc_ + r];
             };
             fetch(lane);
             __syncthreads(); // barrier 1: kin is complete
+            if (lane < T.nscf) {
+                FrameKin f;
+                frame_kin(kin + kKinStride * f_body, f_place, f);
+                st3(scf + kScfStride * lane, f.p);
+                st3(scf + kScfStride * lane + 3, f.a);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int s0 = 0; s0 < T.npair; s0 += kWave) {
                 const int s = s0 + lane;
                 if (s0 > 0) fetch(s);
                 if (s < T.npair) {
-                    FrameKin ft, fa;
-                    frame_kin(kin + kKinStride * bt, ppt, ft);
-                    frame_kin(kin + kKinStride * ba, ppa, fa);
+                    struct { V3 p, a; } ft, fa;
+                    ft.p = ld3(scf + kScfStride * it); ft.a = ld3(scf + kScfStride * it + 3);
+                    fa.p = ld3(scf + kScfStride * ia); fa.a = ld3(scf + kScfStride * ia + 3);
                     const double aa = ppar[0], k5 = ppar[1], s_p = ppar[2], mm_ = ppar[3], kp = ppar[4], kd = ppar[5];
                     const V3 diff = ft.p - fa.p;
                     const V3 drift = ft.a - fa.a; // each in its own frame's axes, as the reference subtracts them (:92,131-133)
@@ -597,17 +614,12 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     // M, row by row into the packed lower triangle: M(i, j) = S_j . F_i for j an ancestor dof of i (crba); F_i by readlane
     {
         TI* Mo = args.M + (size_t)inst * (nv * (nv + 1) / 2);
-        auto row = [&](int i, int ic) {
-            // ic = i clamped into [0, nv): a wave whose last step has no row left still reads valid lanes
-            const int b_i = rl(bj, ic);
-            const V3 fv = {bcast_lane(Fv.x, ic), bcast_lane(Fv.y, ic), bcast_lane(Fv.z, ic)};
-            const V3 fw = {bcast_lane(Fw.x, ic), bcast_lane(Fw.y, ic), bcast_lane(Fw.z, ic)};
+        for (int i = wave; i < nv; i += kWaves) {
+            const int b_i = rl(bj, i);
+            const V3 fv = {bcast_lane(Fv.x, i), bcast_lane(Fv.y, i), bcast_lane(Fv.z, i)};
+            const V3 fw = {bcast_lane(Fw.x, i), bcast_lane(Fw.y, i), bcast_lane(Fw.z, i)};
             const double val = dot(Sv, fv) + dot(Sw, fw);
-            if (i < nv && lane <= i) Mo[i * (i + 1) / 2 + lane] = (TI)((bj <= b_i && b_i <= lastj) ? val : 0.0);
-        };
-        for (int i = wave; i < nv; i += 2 * kWaves) { // two independent rows per trip
-            row(i, i);
-            row(i + kWaves, min(i + kWaves, nv - 1));
+            if (lane <= i) Mo[i * (i + 1) / 2 + lane] = (TI)((bj <= b_i && b_i <= lastj) ? val : 0.0);
         }
     }
     TSTAMP(8)
