@@ -59,8 +59,17 @@ namespace inria_wbc {
             }
         };
 
-        // "The step before the path": rigid-body terms and task rows for every instance at time t
-        // (pinocchio computeAllTerms + each task's compute() in the reference; out of scope here).
+        // TrajectorySample of tsid: value / first / second derivative
+        struct TrajectorySample {
+            std::vector<double> pos, vel, acc;
+            explicit TrajectorySample(int n = 0) : pos(n, 0.0), vel(n, 0.0), acc(n, 0.0) {}
+        };
+
+        // "The step before the path": rigid-body terms and task rows for every instance at time t (pinocchio computeAllTerms +
+        // each task's compute() in the reference, controller.cpp:244 upstream half).  Two kinds: FileSource replays rows
+        // computed elsewhere and leaves the reference-driven right-hand sides to the controller; ModelSource
+        // (model_source.hpp) computes everything on the device from the robot state (wbcqp_problem_data) and therefore
+        // owns the task references too.
         class ProblemSource {
         public:
             virtual ~ProblemSource() {}
@@ -69,12 +78,12 @@ namespace inria_wbc {
             virtual void compute(double t, const MatrixXd& q, const MatrixXd& v, const tasks::TaskStack& stack, const wbcqp_layout& L, TickInputs& in) = 0;
             // current CoM position / velocity per instance (3 columns) for the CoM task's PD law
             virtual void com(MatrixXd& pos, MatrixXd& vel) const = 0;
-        };
-
-        // TrajectorySample of tsid: value / first / second derivative
-        struct TrajectorySample {
-            std::vector<double> pos, vel, acc;
-            explicit TrajectorySample(int n = 0) : pos(n, 0.0), vel(n, 0.0), acc(n, 0.0) {}
+            // sources that evaluate the task laws themselves
+            virtual bool handles_references() const { return false; }
+            virtual void bind(wbcqp_handle*, int, const tasks::TaskStack&, double) {}
+            virtual void set_com_ref(const TrajectorySample&) {}
+            virtual void set_se3_ref(const std::string&, const TrajectorySample&) {}
+            virtual void set_posture_ref(const std::vector<double>&) {}
         };
 
         class Controller {

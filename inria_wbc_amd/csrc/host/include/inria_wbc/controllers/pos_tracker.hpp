@@ -9,6 +9,7 @@
 #include <map>
 
 #include <inria_wbc/controllers/controller.hpp>
+#include <inria_wbc/controllers/model_source.hpp>
 
 namespace inria_wbc {
     namespace controllers {
@@ -18,10 +19,25 @@ namespace inria_wbc {
             {
                 yaml::Node c = IWBC_CHECK(config["CONTROLLER"]);
                 solver_to_use_ = IWBC_CHECK(c["solver"].as<std::string>());
-                // robot dimensions come from the URDF in the reference (controller.cpp:104-118); here from the config
-                const int nv = IWBC_CHECK(c["nv"].as<int>());
-                const int na = IWBC_CHECK(c["na"].as<int>());
-                IWBC_ASSERT(floating_base_ ? (nv == na + 6) : (nv == na), "nv / na do not match floating_base");
+                // robot dimensions come from the URDF in the reference (controller.cpp:104-118).  Here: from `model:` (the parsed
+                // tree, robots/robot_wrapper.hpp) when the step before the path runs on the device too, else from nv / na
+                int nv, na;
+                if (c["model"]) {
+                    auto mf = c["model"].as<std::string>();
+                    robot_ = std::make_shared<robots::RobotWrapper>(mf.size() && mf[0] == '/' ? mf : base_path_ + "/" + mf, verbose_);
+                    nv = robot_->nv();
+                    na = robot_->na();
+                    IWBC_ASSERT(robot_->floating_base() == floating_base_, "floating_base and the model disagree");
+                    // create additional frames if needed (optional) (pos_tracker.cpp:51-55)
+                    if (c["frames"]) {
+                        auto ff = c["frames"].as<std::string>();
+                        parse_frames(ff.size() && ff[0] == '/' ? ff : base_path_ + "/" + ff);
+                    }
+                }
+                else {
+                    nv = IWBC_CHECK(c["nv"].as<int>());
+                    na = IWBC_CHECK(c["na"].as<int>());
+                }
                 closed_loop_ = c["closed_loop"] ? c["closed_loop"].as<bool>() : false;
 
                 // qp solver to be used: the reference accepts 'eiquadprog' or 'qpmad' (pos_tracker.cpp:88-100)
@@ -40,6 +56,15 @@ namespace inria_wbc {
                 auto task_file = IWBC_CHECK(c["tasks"].as<std::string>());
                 auto p = task_file.size() && task_file[0] == '/' ? task_file : base_path_ + "/" + task_file;
                 parse_tasks(p, nv, na);
+                if (robot_) {
+                    // q_tsid_ = the named reference configuration (pos_tracker.cpp:60-67); one controller instance per batch row
+                    auto ref_config = IWBC_CHECK(c["ref_config"].as<std::string>());
+                    const auto& ref_map = robot_->referenceConfigurations();
+                    IWBC_ASSERT(ref_map.find(ref_config) != ref_map.end(), "The following reference config is not in ref_map : ", ref_config);
+                    q0_ = ref_map.at(ref_config);
+                    const int batch = c["batch"] ? c["batch"].as<int>() : 1;
+                    set_problem_source(std::make_shared<ModelSource>(robot_, batch, q0_));
+                }
 
                 if (verbose_) {
                     std::cout << "--------- Solver size info ---------" << std::endl;
@@ -52,11 +77,22 @@ namespace inria_wbc {
             }
 
             // ---- reference setters / getters (pos_tracker.hpp:44-70); one sample drives every instance ----
-            void set_com_ref(const TrajectorySample& sample) { com_ref_ = sample; }
+            void set_com_ref(const TrajectorySample& sample)
+            {
+                com_ref_ = sample;
+                if (source_ && source_->handles_references()) source_->set_com_ref(sample);
+            }
+            void set_posture_ref(const std::vector<double>& ref)
+            {
+                IWBC_ASSERT(source_ && source_->handles_references(), "set_posture_ref needs a source that evaluates the task laws");
+                source_->set_posture_ref(ref);
+            }
+            const std::shared_ptr<robots::RobotWrapper>& robot() const { return robot_; }
             void set_se3_ref(const TrajectorySample& sample, const std::string& task_name)
             {
                 IWBC_ASSERT(stack_.has_task(task_name), "Task [", task_name, "] not found");
                 se3_refs_[task_name] = sample;
+                if (source_ && source_->handles_references()) source_->set_se3_ref(task_name, sample);
             }
             const std::vector<double>& get_com_ref() const { return com_init_; }
             double objective_value(int instance = 0) const { return objective_.at(instance); }
@@ -110,6 +146,19 @@ namespace inria_wbc {
                 if (verbose_) std::cout << "Number of parsed tasks " << task_list.size() << std::endl;
             }
 
+            // PosTracker::parse_frames (pos_tracker.cpp:191-209): virtual frames, `ref:` an existing frame, `pos:` the offset
+            void parse_frames(const std::string& path)
+            {
+                if (verbose_) std::cout << "Parsing virtual frame file:" << path << std::endl;
+                yaml::Node node = IWBC_CHECK(yaml::LoadFile(path));
+                for (const auto& kv : node) {
+                    auto ref = IWBC_CHECK(kv.second["ref"].as<std::string>());
+                    auto pos = IWBC_CHECK(kv.second["pos"].as<std::vector<double>>());
+                    IWBC_ASSERT(pos.size() == 3, "frame ", kv.first, ": pos needs 3 numbers");
+                    robot_->addFrame(kv.first, ref, {{pos[0], pos[1], pos[2]}});
+                }
+            }
+
             void _install_stack()
             {
                 wbcqp_structure s = stack_.c_struct();
@@ -128,14 +177,20 @@ namespace inria_wbc {
                 activated_contacts_.clear();
                 for (const auto& c : stack_.contacts()) activated_contacts_.push_back(c.name);
                 if (all_contacts_.empty()) all_contacts_ = activated_contacts_;
+                if (source_ && source_->handles_references()) source_->bind(handle_, 0, stack_, dt_); // set_structure dropped the model
             }
 
             void _reset() override
             {
                 const int nv = stack_.nv(), nq = floating_base_ ? nv + 1 : nv;
                 q_tsid_ = MatrixXd(batch_, nq);
-                if (floating_base_)
+                if (!q0_.empty()) {
+                    for (int i = 0; i < batch_; ++i)
+                        for (int j = 0; j < nq; ++j) q_tsid_(i, j) = q0_[j];
+                }
+                else if (floating_base_)
                     for (int i = 0; i < batch_; ++i) q_tsid_(i, 6) = 1.0; // unit quaternion
+                if (source_->handles_references()) source_->bind(handle_, 0, stack_, dt_);
                 v_tsid_ = MatrixXd(batch_, nv);
                 a_tsid_ = MatrixXd(batch_, nv);
                 MatrixXd cp, cv;
@@ -155,7 +210,8 @@ namespace inria_wbc {
                 for (int i = 0; i < batch_; ++i)
                     for (int k = 0; k < layout_.len_w; ++k) in_.w[(size_t)i * layout_.len_w + k] = weights_[k];
                 // CoM task PD law: b += Kp (x_ref - x) + Kd (v_ref - v) + a_ref on the masked axes (tsid TaskComEquality)
-                if (com_ref_set_ && stack_.has_task("com")) {
+                // -- unless the source evaluates the task laws itself (ModelSource: the reference went to it in set_com_ref)
+                if (com_ref_set_ && stack_.has_task("com") && !source_->handles_references()) {
                     const auto& t = stack_.task("com");
                     MatrixXd cp, cv;
                     source_->com(cp, cv);
@@ -180,6 +236,7 @@ namespace inria_wbc {
             {
                 com_ref_ = sample;
                 com_ref_set_ = true;
+                if (source_ && source_->handles_references()) source_->set_com_ref(sample);
             }
 
         protected:
@@ -189,7 +246,8 @@ namespace inria_wbc {
             std::vector<std::string> weight_names_;
             TrajectorySample com_ref_{3};
             bool com_ref_set_ = false;
-            std::vector<double> com_init_;
+            std::vector<double> com_init_, q0_;
+            std::shared_ptr<robots::RobotWrapper> robot_;
             std::map<std::string, TrajectorySample> se3_refs_;
         };
     } // namespace controllers

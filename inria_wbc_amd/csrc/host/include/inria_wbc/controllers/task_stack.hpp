@@ -78,6 +78,7 @@ namespace inria_wbc {
                 IWBC_ERROR("Task [", name, "] not found");
             }
             const std::vector<TaskSpec>& tasks() const { return tasks_; }
+            const yaml::Node& source() const { return source_; } // the tasks.yaml tree, in file order
             const std::vector<ContactSpec>& contacts() const { return contacts_; }
             const std::vector<double>& default_weights() const { return weights_; }
             const std::vector<std::string>& weight_names() const { return weight_names_; }

@@ -2,7 +2,9 @@
 // builds a PosTracker from argv[1] and a behavior from argv[2], then loops behavior->update() with empty sensor data
 // (open loop) under the "solver" timer.  Differences: B robot instances per tick (from the batch file argv[3]), and the
 // last tick's torques can be written to argv[5] so that a test can compare them with the CPU oracle.
-//   qp_timer_test <controller.yaml> <behavior.yaml> <batch.bin> [n_ticks=10] [tau_out.bin] [first_tick=0]
+//   qp_timer_test <controller.yaml> <behavior.yaml> <batch.bin | -> [n_ticks=10] [tau_out.bin] [first_tick=0] [q_out.bin]
+// With `-` for the batch file the controller must carry its own model (CONTROLLER.model): the rows come from the robot
+// state on the device (ModelSource), the loop is closed through the integrated state, and the final q can be written too.
 #include <csignal>
 #include <fstream>
 #include <iostream>
@@ -28,7 +30,7 @@ int main(int argc, char** argv)
         c_config["CONTROLLER"].set("base_path", ctrl_path.substr(0, ctrl_path.find_last_of('/')));
         auto controller_name = IWBC_CHECK(c_config["CONTROLLER"]["name"].as<std::string>());
         auto controller = controllers::Factory::instance().create(controller_name, c_config);
-        controller->set_problem_source(std::make_shared<controllers::FileSource>(argv[3]));
+        if (std::string(argv[3]) != "-") controller->set_problem_source(std::make_shared<controllers::FileSource>(argv[3]));
 
         yaml::Node b_config = IWBC_CHECK(yaml::LoadFile(argv[2]));
         auto behavior_name = IWBC_CHECK(b_config["BEHAVIOR"]["name"].as<std::string>());
@@ -50,6 +52,11 @@ int main(int argc, char** argv)
             std::ofstream f(argv[5], std::ios::binary);
             const auto& tau = controller->tau();
             f.write(reinterpret_cast<const char*>(tau.data.data()), (std::streamsize)(tau.data.size() * sizeof(double)));
+        }
+        if (argc > 7) {
+            std::ofstream f(argv[7], std::ios::binary);
+            const auto& q = controller->q();
+            f.write(reinterpret_cast<const char*>(q.data.data()), (std::streamsize)(q.data.size() * sizeof(double)));
         }
     }
     catch (std::exception& e) {

@@ -6,6 +6,7 @@
 
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
 #include <inria_wbc/controllers/pos_tracker.hpp>
+#include <inria_wbc/robots/robot_wrapper.hpp>
 #include <inria_wbc/trajs/loader.hpp>
 #include <inria_wbc/utils/timer.hpp>
 #include <cstdio>
@@ -116,6 +117,39 @@ int main(int argc, char** argv)
         timer.begin("solver");
         timer.end("solver");
         UTEST_CHECK(timer["solver"].iterations == 1 && timer["solver"].min_time <= timer["solver"].max_time);
+    }
+    // ---- the robot as data: tree (stand-in for the URDF), virtual frames in the reference's frames.yaml schema, host FK ----
+    {
+        robots::RobotWrapper robot(cfg + "/talos/talos_like.model.yaml");
+        UTEST_CHECK(robot.nq() == 51 && robot.nv() == 50 && robot.na() == 44 && robot.floating_base());
+        UTEST_CHECK(robot.existJointName("leg_left_6_joint") && robot.existFrame("torso_2_link") && !robot.existFrame("v_leg_left_3"));
+        const int before = robot.nframes();
+        yaml::Node fr = yaml::LoadFile(cfg + "/talos/frames.yaml");
+        for (const auto& kv : fr) {
+            auto pos = kv.second["pos"].as<std::vector<double>>();
+            robot.addFrame(kv.first, kv.second["ref"].as<std::string>(), {{pos[0], pos[1], pos[2]}});
+        }
+        UTEST_CHECK(robot.nframes() == before + 4 && robot.existFrame("v_base_link_right"));
+        UTEST_CHECK_EXCEPTION(robot.getFrameId("nope"), "Unknown frame or joint");
+        const auto& q0 = robot.referenceConfigurations().at("inria_start");
+        auto base = robot.framePosition(q0.data(), robot.getFrameId("root_joint"));
+        UTEST_CHECK(base.p[0] == q0[0] && base.p[1] == q0[1] && base.p[2] == q0[2]);
+        // a virtual frame sits `pos` away from its reference frame, in that frame's axes
+        auto a = robot.framePosition(q0.data(), robot.getFrameId("base_link"));
+        auto b = robot.framePosition(q0.data(), robot.getFrameId("v_base_link_left"));
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) d2 += (a.p[k] - b.p[k]) * (a.p[k] - b.p[k]);
+        UTEST_CHECK(std::fabs(std::sqrt(d2) - 0.1) < 1e-12);
+        auto c = robot.com(q0.data());
+        UTEST_CHECK(c[2] > 0.8 && c[2] < 1.0 && std::fabs(c[1]) < 0.01);
+        // feet flat and level at the reference posture
+        auto lf = robot.framePosition(q0.data(), robot.getFrameId("leg_left_6_joint"));
+        auto rf = robot.framePosition(q0.data(), robot.getFrameId("leg_right_6_joint"));
+        UTEST_CHECK(std::fabs(lf.p[2] - rf.p[2]) < 1e-6 && lf.R[8] > 0.999999);
+        wbcqp_model m = robot.c_model();
+        UTEST_CHECK(m.nbody == 45 && m.nframe == robot.nframes() && m.parent[0] == -1 && m.jtype[0] == WBCQP_J_FREEFLYER);
+        auto v = base.to_vector();
+        UTEST_CHECK(v[0] == q0[0] && v[3] == base.R[0] && v[4] == base.R[3] && v[6] == base.R[1]); // rotation column-major
     }
     std::cout << (failures ? "FAILED" : "OK") << " (" << failures << " failures)" << std::endl;
     return failures ? 1 : 0;

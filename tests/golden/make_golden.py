@@ -68,6 +68,27 @@ def main_after_path():
         print("wrote", path)
 
 
+def main_before_path():
+    """The step before the path: q, v, references -> QP record by oracle/rbd_oracle.c for the
+    Talos-like and Franka-like models (inria_wbc_amd/model.py; seeded, so the fixture also pins the model builders),
+    accepted after the identities of tests/test_oracle_rbd.py hold for the same models."""
+    from inria_wbc_amd import model as mdl, structure
+    from oracle import rbd
+    os.makedirs(os.path.join(HERE, "before_path"), exist_ok=True)
+    for tag, m, st, stack in (("talos", mdl.talos_like(), structure.talos_structure(), mdl.talos_stack()),
+                              ("franka", mdl.franka_like(), structure.franka_structure(), mdl.franka_stack())):
+        tm = mdl.build_taskmap(m, st, stack)
+        s = mdl.sample_states(m, tm, 3, 555_000, q_noise=0.05, v_noise=0.2, ref_noise=0.02)
+        rows = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"])
+        t = rbd.rbd_terms(m, s["q"][0], s["v"][0])
+        a = np.random.default_rng(5).standard_normal(m.nv)
+        assert np.abs(t["M"] @ a + t["nle"] - rbd.rnea(m, s["q"][0], s["v"][0], a)).max() < 1e-9
+        path = os.path.join(HERE, "before_path", "rows_%s.npz" % tag)
+        np.savez_compressed(path, q=s["q"], v=s["v"], ref=s["ref"], **rows)
+        print("wrote", path, os.path.getsize(path))
+
+
 if __name__ == "__main__":
     main()
     main_after_path()
+    main_before_path()

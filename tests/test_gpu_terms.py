@@ -159,3 +159,15 @@ def test_problem_data_f32_boundary(rbd):
         scale = max(1.0, np.abs(ora[k]).max())
         assert np.abs(dev[k].astype(np.float64) - ora[k]).max() / scale < 1e-6, k
     h.close()
+
+
+@pytest.mark.parametrize("tag", ["talos", "franka"])
+def test_problem_data_golden_gpu(handle, tag):
+    """The committed fixtures (tests/golden/before_path) through the C ABI: the oracle does not run here."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "before_path", "rows_%s.npz" % tag))
+    m, st, tm = CASES[tag]()
+    handle.set_structure(5, st)
+    handle.set_model(5, m, tm)
+    dev = handle.problem_data_host(5, z["q"], z["v"], z["ref"])
+    _compare(dev, {k: z[k] for k in capi.ROW_FIELDS})

@@ -62,3 +62,41 @@ def test_qp_timer_test_squat_matches_oracle(host_build, oracle_mod, tmp_path):
     ref = oracle_mod.tick_batch(st, ref_in, nthreads=4)
     assert (ref["status"] == 0).all()
     assert np.abs(tau - ref["tau"]).max() <= 1e-8 * max(1.0, np.abs(ref["tau"]).max())
+
+
+@pytest.mark.gpu
+def test_qp_timer_test_closed_loop_on_the_model(host_build, oracle_mod, tmp_path):
+    """The same harness with the step before the path on the device too (CONTROLLER.model / frames / ref_config as the
+    reference's urdf / frames / ref_config keys): PosTracker + humanoid::move_com close the loop through the integrated
+    state for 40 ticks of the squat.  Every instance starts at the reference configuration, so all rows must stay
+    bitwise equal (the reference's test_determinism.cpp:44-57 bar), and they must match the loop built from the oracles."""
+    from inria_wbc_amd import model as mdl, structure, trajs
+    from oracle import rbd
+    n_ticks = 40
+    tau_path, q_path = str(tmp_path / "tau.bin"), str(tmp_path / "q.bin")
+    r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/talos/pos_tracker_model.yaml"),
+                        os.path.join(ROOT, "configs/talos/squat.yaml"), "-", str(n_ticks), tau_path, "0", q_path],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "instances per tick: 8" in r.stdout
+    m = mdl.talos_like()
+    st = structure.talos_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    tau = np.fromfile(tau_path, dtype=np.float64).reshape(8, st.na)
+    q = np.fromfile(q_path, dtype=np.float64).reshape(8, m.nq)
+    assert all(np.array_equal(tau[0], tau[i]) and np.array_equal(q[0], q[i]) for i in range(1, 8))
+    # the oracle loop: references of a fresh controller (placements at q0), CoM reference from the squat stream
+    s = mdl.sample_states(m, tm, 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+    oq, ov, oref = s["q"], s["v"], s["ref"]
+    com_blk = next(b for b in tm.blocks if b.kind == mdl.T_COM)
+    pos, vel, acc = trajs.move_com_stream(m.com(m.q0), [[0.0, 0.0, -0.2]], "001", tm.dt, 2.0, loop=True, absolute=False)
+    tl, tu, w = -m.tau_max[None], m.tau_max[None], st.default_weights[None]
+    for k in range(n_ticks):
+        oref[:, com_blk.ref:com_blk.ref + 9] = np.concatenate([pos[k], vel[k], acc[k]])
+        rows = rbd.task_rows(m, tm, st, oq, ov, oref)
+        oo = oracle_mod.tick_batch(st, dict(rows, tlb=tl, tub=tu, w=w))
+        assert oo["status"][0] == 0
+        nxt = oracle_mod.integrate(True, tm.dt, oq, ov, oo["x"][:, :st.nv])
+        oq, ov = nxt["q_next"], nxt["v_next"]
+    assert np.abs(q[0] - oq[0]).max() < 1e-8, np.abs(q[0] - oq[0]).max()
+    assert np.abs(tau[0] - oo["tau"][0]).max() < 1e-6 * max(1.0, np.abs(oo["tau"]).max())

@@ -243,3 +243,32 @@ def test_bounds_keep_a_joint_inside_its_limits(rbd):
             assert abs(v[6 + j]) <= m.dq_max[j] * (1 + 1e-9)
         hit = hit or (m.q_ub[j] - q[7 + j]) < 1e-3
     assert worst < 1e-6, worst
+
+
+def _golden_case(tag):
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "before_path", "rows_%s.npz" % tag))
+    if tag == "talos":
+        m, st, stack = mdl.talos_like(), structure.talos_structure(), mdl.talos_stack()
+    else:
+        m, st, stack = mdl.franka_like(), structure.franka_structure(), mdl.franka_stack()
+    return z, m, st, mdl.build_taskmap(m, st, stack)
+
+
+@pytest.mark.parametrize("tag", ["talos", "franka"])
+def test_rows_golden(rbd, tag):
+    """The committed fixtures pin the oracle AND the seeded model builders (tests/golden/make_golden.py::main_before_path)."""
+    z, m, st, tm = _golden_case(tag)
+    rows = rbd.task_rows(m, tm, st, z["q"], z["v"], z["ref"])
+    for k, a in rows.items():
+        if a.size:
+            assert np.abs(a - z[k]).max() <= 1e-12 * max(1.0, np.abs(z[k]).max()), k
+
+
+def test_sample_states_do_not_depend_on_the_sharding():
+    """Instance i of a stream depends on seed + i only: a rank that owns [lo, hi) draws exactly its slice."""
+    m, st, tm = _talos_setup()
+    full = mdl.sample_states(m, tm, 12, 42_000)
+    part = mdl.sample_states(m, tm, 5, 42_000 + 4)
+    for k in ("q", "v", "ref"):
+        assert np.array_equal(full[k][4:9], part[k])

@@ -67,11 +67,54 @@ def emit_tasks(tasks):
         out.append("%s:" % name)
         out.append("  type: %s" % typ)
         for k, v in fields.items():
-            out.append("  %s: %s" % (k, v))
+            if isinstance(v, dict):  # nested map (self-collision `avoided:` frame -> radius)
+                out.append("  %s:" % k)
+                for kk, vv in v.items():
+                    out.append("    %s: %s" % (kk, vv))
+            else:
+                out.append("  %s: %s" % (k, v))
     return "\n".join(out) + "\n"
 
 
+def talos_with_avoided():
+    from inria_wbc_amd import model as mdl
+    av = {n["name"]: n["avoided"] for n in mdl.talos_stack() if n["type"] == "self-collision"}
+    out = []
+    for name, typ, fields in TALOS:
+        if typ == "self-collision":
+            f = dict(fields)
+            kp, kd, margin, m = f.pop("kp"), f.pop("kd"), f.pop("margin"), f.pop("m")
+            w = f.pop("weight")
+            f["avoided"] = av[name]
+            f.update(weight=w, kp=kp, kd=kd, margin=margin, m=m)
+            fields = f
+        out.append((name, typ, fields))
+    return out
+
+
+def emit_model_files():
+    """The URDF's stand-in for the facade (robots/robot_wrapper.hpp), the virtual frames in the reference's own frames.yaml
+    schema (etc/talos/frames.yaml) and a CONTROLLER tree that uses them."""
+    from inria_wbc_amd import model as mdl
+    d = os.path.join(ROOT, "configs", "talos")
+    m = mdl.talos_like()
+    virtual = ["v_leg_right_3", "v_leg_left_3", "v_base_link_left", "v_base_link_right"]
+    mdl.to_yaml(m, os.path.join(d, "talos_like.model.yaml"), skip_frames=virtual, ref_name="inria_start")
+    with open(os.path.join(d, "frames.yaml"), "w") as f:
+        f.write("# virtual frames (schema and values of inria_wbc's etc/talos/frames.yaml)\n")
+        for name, ref, pos in (("v_leg_right_3", "leg_right_3_joint", [0.0, -0.1, -0.2]), ("v_leg_left_3", "leg_left_3_joint", [0, 0.1, -0.2]),
+                               ("v_base_link_left", "base_link", [0.0, -0.1, 0]), ("v_base_link_right", "base_link", [0, 0.1, 0])):
+            f.write("%s:\n  ref: \"%s\"\n  pos: %s\n" % (name, ref, pos))
+    with open(os.path.join(d, "pos_tracker_model.yaml"), "w") as f:
+        f.write("# CONTROLLER tree with the step before the path on the device: `model` stands where inria_wbc has `urdf`\n")
+        f.write("# (a parsed tree, see robots/robot_wrapper.hpp), `frames` / `ref_config` / `tasks` as in talos_pos_tracker.yaml\n")
+        f.write("CONTROLLER:\n  name: pos-tracker\n  solver: hip-batched\n  base_path: .\n  model: talos_like.model.yaml\n  frames: frames.yaml\n")
+        f.write("  ref_config: inria_start\n  tasks: tasks.yaml\n  dt: 0.001\n  floating_base: true\n  closed_loop: false\n  verbose: false\n  batch: 8\n")
+
+
 def main():
+    ROBOTS["talos"] = (talos_with_avoided(), 50, 44, True)
+    emit_model_files()
     for robot, (tasks, nv, na, fb) in ROBOTS.items():
         d = os.path.join(ROOT, "configs", robot)
         os.makedirs(d, exist_ok=True)
