@@ -287,6 +287,32 @@ int wbcqp_problem_data(wbcqp_handle* handle, int slot, int batch, const wbcqp_st
 /* Same with HOST pointers; blocks until done. */
 int wbcqp_problem_data_host(wbcqp_handle* handle, int slot, int batch, const wbcqp_state* state, const wbcqp_inputs* rows);
 
+/* ---- One whole control tick on the device: all of Controller::_solve (controller.cpp:231-313) for `batch` instances ----
+ * rows (wbcqp_problem_data) -> QP (wbcqp_solve_batch) -> state integration (wbcqp_integrate), ordered on one stream.
+ * All pointers are DEVICE pointers. `rows` is the QP record: M, h, A, b1, Ac, bc, blb, bub are scratch the rows kernel
+ * writes and the solve reads; tlb, tub, w are supplied by the caller (constant limits, task weights). */
+typedef struct {
+    wbcqp_state state;
+    wbcqp_inputs rows;
+    wbcqp_outputs out;
+    void* q_next;    /* [batch][nq] */
+    void* v_next;    /* [batch][nv] */
+    void* q_solver;  /* [batch][nv] or NULL */
+    double dt;
+} wbcqp_tick_io;
+
+int wbcqp_tick(wbcqp_handle* handle, int slot, int batch, const wbcqp_tick_io* io, void* stream);
+
+/* The same sequence captured once into a HIP graph and replayed: one graph launch per tick instead of four kernel
+ * launches (what matters when the batch is small -- one robot at 1 kHz is the reference's own use case).  The graph is
+ * bound to the pointers of `io`; the caller changes the CONTENT of those buffers between ticks (new references, or
+ * q_next / v_next copied back into state.q / state.v), not the pointers.  wbcqp_tick_graph_create runs one ordinary tick
+ * first (so nothing is allocated inside the capture) and blocks until it is done. */
+typedef struct wbcqp_graph wbcqp_graph;
+int wbcqp_tick_graph_create(wbcqp_handle* handle, int slot, int batch, const wbcqp_tick_io* io, wbcqp_graph** out);
+int wbcqp_tick_graph_launch(wbcqp_handle* handle, wbcqp_graph* graph, void* stream);
+int wbcqp_tick_graph_destroy(wbcqp_handle* handle, wbcqp_graph* graph);
+
 int wbcqp_sync(wbcqp_handle* handle, void* stream);
 
 #ifdef __cplusplus

@@ -25,7 +25,8 @@ FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
 EXPORTS = ("wbcqp_version", "wbcqp_last_error", "wbcqp_create", "wbcqp_destroy", "wbcqp_set_structure",
            "wbcqp_layout_of", "wbcqp_solve_batch", "wbcqp_solve_batch_host", "wbcqp_solve_ragged",
            "wbcqp_allgather_tau", "wbcqp_integrate", "wbcqp_integrate_host", "wbcqp_set_model", "wbcqp_problem_data",
-           "wbcqp_problem_data_host", "wbcqp_sync")
+           "wbcqp_problem_data_host", "wbcqp_tick", "wbcqp_tick_graph_create", "wbcqp_tick_graph_launch", "wbcqp_tick_graph_destroy",
+           "wbcqp_sync")
 ROW_FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub")  # what wbcqp_problem_data writes
 
 c_i32_p = C.POINTER(C.c_int32)
@@ -96,6 +97,13 @@ class CState(C.Structure):
     _fields_ = [("q", C.c_void_p), ("v", C.c_void_p), ("ref", C.c_void_p)]
 
 
+class CTickIO(C.Structure):
+    pass  # fields set below (needs CInputs / COutputs)
+
+
+CTickIO._fields_ = [("state", CState), ("rows", CInputs), ("out", COutputs), ("q_next", C.c_void_p), ("v_next", C.c_void_p),
+                    ("q_solver", C.c_void_p), ("dt", C.c_double)]
+
 _lib = None
 
 
@@ -128,6 +136,10 @@ def load_library(path: Optional[str] = None):
     lib.wbcqp_set_model.argtypes = [C.c_void_p, C.c_int, C.POINTER(CModel), C.POINTER(CTaskMap)]
     lib.wbcqp_problem_data.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CState), C.POINTER(CInputs), C.c_void_p]
     lib.wbcqp_problem_data_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CState), C.POINTER(CInputs)]
+    lib.wbcqp_tick.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CTickIO), C.c_void_p]
+    lib.wbcqp_tick_graph_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CTickIO), C.POINTER(C.c_void_p)]
+    lib.wbcqp_tick_graph_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.wbcqp_tick_graph_destroy.argtypes = [C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -336,6 +348,34 @@ class Handle:
             setattr(cin, k, out[k].ctypes.data if k in ROW_FIELDS and L[k] else None)
         self._check(self.lib.wbcqp_problem_data_host(self._h, slot, batch, C.byref(cs), C.byref(cin)))
         return {k: a[:, :L[k]] for k, a in out.items()}
+
+    def _tick_io(self, slot: int, batch: int, state, rows, out, q_next, v_next, dt: float, q_solver=None) -> CTickIO:
+        cin, cout = self._pack(slot, batch, rows, out)
+        io = CTickIO()
+        io.state = CState(state["q"].data_ptr(), state["v"].data_ptr(), state["ref"].data_ptr())
+        io.rows, io.out = cin, cout
+        io.q_next, io.v_next = q_next.data_ptr(), v_next.data_ptr()
+        io.q_solver = q_solver.data_ptr() if q_solver is not None else None
+        io.dt = float(dt)
+        return io
+
+    def tick(self, slot: int, batch: int, state, rows, out, q_next, v_next, dt: float, q_solver=None, stream: int = 0):
+        """rows -> QP -> integration for one control tick (wbcqp_tick), device tensors."""
+        io = self._tick_io(slot, batch, state, rows, out, q_next, v_next, dt, q_solver)
+        self._check(self.lib.wbcqp_tick(self._h, slot, batch, C.byref(io), C.c_void_p(stream)))
+
+    def tick_graph(self, slot: int, batch: int, state, rows, out, q_next, v_next, dt: float, q_solver=None) -> int:
+        """Captures the tick into a HIP graph bound to these buffers; returns the graph handle for tick_graph_launch."""
+        io = self._tick_io(slot, batch, state, rows, out, q_next, v_next, dt, q_solver)
+        g = C.c_void_p()
+        self._check(self.lib.wbcqp_tick_graph_create(self._h, slot, batch, C.byref(io), C.byref(g)))
+        return g.value
+
+    def tick_graph_launch(self, graph: int, stream: int = 0):
+        self._check(self.lib.wbcqp_tick_graph_launch(self._h, C.c_void_p(graph), C.c_void_p(stream)))
+
+    def tick_graph_destroy(self, graph: int):
+        self.lib.wbcqp_tick_graph_destroy(self._h, C.c_void_p(graph))
 
     def sync(self, stream: int = 0):
         self._check(self.lib.wbcqp_sync(self._h, C.c_void_p(stream)))

@@ -866,6 +866,78 @@ int wbcqp_problem_data_host(wbcqp_handle* h, int slot, int batch, const wbcqp_st
     return WBCQP_OK;
 }
 
+int wbcqp_tick(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (!io) return fail(h, WBCQP_ERR_INVALID, "io is NULL");
+    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES || !h->slots[slot].set || !h->slots[slot].has_model)
+        return fail(h, WBCQP_ERR_INVALID, "slot has no model (wbcqp_set_model)");
+    if (batch < 0) return fail(h, WBCQP_ERR_INVALID, "negative batch");
+    if (batch == 0) return WBCQP_OK;
+    if (!io->q_next || !io->v_next) return fail(h, WBCQP_ERR_INVALID, "q_next / v_next is NULL");
+    const Slot& s = h->slots[slot];
+    int rc = wbcqp_problem_data(h, slot, batch, &io->state, &io->rows, stream);
+    if (rc != WBCQP_OK) return rc;
+    rc = wbcqp_solve_batch(h, slot, batch, &io->rows, &io->out, stream);
+    if (rc != WBCQP_OK) return rc;
+    return wbcqp_integrate(h, batch, s.terms.nv, s.terms.floating_base, io->dt, io->state.q, io->state.v, io->out.x, s.host.n,
+                           io->out.status, io->q_next, io->v_next, io->q_solver, stream);
+}
+
+struct wbcqp_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t capture = nullptr;
+};
+
+int wbcqp_tick_graph_destroy(wbcqp_handle* h, wbcqp_graph* g)
+{
+    if (!g) return WBCQP_OK;
+    if (h) (void)hipSetDevice(h->device);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->capture) (void)hipStreamDestroy(g->capture);
+    delete g;
+    return WBCQP_OK;
+}
+
+int wbcqp_tick_graph_create(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io, wbcqp_graph** out)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (!out || !io) return fail(h, WBCQP_ERR_INVALID, "io / out is NULL");
+    if (batch <= 0) return fail(h, WBCQP_ERR_INVALID, "a graph needs a positive batch");
+    *out = nullptr;
+    HIP_TRY(h, hipSetDevice(h->device));
+    wbcqp_graph* g = new wbcqp_graph();
+    hipError_t e = hipStreamCreateWithFlags(&g->capture, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete g; return fail(h, WBCQP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    // an ordinary tick on the capture stream first: function attributes, the schedule buffer and its validity for this
+    // stream and shape are then settled, and the capture below contains kernel launches only
+    int rc = wbcqp_tick(h, slot, batch, io, g->capture);
+    if (rc == WBCQP_OK && hipStreamSynchronize(g->capture) != hipSuccess) rc = fail(h, WBCQP_ERR_HIP, "warm-up tick failed");
+    if (rc != WBCQP_OK) { wbcqp_tick_graph_destroy(h, g); return rc; }
+    e = hipStreamBeginCapture(g->capture, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { wbcqp_tick_graph_destroy(h, g); return fail(h, WBCQP_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
+    rc = wbcqp_tick(h, slot, batch, io, g->capture);
+    e = hipStreamEndCapture(g->capture, &g->graph);
+    if (rc != WBCQP_OK || e != hipSuccess || !g->graph) {
+        wbcqp_tick_graph_destroy(h, g);
+        return rc != WBCQP_OK ? rc : fail(h, WBCQP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { wbcqp_tick_graph_destroy(h, g); return fail(h, WBCQP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    *out = g;
+    return WBCQP_OK;
+}
+
+int wbcqp_tick_graph_launch(wbcqp_handle* h, wbcqp_graph* g, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (!g || !g->exec) return fail(h, WBCQP_ERR_INVALID, "graph is NULL");
+    HIP_TRY(h, hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+    return WBCQP_OK;
+}
+
 int wbcqp_sync(wbcqp_handle* h, void* stream)
 {
     if (!h) return WBCQP_ERR_INVALID;

@@ -72,3 +72,57 @@ def test_squat_rollout_matches_oracle_loop_and_tracks_the_com():
         assert np.abs(m.frame_placements(gq[i])[1][lf] - m.frame_placements(s["q"][i])[1][lf]).max() < 2e-3
     assert np.isfinite(foot0).all()
     h.close()
+
+
+def _tick_buffers(m, st, tm, B, seed, dev, torch):
+    s = mdl.sample_states(m, tm, B, seed, q_noise=0.005, v_noise=0.02, ref_noise=0.005)
+    L = st.field_lengths()
+    state = {k: torch.from_numpy(s[k]).to(dev) for k in ("q", "v", "ref")}
+    rows = {k: torch.zeros(B, L[k], dtype=torch.float64, device=dev) for k in capi.ROW_FIELDS}
+    rows["tlb"] = torch.from_numpy(np.tile(-m.tau_max, (B, 1))).to(dev)
+    rows["tub"] = torch.from_numpy(np.tile(m.tau_max, (B, 1))).to(dev)
+    rows["w"] = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev)
+    out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, st.na, dtype=torch.float64, device=dev),
+               status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+    return state, rows, out, torch.zeros_like(state["q"]), torch.zeros_like(state["v"])
+
+
+@pytest.mark.parametrize("B", [1, 37])
+def test_tick_and_graph_replay_are_the_three_calls(B):
+    """wbcqp_tick = problem_data + solve_batch + integrate; the captured graph replays it bit for bit, tick after tick, with
+    the state fed back between launches."""
+    import torch
+    m = mdl.talos_like()
+    st = structure.talos_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    results = []
+    for mode in ("calls", "tick", "graph"):
+        h = capi.Handle(0, capi.F64)
+        h.set_structure(0, st)
+        h.set_model(0, m, tm)
+        state, rows, out, qn, vn = _tick_buffers(m, st, tm, B, 88_000, dev, torch)
+        q_init, v_init = state["q"].clone(), state["v"].clone()
+        g = h.tick_graph(0, B, state, rows, out, qn, vn, tm.dt) if mode == "graph" else None
+        if g is not None:  # creation ran warm-up ticks on these buffers: start every mode from the same state
+            state["q"].copy_(q_init); state["v"].copy_(v_init)
+        for k in range(12):
+            if mode == "calls":
+                h.problem_data(0, B, state, rows, stream=stream)
+                h.solve_batch(0, B, rows, out, stream=stream)
+                h.integrate(B, st.nv, True, tm.dt, state["q"], state["v"], out["x"], st.n, out["status"], qn, vn, None, stream=stream)
+            elif mode == "tick":
+                h.tick(0, B, state, rows, out, qn, vn, tm.dt, stream=stream)
+            else:
+                h.tick_graph_launch(g, stream=stream)
+            state["q"].copy_(qn)
+            state["v"].copy_(vn)
+        torch.cuda.synchronize()
+        results.append((state["q"].cpu().numpy().copy(), out["tau"].cpu().numpy().copy(), out["status"].cpu().numpy().copy()))
+        if g is not None:
+            h.tick_graph_destroy(g)
+        h.close()
+    for r in results[1:]:
+        assert np.array_equal(r[0], results[0][0]) and np.array_equal(r[1], results[0][1]) and np.array_equal(r[2], results[0][2])
+    assert (results[0][2] == 0).all()
