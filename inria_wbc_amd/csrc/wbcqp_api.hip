@@ -707,7 +707,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     if (D.n_bound > 0 && (!md->q_lb || !md->q_ub || !md->dq_max)) return fail(h, WBCQP_ERR_INVALID, "bounds need q_lb / q_ub / dq_max");
 
     TermsDev T{};
-    T.nb = nb; T.nq = nq; T.nv = nv; T.na = na; T.floating_base = fb; T.maxdepth = maxdepth;
+    T.nb = nb; T.nq = nq; T.nv = nv; T.na = na; T.floating_base = fb;
     int nrounds = 0;
     while ((1 << nrounds) < maxdepth + 1) ++nrounds;
     T.nrounds = nrounds; // <= 6 for 64 bodies
@@ -731,19 +731,19 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     // (tasks.cpp:197-217: the actuated joints, in order) -- checked against n_sel
     if (D.n_sel != 0 && D.n_sel != na) return fail(h, WBCQP_ERR_UNSUPPORTED, "a posture task over a subset of the actuated joints");
     for (int r = 0; r < D.n_sel; ++r) sel[r] = nv - na + r;
-    T.i_parent = puti(md->parent, nb); T.i_jtype = puti(md->jtype, nb); T.i_depth = puti(depth.data(), nb); T.i_last = puti(last.data(), nb);
+    T.i_jtype = puti(md->jtype, nb); T.i_last = puti(last.data(), nb);
     T.i_anc = puti(anc.data(), (size_t)nrounds * nb);
     T.i_idxq = puti(idxq.data(), nb); T.i_idxv = puti(idxv.data(), nb); T.i_bodyof = puti(bodyof.data(), nv); T.i_kof = puti(kof.data(), nv);
     T.i_law_body = puti(law_body.data(), law_body.size()); T.i_law_mask = puti(law_mask.data(), law_mask.size());
     T.i_law_row = puti(law_row.data(), law_row.size()); T.i_law_ref = puti(law_ref.data(), law_ref.size());
     T.i_law_va = puti(law_va.data(), law_va.size()); T.i_law_contact = puti(law_contact.data(), law_contact.size());
-    T.i_pair_block = puti(pair_block.data(), pair_block.size()); T.i_pair_bt = puti(pair_bt.data(), pair_bt.size());
+    T.i_pair_bt = puti(pair_bt.data(), pair_bt.size());
     T.i_pair_ba = puti(pair_ba.data(), pair_ba.size());
     T.i_pair_ft = puti(pair_ft.data(), pair_ft.size()); T.i_pair_fa = puti(pair_fa.data(), pair_fa.size());
     T.i_scf_body = puti(scf_body.data(), scf_body.size());
     T.i_blk_kind = puti(blk_kind.data(), blk_kind.size()); T.i_blk_mask = puti(blk_mask.data(), blk_mask.size());
     T.i_blk_row = puti(blk_row.data(), blk_row.size()); T.i_blk_ref = puti(blk_ref.data(), blk_ref.size());
-    T.i_blk_law = puti(blk_law.data(), blk_law.size()); T.i_blk_pair0 = puti(blk_pair0.data(), blk_pair0.size());
+    T.i_blk_pair0 = puti(blk_pair0.data(), blk_pair0.size());
     T.i_blk_npair = puti(blk_npair.data(), blk_npair.size()); T.i_sel_col = puti(sel.data(), sel.size());
     T.d_place = putd(md->placement, (size_t)nb * 12); T.d_inertia = putd(md->inertia, (size_t)nb * 10);
     T.d_law_place = putd(law_place.data(), law_place.size()); T.d_law_kp = putd(law_kp.data(), law_kp.size());
@@ -757,7 +757,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     T.o_state = take(nq + nv + tm->nref);
     T.o_kin = take(nb * kKinStride);
     T.o_scan = take((nb + 1) * kScanStride);
-    T.o_F = take(8); // momentum totals
+    T.o_tot = take(8); // momentum totals
     T.o_law = take(T.nlaw * kLawStride);
     T.o_pair = take(T.npair * kPairStride);
     T.o_scf = take(T.nscf * kScfStride);

@@ -31,14 +31,13 @@ enum { T_SE3 = 0, T_COM = 1, T_MOMENTUM = 2, T_SELFCOLLISION = 3 };
 
 constexpr int kKinStride = 25; // per body: R (9) p (3) v (6) a (6), odd stride
 constexpr int kScanStride = 17; // per body: m, m c (3), inertia about the origin (6), bias force (6)
-constexpr int kFStride = 7;
 constexpr int kLawStride = 13;  // per task frame: R (9) p (3)
 constexpr int kPairStride = 7;  // per self-collision pair: grad (3), rhs share, tracked body, avoided body
 constexpr int kScfStride = 7;   // per self-collision frame: position (3), classical linear acceleration in its own axes (3)
 
 // Constant tables of one (model, task map), resident in device memory; offsets index the two pools.
 struct TermsDev {
-    int nb, nq, nv, na, floating_base, maxdepth, nrounds;
+    int nb, nq, nv, na, floating_base, nrounds;
     int nlaw, npair, nscf, nblock, nc, n_dense, n_sel, n_bound, r1, nref;
     int posture_ref;
     double posture_kp, posture_kd, dt;
@@ -46,13 +45,13 @@ struct TermsDev {
     const int* ipool;
     const double* dpool;
     // int pool offsets
-    int i_parent, i_jtype, i_depth, i_last, i_idxq, i_idxv; // [nb]
+    int i_jtype, i_last, i_idxq, i_idxv;                    // [nb]
     int i_anc;                                              // [nrounds][nb] 2^r-th ancestor, -1 beyond the root
     int i_bodyof, i_kof;                                    // [nv]
     int i_law_body, i_law_mask, i_law_row, i_law_ref, i_law_va, i_law_contact; // [nlaw]
-    int i_pair_block, i_pair_bt, i_pair_ba, i_pair_ft, i_pair_fa; // [npair] bodies and self-collision-frame indices
+    int i_pair_bt, i_pair_ba, i_pair_ft, i_pair_fa;         // [npair] bodies and self-collision-frame indices
     int i_scf_body;                                         // [nscf] distinct frames the self-collision tasks touch
-    int i_blk_kind, i_blk_mask, i_blk_row, i_blk_ref, i_blk_law, i_blk_pair0, i_blk_npair; // [nblock]
+    int i_blk_kind, i_blk_mask, i_blk_row, i_blk_ref, i_blk_pair0, i_blk_npair; // [nblock]
     int i_sel_col;                                          // [n_sel]
     // double pool offsets
     int d_place, d_inertia;                                  // [nb][12], [nb][10]
@@ -61,7 +60,7 @@ struct TermsDev {
     int d_blk_kp, d_blk_kd;                                  // [nblock]
     int d_qlb, d_qub, d_dqmax;                               // [na]
     // LDS layout (doubles)
-    int o_state, o_kin, o_scan, o_F, o_law, o_pair, o_scf, o_b1, o_bc;
+    int o_state, o_kin, o_scan, o_tot, o_law, o_pair, o_scf, o_b1, o_bc;
     int lds_doubles;
 };
 
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     double* pair = lds + T.o_pair;
     double* b1s = lds + T.o_b1;
     double* bcs = lds + T.o_bc;
-    double* tots = lds + T.o_F; // totals of the momentum (6 doubles)
+    double* tots = lds + T.o_tot; // total momentum of the robot (6 doubles)
 
     // ---- state and references into LDS ----------------------------------------------------------------------------
     {

@@ -361,6 +361,100 @@ def talos_stack() -> List[dict]:
     ]
 
 
+def icub_stack() -> List[dict]:
+    """/root/reference/etc/icub/tasks.yaml in file order (virtual frames of etc/icub/frames.yaml)."""
+    foot = dict(type="contact", kp=30.0, lxp=0.14, lxn=0.06, lyp=0.045, lyn=0.045, lz=0.065, fmin=5.0, fmax=1500.0, mu=0.3)
+    av = lambda other: {other: 0.05, "v_leg_right": 0.08, "v_leg_left": 0.08, "torso_pitch": 0.11, "l_hip_pitch": 0.08,
+                        "r_hip_pitch": 0.08, "l_knee": 0.08, "r_knee": 0.08}
+    return [
+        dict(name="lh", type="se3", tracked="l_hand", kp=30.0, mask="111111"),
+        dict(name="rh", type="se3", tracked="r_hand", kp=30.0, mask="111111"),
+        dict(name="lf", type="se3", tracked="left_foot", kp=30.0, mask="111111"),
+        dict(name="rf", type="se3", tracked="right_foot", kp=30.0, mask="111111"),
+        dict(name="com", type="com", kp=50.0, mask="111"),
+        dict(name="momentum", type="momentum", kp=30.0, mask="000110"),
+        dict(name="posture", type="posture", kp=10.0),
+        dict(name="torso", type="se3", tracked="chest", kp=30.0, mask="000111"),
+        dict(name="head", type="se3", tracked="head", kp=30.0, mask="110111"),
+        dict(name="bounds", type="bounds"),
+        dict(name="contact_lfoot", joint="l_ankle_roll", **foot),
+        dict(name="contact_rfoot", joint="r_ankle_roll", **foot),
+        _sc("self_collision-left", "l_wrist_yaw", 0.05, av("r_wrist_yaw"), 50.0),
+        _sc("self_collision-right", "r_wrist_yaw", 0.05, av("l_wrist_yaw"), 50.0),
+    ]
+
+
+def icub_like(seed: int = 9) -> Model:
+    """iCub's tree: free-flyer + 32 revolute joints (etc/icub/configurations.srdf:4-52: legs 6 + 6, torso 3, arms 7 + 7,
+    neck 3), numbered depth-first.  Child-sized geometry (total 33 kg), NOT icub.urdf; the ankle-roll frames have z pointing
+    DOWN, which is what the stack's contact normal (0, 0, -1) presumes (etc/icub/tasks.yaml:55-80); the reference posture is a
+    crouch chosen for this geometry (feet flat), not the srdf's joint values, whose axis conventions belong to the real URDF."""
+    rng = np.random.default_rng(seed)
+    names, parent, jtype, place, inert = [], [], [], [], []
+
+    def add(name, par, jt, xyz, mass, size, com, R=None):
+        names.append(name)
+        parent.append(par)
+        jtype.append(jt)
+        place.append(pack_se3(np.eye(3) if R is None else R, xyz))
+        inert.append(_inertia(rng, mass, size, com))
+        return len(names) - 1
+
+    base = add("root_joint", -1, J_FREEFLYER, (0, 0, 0), 5.0, (0.15, 0.2, 0.12), (0.0, 0.0, 0.0))
+    for side, sy in (("l", 1.0), ("r", -1.0)):
+        j = add("%s_hip_pitch" % side, base, J_RY, (0.0, sy * 0.068, -0.12), 0.7, (0.06, 0.06, 0.06), (0, 0, 0))
+        j = add("%s_hip_roll" % side, j, J_RX, (0, 0, 0), 0.5, (0.06, 0.06, 0.06), (0, 0, -0.01))
+        j = add("%s_hip_yaw" % side, j, J_RZ, (0, 0, 0), 1.5, (0.09, 0.09, 0.2), (0, 0, -0.1))
+        j = add("%s_knee" % side, j, J_RY, (0, 0, -0.22), 1.3, (0.08, 0.08, 0.2), (0, 0, -0.1))
+        j = add("%s_ankle_pitch" % side, j, J_RY, (0, 0, -0.21), 0.3, (0.05, 0.05, 0.05), (0, 0, 0))
+        add("%s_ankle_roll" % side, j, J_RX, (0, 0, 0), 0.6, (0.2, 0.09, 0.04), (0.03, 0.0, 0.04), R=_rot(0, np.pi))
+    t = add("torso_pitch", base, J_RY, (0, 0, 0.05), 1.0, (0.1, 0.1, 0.08), (0, 0, 0.02))
+    t = add("torso_roll", t, J_RX, (0, 0, 0.03), 1.0, (0.1, 0.1, 0.08), (0, 0, 0.02))
+    chest = add("torso_yaw", t, J_RZ, (0, 0, 0.03), 7.0, (0.18, 0.25, 0.2), (0.0, 0.0, 0.1))
+    for side, sy in (("l", 1.0), ("r", -1.0)):
+        j = add("%s_shoulder_pitch" % side, chest, J_RY, (0.0, sy * 0.11, 0.16), 0.5, (0.06, 0.06, 0.06), (0, sy * 0.02, 0))
+        j = add("%s_shoulder_roll" % side, j, J_RX, (0, sy * 0.02, 0), 0.3, (0.05, 0.05, 0.05), (0, 0, 0))
+        j = add("%s_shoulder_yaw" % side, j, J_RZ, (0, 0, 0), 0.9, (0.06, 0.06, 0.15), (0, 0, -0.07))
+        j = add("%s_elbow_joint" % side, j, J_RY, (0.0, 0, -0.15), 0.5, (0.05, 0.05, 0.12), (0, 0, -0.05))
+        j = add("%s_wrist_prosup" % side, j, J_RZ, (0, 0, -0.07), 0.3, (0.05, 0.05, 0.08), (0, 0, -0.03))
+        j = add("%s_wrist_pitch" % side, j, J_RY, (0, 0, -0.07), 0.1, (0.04, 0.04, 0.04), (0, 0, 0))
+        add("%s_wrist_yaw" % side, j, J_RX, (0, 0, 0), 0.25, (0.06, 0.03, 0.1), (0, 0, -0.04))
+    n = add("neck_pitch", chest, J_RY, (0, 0, 0.22), 0.2, (0.04, 0.04, 0.04), (0, 0, 0))
+    n = add("neck_roll", n, J_RX, (0, 0, 0.02), 0.2, (0.04, 0.04, 0.04), (0, 0, 0))
+    add("neck_yaw", n, J_RZ, (0, 0, 0.02), 1.3, (0.14, 0.14, 0.16), (0.01, 0, 0.07))
+    nb = len(names)
+    fnames, fbody = list(names), list(range(nb))
+    fplace = [pack_se3(np.eye(3), (0, 0, 0)) for _ in range(nb)]
+
+    def frame(name, body_name, xyz, R=None):
+        fnames.append(name)
+        fbody.append(names.index(body_name))
+        fplace.append(pack_se3(np.eye(3) if R is None else R, xyz))
+
+    frame("l_hand", "l_wrist_yaw", (0, 0, -0.06))
+    frame("r_hand", "r_wrist_yaw", (0, 0, -0.06))
+    frame("left_foot", "l_ankle_roll", (0.03, 0, 0.04))
+    frame("right_foot", "r_ankle_roll", (0.03, 0, 0.04))
+    frame("chest", "torso_yaw", (0, 0, 0.1))
+    frame("head", "neck_yaw", (0, 0, 0.08))
+    frame("v_leg_right", "r_hip_yaw", (0.0, -0.12, 0.0))  # etc/icub/frames.yaml
+    frame("v_leg_left", "l_hip_yaw", (0.0, -0.12, 0.0))
+    na = nb - 1
+    leg = [-0.45, 0.0, 0.0, 0.9, -0.45, 0.0]  # crouch: hip + knee + ankle pitch = 0 keeps the sole level
+    arm = [-0.6, 0.4, 0.0, 0.6, 0.0, 0.0, 0.0]
+    q0 = np.array([0.0, 0.0, 0.5, 0.0, 0.0, 0.0, 1.0] + leg + leg + [0.0, 0.0, 0.0] + arm + [-0.6, -0.4, 0.0, 0.6, 0.0, 0.0, 0.0] + [0.0, 0.0, 0.0])
+    m = Model(name="icub_like", floating_base=True, parent=np.array(parent, dtype=np.int32), jtype=np.array(jtype, dtype=np.int32),
+              placement=np.stack(place), inertia=np.stack(inert), joint_names=names, frame_names=fnames,
+              frame_body=np.array(fbody, dtype=np.int32), frame_placement=np.stack(fplace),
+              q_lb=np.minimum(-rng.uniform(1.0, 2.0, na), q0[7:] - 0.3), q_ub=np.maximum(rng.uniform(1.0, 2.0, na), q0[7:] + 0.3),
+              dq_max=rng.uniform(2.0, 8.0, na), tau_max=np.full(na, 40.0), q0=q0)
+    m.validate()
+    # stand on the ground: put the soles at z = 0
+    _, pf = m.frame_placements(q0)
+    m.q0[2] -= pf[m.frame("left_foot")][2] - 0.0
+    return m
+
+
 def franka_stack() -> List[dict]:
     """/root/reference/etc/franka/tasks.yaml."""
     return [dict(name="ee", type="se3", tracked="panda_joint7", kp=30.0, mask="111111"),

@@ -26,6 +26,11 @@ def _cases():
         st = structure.franka_structure()
         return m, st, mdl.build_taskmap(m, st, mdl.franka_stack())
 
+    def icub():
+        m = mdl.icub_like()
+        st = structure.icub_structure()
+        return m, st, mdl.build_taskmap(m, st, mdl.icub_stack())
+
     def tree(seed, nb, fb):
         def f():
             m = mdl.random_tree(seed, nb, fb, nframe=12)
@@ -33,7 +38,7 @@ def _cases():
             return m, st, mdl.build_taskmap(m, st, stack, dt=2e-3)
         return f
 
-    return {"talos": talos, "franka": franka, "tree_fb": tree(21, 30, True), "tree_fixed": tree(22, 19, False), "tree_big": tree(23, 62, False)}
+    return {"talos": talos, "icub": icub, "franka": franka, "tree_fb": tree(21, 30, True), "tree_fixed": tree(22, 19, False), "tree_big": tree(23, 62, False)}
 
 
 CASES = _cases()

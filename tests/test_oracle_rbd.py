@@ -21,7 +21,7 @@ def oracle_mod():
     return o
 
 
-MODELS = {"talos": lambda: mdl.talos_like(), "franka": lambda: mdl.franka_like(), "tree_fb": lambda: mdl.random_tree(3, 24, True),
+MODELS = {"talos": lambda: mdl.talos_like(), "icub": lambda: mdl.icub_like(), "franka": lambda: mdl.franka_like(), "tree_fb": lambda: mdl.random_tree(3, 24, True),
           "tree_fixed": lambda: mdl.random_tree(4, 17, False)}
 
 
@@ -152,6 +152,22 @@ def test_taskmap_matches_structure():
     assert tm2.n_dense == 6 and tm2.nref == 24 + 9
     with pytest.raises(KeyError):
         mdl.build_taskmap(m2, st2, [dict(name="ee", type="se3", tracked="nope", kp=1.0, mask="111111")])
+
+
+def test_icub_stack_stands_still_at_its_reference_posture(rbd, oracle_mod):
+    """Static equilibrium through the whole oracle pipeline: at rest in the reference posture, with every reference where the
+    robot is, the QP must ask for (almost) no acceleration and for contact forces that carry the weight -- along -z of the
+    ankle frames, the normal etc/icub/tasks.yaml:55-80 gives."""
+    m = mdl.icub_like()
+    st = structure.icub_structure()
+    tm = mdl.build_taskmap(m, st, mdl.icub_stack())
+    s = mdl.sample_states(m, tm, 1, 0, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+    rows = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"])
+    out = oracle_mod.tick_batch(st, dict(rows, tlb=np.zeros((1, 0)), tub=np.zeros((1, 0)), w=st.default_weights[None]))
+    assert out["status"][0] == 0
+    assert np.abs(out["x"][0, :m.nv]).max() < 1e-2
+    fz = out["x"][0, m.nv:].reshape(8, 3)[:, 2]
+    assert np.all(fz < 0.0) and abs(fz.sum() + m.inertia[:, 0].sum() * 9.81) < 1e-3 * m.inertia[:, 0].sum() * 9.81
 
 
 def test_task_rows_reuse_the_terms(rbd):
