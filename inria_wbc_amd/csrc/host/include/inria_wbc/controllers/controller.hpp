@@ -84,6 +84,7 @@ namespace inria_wbc {
             virtual void set_com_ref(const TrajectorySample&) {}
             virtual void set_se3_ref(const std::string&, const TrajectorySample&) {}
             virtual void set_posture_ref(const std::vector<double>&) {}
+            virtual std::vector<double> get_se3_ref(const std::string&) const { return {}; } // 12 numbers, SE3ToVector order
         };
 
         class Controller {

@@ -202,6 +202,12 @@ namespace inria_wbc {
                     }
                 IWBC_ERROR("Task [", name, "] not found");
             }
+            std::vector<double> get_se3_ref(const std::string& name) const override
+            {
+                for (size_t i = 0; i < tasks_.size(); ++i)
+                    if (names_[i] == name && tasks_[i].kind == WBCQP_T_SE3) return std::vector<double>(ref_.begin() + tasks_[i].ref, ref_.begin() + tasks_[i].ref + 12);
+                IWBC_ERROR("Task [", name, "] not found");
+            }
             void set_posture_ref(const std::vector<double>& q_actuated) override
             {
                 IWBC_ASSERT((int)q_actuated.size() == robot_->na(), "the posture reference holds na entries");

@@ -95,6 +95,14 @@ namespace inria_wbc {
                 if (source_ && source_->handles_references()) source_->set_se3_ref(task_name, sample);
             }
             const std::vector<double>& get_com_ref() const { return com_init_; }
+            // PosTracker::get_se3_ref (pos_tracker.cpp:211-218): the task's current reference placement, 12 numbers in
+            // SE3ToVector order (translation, rotation column-major)
+            std::vector<double> get_se3_ref(const std::string& task_name) const
+            {
+                IWBC_ASSERT(stack_.has_task(task_name), "Task [", task_name, "] not found");
+                IWBC_ASSERT(source_ && source_->handles_references(), "get_se3_ref needs a source that holds the task references (CONTROLLER.model)");
+                return source_->get_se3_ref(task_name);
+            }
             double objective_value(int instance = 0) const { return objective_.at(instance); }
             double cost(const std::string& task_name) const override
             {

@@ -1,4 +1,5 @@
-// Static registrations under the reference's string keys (pos_tracker.cpp:38, move_com.cpp:6).
+// Static registrations under the reference's string keys (pos_tracker.cpp:38, move_com.cpp:6, cartesian.cpp:6).
+#include <inria_wbc/behaviors/generic/cartesian.hpp>
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
 #include <inria_wbc/controllers/pos_tracker.hpp>
 
@@ -7,6 +8,9 @@ namespace inria_wbc {
         static Register<PosTracker> __generic_pos_tracker("pos-tracker");
     }
     namespace behaviors {
+        namespace generic {
+            static Register<Cartesian> __talos_move_arm("generic::cartesian");
+        }
         namespace humanoid {
             static Register<MoveCom> __talos_move_com("humanoid::move_com");
         }

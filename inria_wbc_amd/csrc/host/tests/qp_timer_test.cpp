@@ -9,6 +9,7 @@
 #include <fstream>
 #include <iostream>
 
+#include <inria_wbc/behaviors/generic/cartesian.hpp>
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
 #include <inria_wbc/controllers/file_source.hpp>
 #include <inria_wbc/utils/timer.hpp>

@@ -51,3 +51,66 @@ def move_com_stream(task_init, targets, mask: str, dt: float, duration: float, l
         acc.append(min_jerk_trajectory(start, end, dt, duration, 2))
         start = end
     return np.concatenate(pos), np.concatenate(vel), np.concatenate(acc)
+
+
+def _angle_axis(R: np.ndarray):
+    """Eigen::AngleAxisd(Matrix3d): matrix -> quaternion -> (angle, axis); identity gives (0, x)."""
+    t = np.trace(R)
+    if t > 0.0:
+        s = np.sqrt(t + 1.0)
+        w = 0.5 * s
+        s = 0.5 / s
+        v = np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s])
+    else:
+        i = 0
+        if R[1, 1] > R[0, 0]:
+            i = 1
+        if R[2, 2] > R[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        v = np.zeros(3)
+        v[i] = 0.5 * s
+        s = 0.5 / s
+        w = (R[k, j] - R[j, k]) * s
+        v[j] = (R[j, i] + R[i, j]) * s
+        v[k] = (R[k, i] + R[i, k]) * s
+    n = np.linalg.norm(v)
+    if n == 0.0:
+        return 0.0, np.array([1.0, 0.0, 0.0])
+    angle = 2.0 * np.arctan2(n, abs(w))
+    return angle, v / (-n if w < 0.0 else n)
+
+
+def min_jerk_se3(R0: np.ndarray, p0: np.ndarray, R1: np.ndarray, p1: np.ndarray, dt: float, duration: float):
+    """Poses (R [n,3,3], p [n,3]) and 6-D first / second derivatives (linear, angular) of the SE(3) min-jerk move of
+    /root/reference/include/inria_wbc/trajs/trajectory_generator.hpp:80-147: translation by the polynomial, rotation about
+    the fixed axis of R0' R1 with a min-jerk angle."""
+    angle, axis = _angle_axis(R0.T @ R1)
+    n = int(np.floor(duration / dt))
+    Rs, ps, d1, d2 = np.zeros((n, 3, 3)), np.zeros((n, 3)), np.zeros((n, 6)), np.zeros((n, 6))
+    K = np.array([[0.0, -axis[2], axis[1]], [axis[2], 0.0, -axis[0]], [-axis[1], axis[0], 0.0]])
+    for i in range(n):
+        t = dt * i
+        ps[i] = minimum_jerk_polynom(p0, p1, t, duration, 0)
+        a = minimum_jerk_polynom([0.0], [angle], t, duration, 0)[0]
+        Rs[i] = R0 @ (np.eye(3) + np.sin(a) * K + (1.0 - np.cos(a)) * (K @ K))
+        for order, out in ((1, d1), (2, d2)):
+            out[i, :3] = minimum_jerk_polynom(p0, p1, t, duration, order)
+            out[i, 3:] = R0 @ (minimum_jerk_polynom([0.0], [angle], t, duration, order)[0] * axis)
+    return Rs, ps, d1, d2
+
+
+def cartesian_stream(R_init: np.ndarray, p_init: np.ndarray, rel_pos, dt: float, duration: float, loop: bool = True, rel_rpy=None):
+    """The sample stream `generic::cartesian` precomputes for one task (cartesian.cpp:28-61): init -> target (-> init when
+    looping).  Returns (R, p, vel, acc) concatenated over the segments."""
+    Rf, pf = R_init.copy(), p_init + np.asarray(rel_pos, dtype=np.float64)
+    if rel_rpy is not None and len(rel_rpy) == 3:
+        r, pch, y = rel_rpy
+        cz, sz, cy, sy, cx, sx = np.cos(y), np.sin(y), np.cos(pch), np.sin(pch), np.cos(r), np.sin(r)
+        rot = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        Rf = rot @ R_init
+    segs = [min_jerk_se3(R_init, p_init, Rf, pf, dt, duration)]
+    if loop:
+        segs.append(min_jerk_se3(Rf, pf, R_init, p_init, dt, duration))
+    return tuple(np.concatenate([s[k] for s in segs]) for k in range(4))

@@ -112,9 +112,26 @@ def emit_model_files():
         f.write("  ref_config: inria_start\n  tasks: tasks.yaml\n  dt: 0.001\n  floating_base: true\n  closed_loop: false\n  verbose: false\n  batch: 8\n")
 
 
+def emit_franka_model_files():
+    """BASELINE config 1 on the model: Franka-like tree, CONTROLLER tree with it, the line behaviour of etc/franka/cartesian_line.yaml."""
+    from inria_wbc_amd import model as mdl
+    d = os.path.join(ROOT, "configs", "franka")
+    os.makedirs(d, exist_ok=True)
+    mdl.to_yaml(mdl.franka_like(), os.path.join(d, "franka_like.model.yaml"), ref_name="start")
+    with open(os.path.join(d, "pos_tracker_model.yaml"), "w") as f:
+        f.write("# CONTROLLER tree with the step before the path on the device (`model` stands where inria_wbc has `urdf`)\n")
+        f.write("CONTROLLER:\n  name: pos-tracker\n  solver: hip-batched\n  base_path: .\n  model: franka_like.model.yaml\n")
+        f.write("  ref_config: start\n  tasks: tasks.yaml\n  dt: 0.001\n  floating_base: false\n  closed_loop: false\n  verbose: false\n  batch: 4\n")
+    with open(os.path.join(d, "cartesian_line.yaml"), "w") as f:
+        f.write("# BEHAVIOR tree of the line (schema and values of inria_wbc's etc/franka/cartesian_line.yaml)\n")
+        f.write("BEHAVIOR:\n  name: generic::cartesian\n  task_names: [ee]\n  trajectory_duration: 2\n  relative_targets_pos: [[-0.4, 0, 0]]\n")
+        f.write("  relative_targets_rpy: [[], []]\n  loop: true\n")
+
+
 def main():
     ROBOTS["talos"] = (talos_with_avoided(), 50, 44, True)
     emit_model_files()
+    emit_franka_model_files()
     for robot, (tasks, nv, na, fb) in ROBOTS.items():
         d = os.path.join(ROOT, "configs", robot)
         os.makedirs(d, exist_ok=True)
