@@ -1,5 +1,6 @@
-// Static registrations under the reference's string keys (pos_tracker.cpp:38, move_com.cpp:6, cartesian.cpp:6).
+// Static registrations under the reference's string keys (pos_tracker.cpp:38, move_com.cpp:6, cartesian.cpp:6, cartesian_traj.cpp:6).
 #include <inria_wbc/behaviors/generic/cartesian.hpp>
+#include <inria_wbc/behaviors/generic/cartesian_traj.hpp>
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
 #include <inria_wbc/controllers/pos_tracker.hpp>
 
@@ -10,6 +11,7 @@ namespace inria_wbc {
     namespace behaviors {
         namespace generic {
             static Register<Cartesian> __talos_move_arm("generic::cartesian");
+            static Register<CartesianTraj> __generic_cartesian_trajectory("generic::cartesian_traj");
         }
         namespace humanoid {
             static Register<MoveCom> __talos_move_com("humanoid::move_com");

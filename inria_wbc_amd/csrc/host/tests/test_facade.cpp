@@ -72,6 +72,7 @@ int main(int argc, char** argv)
     // ---- factories: unknown name lists the known ones; known names are registered ----
     UTEST_CHECK(controllers::Factory::instance().has("pos-tracker"));
     UTEST_CHECK(behaviors::Factory::instance().has("humanoid::move_com"));
+    UTEST_CHECK(behaviors::Factory::instance().has("generic::cartesian") && behaviors::Factory::instance().has("generic::cartesian_traj"));
     UTEST_CHECK_EXCEPTION(controllers::Factory::instance().create("no-such-controller", yaml::Node()), "is not in the factory");
     // ---- solver switch (pos_tracker.cpp:88-100) ----
     {

@@ -145,3 +145,53 @@ def test_qp_timer_test_franka_cartesian_line(host_build, oracle_mod, tmp_path):
     p_now = m.frame_placements(q[0])[1][ee]
     assert np.abs(p_now - ps[n_ticks - 1]).max() < 0.06, (p_now, ps[n_ticks - 1])
     assert pf0[ee][0] - p_now[0] > 0.02
+
+
+@pytest.mark.gpu
+def test_qp_timer_test_franka_cartesian_traj_files(host_build, oracle_mod, tmp_path):
+    """generic::cartesian_traj: SE(3) references replayed from trajectory files in the reference's wire format
+    (src/trajs/loader.cpp:11-53: 3 + 9 numbers per sample, rotation column-major), forward then backward, against the oracle
+    loop stepping through the same samples."""
+    from scipy.spatial.transform import Rotation as Rot
+    from inria_wbc_amd import model as mdl, structure
+    from oracle import rbd
+    m = mdl.franka_like()
+    st = structure.franka_structure()
+    tm = mdl.build_taskmap(m, st, mdl.franka_stack())
+    ee = m.frame("panda_joint7")
+    Rf0, pf0 = m.frame_placements(m.q0)
+    n_samples, n_ticks, scale = 60, 150, 1.0
+    poses = []
+    for k in range(n_samples):
+        a = k / (n_samples - 1.0)
+        R = Rf0[ee] @ Rot.from_rotvec([0.3 * a, -0.2 * a, 0.1 * a]).as_matrix()
+        poses.append(mdl.se3_ref(R, pf0[ee] + np.array([-0.1 * a, 0.05 * a, 0.02 * np.sin(3 * a)])))
+    np.savetxt(tmp_path / "ee.csv", np.array(poses))
+    (tmp_path / "refs.yaml").write_text("refs:\n  ee: ee.csv\n")
+    (tmp_path / "traj.yaml").write_text("BEHAVIOR:\n  name: generic::cartesian_traj\n  trajectories: %s\n  scale: %g\n  loop: true\n"
+                                        % (tmp_path / "refs.yaml", scale))
+    tau_path, q_path = str(tmp_path / "tau.bin"), str(tmp_path / "q.bin")
+    r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/franka/pos_tracker_model.yaml"), str(tmp_path / "traj.yaml"),
+                        "-", str(n_ticks), tau_path, "0", q_path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    q = np.fromfile(q_path, dtype=np.float64).reshape(4, m.nq)
+    s = mdl.sample_states(m, tm, 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+    oq, ov, oref = s["q"], s["v"], s["ref"]
+    blk = tm.blocks[0]
+    empty, w = np.zeros((1, 0)), st.default_weights[None]
+    t, step, visited = 0, 1, []
+    for k in range(n_ticks):
+        visited.append(t)
+        oref[0, blk.ref:blk.ref + 24] = 0.0
+        oref[0, blk.ref:blk.ref + 12] = poses[t]
+        rows = rbd.task_rows(m, tm, st, oq, ov, oref)
+        oo = oracle_mod.tick_batch(st, dict(rows, tlb=empty, tub=empty, w=w))
+        nxt = oracle_mod.integrate(False, tm.dt, oq, ov, oo["x"][:, :st.nv])
+        oq, ov = nxt["q_next"], nxt["v_next"]
+        t += step
+        if t >= n_samples - 1:
+            step = -1
+        elif t <= 0:
+            step = 1
+    assert max(visited) == n_samples - 1 and visited[-1] < n_samples - 1  # went to the end and is on its way back
+    assert np.abs(q[0] - oq[0]).max() < 1e-8, np.abs(q[0] - oq[0]).max()
