@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--noise", type=float, default=0.5)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--model", action="store_true", help="rows from the Talos-like model (wbcqp_problem_data) instead of the synthetic generator")
+    ap.add_argument("--qnoise", type=float, default=0.01)
     args = ap.parse_args()
     import torch
     from inria_wbc_amd import capi, structure, synth
@@ -34,9 +36,25 @@ def main():
     lib = capi.load_library(capi.LIB_PATH)
     st = structure.STRUCTURES[args.robot]()
     B = args.batch
-    inputs = synth.generate(st, B, synth.SEED_BASE[args.robot], task_noise=args.noise)
     dev = torch.device("cuda", 0)
-    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
+    if args.model:
+        from inria_wbc_amd import model as mdl
+        m = mdl.talos_like()
+        tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+        s = mdl.sample_states(m, tm, B, 9_000_000, q_noise=args.qnoise, v_noise=5 * args.qnoise, ref_noise=args.qnoise)
+        hh = capi.Handle(0, capi.F64)
+        hh.set_structure(0, st)
+        hh.set_model(0, m, tm)
+        L = st.field_lengths()
+        d_in = {k: torch.zeros(B, L[k], dtype=torch.float64, device=dev) for k in capi.ROW_FIELDS}
+        hh.problem_data(0, B, {k: torch.from_numpy(s[k]).to(dev) for k in ("q", "v", "ref")}, d_in)
+        torch.cuda.synchronize()
+        d_in["tlb"] = torch.from_numpy(np.tile(-m.tau_max, (B, 1))).to(dev)
+        d_in["tub"] = torch.from_numpy(np.tile(m.tau_max, (B, 1))).to(dev)
+        d_in["w"] = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev)
+    else:
+        inputs = synth.generate(st, B, synth.SEED_BASE[args.robot], task_noise=args.noise)
+        d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
     d_out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
                  status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
     dbg = torch.zeros(B, 24, dtype=torch.int64, device=dev)
