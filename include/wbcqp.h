@@ -302,6 +302,11 @@ typedef struct {
 } wbcqp_tick_io;
 
 int wbcqp_tick(wbcqp_handle* handle, int slot, int batch, const wbcqp_tick_io* io, void* stream);
+/* Same with HOST pointers; blocks until done.  Only the state, the references and the constant tlb / tub / w cross to the
+ * device and only x, tau, status, iters (objective, n_active if given) and the integrated state come back: about 4 KB per
+ * Talos instance instead of the 34 KB record.  The row arrays M .. bub of io->rows may be NULL; where given they receive the
+ * rows of this tick (what Controller::cost() reads). */
+int wbcqp_tick_host(wbcqp_handle* handle, int slot, int batch, const wbcqp_tick_io* io);
 
 /* The same sequence captured once into a HIP graph and replayed: one graph launch per tick instead of four kernel
  * launches (what matters when the batch is small -- one robot at 1 kHz is the reference's own use case).  The graph is

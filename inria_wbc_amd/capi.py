@@ -25,7 +25,7 @@ FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
 EXPORTS = ("wbcqp_version", "wbcqp_last_error", "wbcqp_create", "wbcqp_destroy", "wbcqp_set_structure",
            "wbcqp_layout_of", "wbcqp_solve_batch", "wbcqp_solve_batch_host", "wbcqp_solve_ragged",
            "wbcqp_allgather_tau", "wbcqp_integrate", "wbcqp_integrate_host", "wbcqp_set_model", "wbcqp_problem_data",
-           "wbcqp_problem_data_host", "wbcqp_tick", "wbcqp_tick_graph_create", "wbcqp_tick_graph_launch", "wbcqp_tick_graph_destroy",
+           "wbcqp_problem_data_host", "wbcqp_tick", "wbcqp_tick_host", "wbcqp_tick_graph_create", "wbcqp_tick_graph_launch", "wbcqp_tick_graph_destroy",
            "wbcqp_sync")
 ROW_FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub")  # what wbcqp_problem_data writes
 
@@ -137,6 +137,7 @@ def load_library(path: Optional[str] = None):
     lib.wbcqp_problem_data.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CState), C.POINTER(CInputs), C.c_void_p]
     lib.wbcqp_problem_data_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CState), C.POINTER(CInputs)]
     lib.wbcqp_tick.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CTickIO), C.c_void_p]
+    lib.wbcqp_tick_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CTickIO)]
     lib.wbcqp_tick_graph_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CTickIO), C.POINTER(C.c_void_p)]
     lib.wbcqp_tick_graph_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.wbcqp_tick_graph_destroy.argtypes = [C.c_void_p, C.c_void_p]
@@ -363,6 +364,37 @@ class Handle:
         """rows -> QP -> integration for one control tick (wbcqp_tick), device tensors."""
         io = self._tick_io(slot, batch, state, rows, out, q_next, v_next, dt, q_solver)
         self._check(self.lib.wbcqp_tick(self._h, slot, batch, C.byref(io), C.c_void_p(stream)))
+
+    def tick_host(self, slot: int, q: np.ndarray, v: np.ndarray, ref: np.ndarray, tlb, tub, w, dt: float, want_rows: bool = False):
+        """One whole tick with host arrays (wbcqp_tick_host): returns dict(x, tau, status, iters, q_next, v_next, q_solver[, rows])."""
+        st = self._structs[slot]
+        L = st.field_lengths()
+        f = lambda a: np.ascontiguousarray(a, dtype=self.np_dtype)
+        q, v, ref, w = f(q), f(v), f(ref), f(w)
+        B = q.shape[0]
+        tlb, tub = (f(tlb), f(tub)) if L["tlb"] else (None, None)
+        out = dict(x=np.zeros((B, st.n), self.np_dtype), tau=np.zeros((B, max(st.na, 1)), self.np_dtype), status=np.full(B, -99, np.int32),
+                   iters=np.zeros(B, np.int32), q_next=np.zeros_like(q), v_next=np.zeros_like(v), q_solver=np.zeros_like(v))
+        rows = {k: np.zeros((B, max(L[k], 1)), self.np_dtype) for k in ROW_FIELDS} if want_rows else {}
+        io = CTickIO()
+        io.state = CState(q.ctypes.data, v.ctypes.data, ref.ctypes.data)
+        cin = CInputs()
+        for k in FIELDS:
+            setattr(cin, k, None)
+        for k, a in rows.items():
+            if L[k]:
+                setattr(cin, k, a.ctypes.data)
+        if L["tlb"]:
+            cin.tlb, cin.tub = tlb.ctypes.data, tub.ctypes.data
+        cin.w = w.ctypes.data
+        io.rows = cin
+        io.out = COutputs(out["x"].ctypes.data, out["tau"].ctypes.data, out["status"].ctypes.data, out["iters"].ctypes.data, None, None)
+        io.q_next, io.v_next, io.q_solver, io.dt = out["q_next"].ctypes.data, out["v_next"].ctypes.data, out["q_solver"].ctypes.data, float(dt)
+        self._check(self.lib.wbcqp_tick_host(self._h, slot, B, C.byref(io)))
+        out["tau"] = out["tau"][:, :st.na]
+        if want_rows:
+            out["rows"] = {k: a[:, :L[k]] for k, a in rows.items()}
+        return out
 
     def tick_graph(self, slot: int, batch: int, state, rows, out, q_next, v_next, dt: float, q_solver=None) -> int:
         """Captures the tick into a HIP graph bound to these buffers; returns the graph handle for tick_graph_launch."""

@@ -85,6 +85,8 @@ namespace inria_wbc {
             virtual void set_se3_ref(const std::string&, const TrajectorySample&) {}
             virtual void set_posture_ref(const std::vector<double>&) {}
             virtual std::vector<double> get_se3_ref(const std::string&) const { return {}; } // 12 numbers, SE3ToVector order
+            virtual const double* reference_data() const { return nullptr; }                   // [batch][nref] for wbcqp_tick_host
+            virtual void fill_limits(const wbcqp_layout&, TickInputs&) const {}                // constant tlb / tub
         };
 
         class Controller {
@@ -175,8 +177,27 @@ namespace inria_wbc {
                 wbcqp_inputs in = {in_.M.data(), in_.h.data(), in_.A.data(), in_.b1.data(), in_.Ac.data(), in_.bc.data(),
                                    in_.blb.data(), in_.bub.data(), in_.tlb.data(), in_.tub.data(), in_.w.data()};
                 wbcqp_outputs out = {x_.data(), tau_.data.data(), status_.data(), iters_.data(), objective_.data(), nullptr};
-                int rc = wbcqp_solve_batch_host(handle_, _slot(), B, &in, &out);
-                if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_solve_batch_host failed: ", wbcqp_last_error(handle_));
+                IWBC_ASSERT(q.cols == (floating_base_ ? nv + 1 : nv), "q must hold ", floating_base_ ? nv + 1 : nv, " entries per instance");
+                MatrixXd vnew(B, nv);
+                MatrixXd qnew(B, q.cols);
+                const bool whole_tick = source_->handles_references();
+                if (whole_tick) {
+                    // rows, QP and integration in one trip to the device: only the state and the references go up, the solution
+                    // and the integrated state come back (plus this tick's rows, which cost() reads)
+                    wbcqp_tick_io io{};
+                    io.state = {q.data.data(), dq.data.data(), source_->reference_data()};
+                    io.rows = in;
+                    io.out = out;
+                    io.q_next = qnew.data.data();
+                    io.v_next = vnew.data.data();
+                    io.q_solver = nullptr;
+                    io.dt = dt_;
+                    if (wbcqp_tick_host(handle_, _slot(), B, &io) != WBCQP_OK) IWBC_ERROR("wbcqp_tick_host failed: ", wbcqp_last_error(handle_));
+                }
+                else {
+                    int rc = wbcqp_solve_batch_host(handle_, _slot(), B, &in, &out);
+                    if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_solve_batch_host failed: ", wbcqp_last_error(handle_));
+                }
                 for (int i = 0; i < B; ++i) {
                     if (status_[i] != WBCQP_HQP_OPTIMAL) {
                         // same text as controller.cpp:285-307, with the instance appended
@@ -199,10 +220,8 @@ namespace inria_wbc {
                 a_tsid_ = MatrixXd(B, nv);
                 for (int i = 0; i < B; ++i)
                     for (int j = 0; j < nv; ++j) a_tsid_(i, j) = x_[(size_t)i * n + j];
-                MatrixXd vnew(B, nv);
-                MatrixXd qnew(B, q.cols);
-                IWBC_ASSERT(q.cols == (floating_base_ ? nv + 1 : nv), "q must hold ", floating_base_ ? nv + 1 : nv, " entries per instance");
-                if (wbcqp_integrate_host(handle_, B, nv, floating_base_ ? 1 : 0, dt_, q.data.data(), dq.data.data(), x_.data(), n,
+                if (!whole_tick &&
+                    wbcqp_integrate_host(handle_, B, nv, floating_base_ ? 1 : 0, dt_, q.data.data(), dq.data.data(), x_.data(), n,
                                          status_.data(), qnew.data.data(), vnew.data.data(), nullptr) != WBCQP_OK)
                     IWBC_ERROR(wbcqp_last_error(handle_));
                 v_tsid_ = vnew;

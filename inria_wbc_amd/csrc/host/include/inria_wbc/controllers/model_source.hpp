@@ -168,15 +168,20 @@ namespace inria_wbc {
                 rows.bc = in.bc.data(); rows.blb = in.blb.data(); rows.bub = in.bub.data();
                 if (wbcqp_problem_data_host(handle_, slot_, batch_, &st, &rows) != WBCQP_OK)
                     IWBC_ERROR("wbcqp_problem_data_host failed: ", wbcqp_last_error(handle_));
-                // actuation bounds: -tau_max, tau_max (tasks.cpp:315-316)
+                fill_limits(L, in);
+                (void)stack;
+            }
+            // actuation bounds: -tau_max, tau_max (tasks.cpp:315-316)
+            void fill_limits(const wbcqp_layout& L, TickInputs& in) const override
+            {
                 const auto& tmax = robot_->effortLimit();
                 for (int i = 0; i < batch_; ++i)
                     for (int j = 0; j < L.len_tlb; ++j) {
                         in.tlb[(size_t)i * L.len_tlb + j] = -tmax[j];
                         in.tub[(size_t)i * L.len_tub + j] = tmax[j];
                     }
-                (void)stack;
             }
+            const double* reference_data() const override { return ref_.data(); }
             void com(MatrixXd& pos, MatrixXd& vel) const override { pos = com_pos_; vel = com_vel_; }
 
             void set_com_ref(const TrajectorySample& s) override

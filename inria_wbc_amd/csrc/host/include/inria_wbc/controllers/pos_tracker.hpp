@@ -214,7 +214,10 @@ namespace inria_wbc {
             void _build_inputs(const MatrixXd& q, const MatrixXd& v) override
             {
                 in_.resize(batch_, layout_);
-                source_->compute(t_, q, v, stack_, layout_, in_);
+                if (source_->handles_references())
+                    source_->fill_limits(layout_, in_); // the rows themselves are computed inside the tick (Controller::_solve)
+                else
+                    source_->compute(t_, q, v, stack_, layout_, in_);
                 for (int i = 0; i < batch_; ++i)
                     for (int k = 0; k < layout_.len_w; ++k) in_.w[(size_t)i * layout_.len_w + k] = weights_[k];
                 // CoM task PD law: b += Kp (x_ref - x) + Kd (v_ref - v) + a_ref on the masked axes (tsid TaskComEquality)

@@ -884,6 +884,73 @@ int wbcqp_tick(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io, vo
                            io->out.status, io->q_next, io->v_next, io->q_solver, stream);
 }
 
+int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (!io) return fail(h, WBCQP_ERR_INVALID, "io is NULL");
+    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES || !h->slots[slot].set || !h->slots[slot].has_model)
+        return fail(h, WBCQP_ERR_INVALID, "slot has no model (wbcqp_set_model)");
+    if (batch < 0) return fail(h, WBCQP_ERR_INVALID, "negative batch");
+    if (batch == 0) return WBCQP_OK;
+    const Slot& s = h->slots[slot];
+    const wbcqp_layout& L = s.layout;
+    const TermsDev& T = s.terms;
+    if (!io->state.q || !io->state.v || (T.nref > 0 && !io->state.ref)) return fail(h, WBCQP_ERR_INVALID, "state arrays q / v / ref are required");
+    if ((L.len_tlb && (!io->rows.tlb || !io->rows.tub)) || !io->rows.w) return fail(h, WBCQP_ERR_INVALID, "tlb / tub / w are required");
+    if (!io->out.x || !io->out.status || !io->out.iters || (s.host.na > 0 && !io->out.tau) || !io->q_next || !io->v_next)
+        return fail(h, WBCQP_ERR_INVALID, "x, tau, status, iters, q_next, v_next are required");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t es = (h->dtype == WBCQP_F64) ? 8 : 4;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t B = (size_t)batch;
+    // device staging: inputs | the record | outputs
+    const int ilen[6] = {T.nq, T.nv, T.nref, L.len_tlb, L.len_tub, L.len_w};
+    const void* isrc[6] = {io->state.q, io->state.v, io->state.ref, io->rows.tlb, io->rows.tub, io->rows.w};
+    size_t ioff[6], in_bytes = 0;
+    for (int f = 0; f < 6; ++f) { ioff[f] = in_bytes; in_bytes += al((size_t)ilen[f] * B * es); }
+    const int rlen[8] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub};
+    void* rdst[8] = {(void*)io->rows.M, (void*)io->rows.h, (void*)io->rows.A, (void*)io->rows.b1, (void*)io->rows.Ac, (void*)io->rows.bc,
+                     (void*)io->rows.blb, (void*)io->rows.bub};
+    size_t roff[8];
+    for (int f = 0; f < 8; ++f) { roff[f] = in_bytes; in_bytes += al((size_t)rlen[f] * B * es); }
+    const size_t o_x = 0, o_tau = o_x + al((size_t)L.n * B * es), o_obj = o_tau + al((size_t)s.host.na * B * es), o_st = o_obj + al(B * es),
+                 o_it = o_st + al(B * 4), o_na = o_it + al(B * 4), o_qn = o_na + al(B * 4), o_vn = o_qn + al((size_t)T.nq * B * es),
+                 o_qs = o_vn + al((size_t)T.nv * B * es), out_bytes = o_qs + al((size_t)T.nv * B * es);
+    int rc = ensure(h, h->stage_in, in_bytes + 256);
+    if (rc != WBCQP_OK) return rc;
+    rc = ensure(h, h->stage_out, out_bytes + 256);
+    if (rc != WBCQP_OK) return rc;
+    char* din = static_cast<char*>(h->stage_in.dev);
+    char* dout = static_cast<char*>(h->stage_out.dev);
+    for (int f = 0; f < 6; ++f)
+        if (ilen[f] > 0) HIP_TRY(h, hipMemcpyAsync(din + ioff[f], isrc[f], (size_t)ilen[f] * B * es, hipMemcpyHostToDevice, nullptr));
+    wbcqp_tick_io d{};
+    d.state = {din + ioff[0], din + ioff[1], din + ioff[2]};
+    d.rows.M = din + roff[0]; d.rows.h = din + roff[1]; d.rows.A = din + roff[2]; d.rows.b1 = din + roff[3]; d.rows.Ac = din + roff[4];
+    d.rows.bc = din + roff[5]; d.rows.blb = din + roff[6]; d.rows.bub = din + roff[7];
+    d.rows.tlb = din + ioff[3]; d.rows.tub = din + ioff[4]; d.rows.w = din + ioff[5];
+    d.out.x = dout + o_x; d.out.tau = dout + o_tau; d.out.objective = dout + o_obj;
+    d.out.status = reinterpret_cast<int32_t*>(dout + o_st); d.out.iters = reinterpret_cast<int32_t*>(dout + o_it);
+    d.out.n_active = reinterpret_cast<int32_t*>(dout + o_na);
+    d.q_next = dout + o_qn; d.v_next = dout + o_vn; d.q_solver = io->q_solver ? dout + o_qs : nullptr;
+    d.dt = io->dt;
+    rc = wbcqp_tick(h, slot, batch, &d, nullptr);
+    if (rc != WBCQP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(io->out.x, d.out.x, (size_t)L.n * B * es, hipMemcpyDeviceToHost, nullptr));
+    if (s.host.na > 0) HIP_TRY(h, hipMemcpyAsync(io->out.tau, d.out.tau, (size_t)s.host.na * B * es, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(h, hipMemcpyAsync(io->out.status, d.out.status, B * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(h, hipMemcpyAsync(io->out.iters, d.out.iters, B * 4, hipMemcpyDeviceToHost, nullptr));
+    if (io->out.objective) HIP_TRY(h, hipMemcpyAsync(io->out.objective, d.out.objective, B * es, hipMemcpyDeviceToHost, nullptr));
+    if (io->out.n_active) HIP_TRY(h, hipMemcpyAsync(io->out.n_active, d.out.n_active, B * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(h, hipMemcpyAsync(io->q_next, d.q_next, (size_t)T.nq * B * es, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(h, hipMemcpyAsync(io->v_next, d.v_next, (size_t)T.nv * B * es, hipMemcpyDeviceToHost, nullptr));
+    if (io->q_solver) HIP_TRY(h, hipMemcpyAsync(io->q_solver, d.q_solver, (size_t)T.nv * B * es, hipMemcpyDeviceToHost, nullptr));
+    for (int f = 0; f < 8; ++f)
+        if (rlen[f] > 0 && rdst[f]) HIP_TRY(h, hipMemcpyAsync(rdst[f], din + roff[f], (size_t)rlen[f] * B * es, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(h, hipStreamSynchronize(nullptr));
+    return WBCQP_OK;
+}
+
 struct wbcqp_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;

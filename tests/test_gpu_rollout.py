@@ -126,3 +126,28 @@ def test_tick_and_graph_replay_are_the_three_calls(B):
     for r in results[1:]:
         assert np.array_equal(r[0], results[0][0]) and np.array_equal(r[1], results[0][1]) and np.array_equal(r[2], results[0][2])
     assert (results[0][2] == 0).all()
+
+
+def test_tick_host_equals_the_device_tick():
+    """wbcqp_tick_host stages the state up and the solution down around the same three launches."""
+    import torch
+    m = mdl.talos_like()
+    st = structure.talos_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    B = 9
+    dev = torch.device("cuda", 0)
+    h = capi.Handle(0, capi.F64)
+    h.set_structure(0, st)
+    h.set_model(0, m, tm)
+    state, rows, out, qn, vn = _tick_buffers(m, st, tm, B, 91_000, dev, torch)
+    h.tick(0, B, state, rows, out, qn, vn, tm.dt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = h.tick_host(0, state["q"].cpu().numpy(), state["v"].cpu().numpy(), state["ref"].cpu().numpy(), rows["tlb"].cpu().numpy(),
+                      rows["tub"].cpu().numpy(), rows["w"].cpu().numpy(), tm.dt, want_rows=True)
+    assert np.array_equal(got["x"], out["x"].cpu().numpy()) and np.array_equal(got["tau"], out["tau"].cpu().numpy())
+    assert np.array_equal(got["status"], out["status"].cpu().numpy()) and np.array_equal(got["q_next"], qn.cpu().numpy())
+    assert np.array_equal(got["v_next"], vn.cpu().numpy())
+    for k in capi.ROW_FIELDS:
+        assert np.array_equal(got["rows"][k], rows[k].cpu().numpy()), k
+    assert np.abs(got["q_solver"][:, 6:] - got["q_next"][:, 7:]).max() == 0.0
+    h.close()
