@@ -26,6 +26,11 @@ def _cases():
         st = structure.franka_structure()
         return m, st, mdl.build_taskmap(m, st, mdl.franka_stack())
 
+    def talos_ss():  # single support: contact_lfoot removed as WalkOnSpot does (walk_on_spot.cpp:165-184)
+        m = mdl.talos_like()
+        st = structure.talos_structure(single_support=True)
+        return m, st, mdl.build_taskmap(m, st, [n for n in mdl.talos_stack() if n["name"] != "contact_lfoot"])
+
     def icub():
         m = mdl.icub_like()
         st = structure.icub_structure()
@@ -38,7 +43,7 @@ def _cases():
             return m, st, mdl.build_taskmap(m, st, stack, dt=2e-3)
         return f
 
-    return {"talos": talos, "icub": icub, "franka": franka, "tree_fb": tree(21, 30, True), "tree_fixed": tree(22, 19, False), "tree_big": tree(23, 62, False)}
+    return {"talos": talos, "talos_single_support": talos_ss, "icub": icub, "franka": franka, "tree_fb": tree(21, 30, True), "tree_fixed": tree(22, 19, False), "tree_big": tree(23, 62, False)}
 
 
 CASES = _cases()
