@@ -641,8 +641,8 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     }
     auto frame_ok = [&](int f) { return f >= 0 && f < md->nframe && md->frame_body[f] >= 0 && md->frame_body[f] < nb; };
     // tasks -> law lanes (SE3 blocks then contacts), self-collision pairs, blocks
-    std::vector<int> law_body, law_mask, law_row, law_ref, law_va, law_contact, pair_block, pair_bt, pair_ba;
-    std::vector<int> blk_kind, blk_mask, blk_row, blk_ref, blk_law, blk_pair0, blk_npair;
+    std::vector<int> law_body, law_mask, law_row, law_ref, law_va, law_contact, pair_bt, pair_ba;
+    std::vector<int> blk_kind, blk_mask, blk_row, blk_ref, blk_pair0, blk_npair;
     std::vector<double> law_place, law_kp, law_kd, scf_place, pair_par, blk_kp, blk_kd;
     std::vector<int> scf_frame, scf_body, pair_ft, pair_fa;
     auto scf_index = [&](int f) {
@@ -658,11 +658,10 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
         const wbcqp_task& K = tm->task[t];
         blk_kind.push_back(K.kind); blk_mask.push_back(K.mask); blk_row.push_back(row); blk_ref.push_back(K.ref);
         blk_kp.push_back(K.kp); blk_kd.push_back(K.kd);
-        blk_law.push_back(-1); blk_pair0.push_back((int)pair_block.size()); blk_npair.push_back(0);
+        blk_pair0.push_back((int)pair_bt.size()); blk_npair.push_back(0);
         int need = 0;
         if (K.kind == WBCQP_T_SE3) {
             if (!frame_ok(K.frame)) return fail(h, WBCQP_ERR_INVALID, "SE3 task tracks a frame that does not exist");
-            blk_law.back() = (int)law_body.size();
             law_body.push_back(md->frame_body[K.frame]); law_mask.push_back(K.mask & 63); law_row.push_back(row);
             law_ref.push_back(K.ref); law_va.push_back(1); law_contact.push_back(-1);
             law_kp.push_back(K.kp); law_kd.push_back(K.kd);
@@ -681,7 +680,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
             for (int a = 0; a < K.n_avoided; ++a) {
                 const int fa = K.avoided_frame[a];
                 if (!frame_ok(fa)) return fail(h, WBCQP_ERR_INVALID, "self-collision task avoids a frame that does not exist");
-                pair_block.push_back(t); pair_bt.push_back(md->frame_body[K.frame]); pair_ba.push_back(md->frame_body[fa]);
+                pair_bt.push_back(md->frame_body[K.frame]); pair_ba.push_back(md->frame_body[fa]);
                 pair_ft.push_back(scf_index(K.frame)); pair_fa.push_back(scf_index(fa));
                 const double par[6] = {K.avoided_r0[a] + K.radius, k5, s_p, K.m, K.kp, K.kd};
                 pair_par.insert(pair_par.end(), par, par + 6);
@@ -718,7 +717,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
             const int a = anc[(size_t)(r - 1) * nb + i];
             anc[(size_t)r * nb + i] = (a >= 0) ? anc[(size_t)(r - 1) * nb + a] : -1;
         }
-    T.nlaw = (int)law_body.size(); T.npair = (int)pair_block.size(); T.nscf = (int)scf_frame.size(); T.nblock = (int)blk_kind.size(); T.nc = D.nc;
+    T.nlaw = (int)law_body.size(); T.npair = (int)pair_bt.size(); T.nscf = (int)scf_frame.size(); T.nblock = (int)blk_kind.size(); T.nc = D.nc;
     T.n_dense = D.n_dense; T.n_sel = D.n_sel; T.n_bound = D.n_bound; T.r1 = D.r1; T.nref = tm->nref;
     T.posture_ref = tm->posture_ref; T.posture_kp = tm->posture_kp; T.posture_kd = tm->posture_kd; T.dt = tm->dt;
     for (int k = 0; k < 3; ++k) T.g[k] = md->gravity[k];
