@@ -181,3 +181,40 @@ def test_problem_data_golden_gpu(handle, tag):
     handle.set_model(5, m, tm)
     dev = handle.problem_data_host(5, z["q"], z["v"], z["ref"])
     _compare(dev, {k: z[k] for k in capi.ROW_FIELDS})
+
+
+def test_mixed_robots_rows_then_one_ragged_solve(rbd):
+    """BASELINE config 5 with rows from the models: Talos-like, iCub-like and Franka-like instances, one wbcqp_problem_data
+    launch per robot type, then ONE wbcqp_solve_ragged launch over the three groups, against the oracle pipeline."""
+    import torch
+    from oracle import oracle as orc
+    dev = torch.device("cuda", 0)
+    h = capi.Handle(0, capi.F64)
+    stream = torch.cuda.current_stream().cuda_stream
+    groups, checks = [], []
+    for slot, (name, B) in enumerate((("talos", 20), ("icub", 33), ("franka", 50))):
+        m, st, tm = CASES[name]()
+        h.set_structure(slot, st)
+        h.set_model(slot, m, tm)
+        s = mdl.sample_states(m, tm, B, 61_000 + slot)
+        L = st.field_lengths()
+        rows = {k: torch.zeros(B, L[k], dtype=torch.float64, device=dev) for k in capi.ROW_FIELDS}
+        tmax = m.tau_max if st.act_bounds else np.zeros(0)
+        rows["tlb"] = torch.from_numpy(np.tile(-tmax, (B, 1))).to(dev)
+        rows["tub"] = torch.from_numpy(np.tile(tmax, (B, 1))).to(dev)
+        rows["w"] = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev)
+        h.problem_data(slot, B, {k: torch.from_numpy(s[k]).to(dev) for k in ("q", "v", "ref")}, rows, stream=stream)
+        out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
+                   status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+        groups.append((slot, B, rows, out))
+        ora = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"], n_threads=4)
+        checks.append((st, out, dict(ora, tlb=np.tile(-tmax, (B, 1)), tub=np.tile(tmax, (B, 1)), w=np.tile(st.default_weights, (B, 1)))))
+    h.solve_ragged(groups, stream=stream)
+    torch.cuda.synchronize()
+    for st, out, ora_in in checks:
+        ref = orc.tick_batch(st, ora_in, nthreads=4)
+        got = {k: v.cpu().numpy() for k, v in out.items()}
+        got["tau"] = got["tau"][:, :st.na]
+        assert (ref["status"] == 0).all()
+        assert_parity(st, got, ref)
+    h.close()
