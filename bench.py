@@ -262,7 +262,10 @@ def main():
             result["after_path"] = {"kernel": "wbcqp::integrate_kernel<double>", "us_per_launch": us, "bytes_per_launch": ibytes,
                                     "achieved_GBps": ibytes / (us * 1e-6) / 1e9, "bound": "hbm (launch-latency sized at this batch)"}
         if world == 1 and args.robot == "talos":
-            result["before_path"] = before_path(h, st, dev, B, torch, not args.no_cpu_baseline)
+            try:  # secondary section: never allowed to take the headline line down with it
+                result["before_path"] = before_path(h, st, dev, B, torch, not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                result["before_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.index_order and not args.no_compare:
             # the same K steps with the launch in plain index order (WBCQP_FLAG_INDEX_ORDER), reported beside `value`
             h2 = capi.Handle(device=local_rank, dtype=capi.F64, flags=capi.FLAG_INDEX_ORDER)
