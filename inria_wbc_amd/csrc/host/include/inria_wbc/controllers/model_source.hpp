@@ -33,7 +33,7 @@ namespace inria_wbc {
                 const int na = robot_->na();
                 IWBC_ASSERT(stack.nv() == robot_->nv() && stack.na() == na, "task stack and robot disagree on nv / na");
                 tasks_.clear(); avoided_frames_.clear(); avoided_r0_.clear(); names_.clear();
-                contact_frame_.clear(); contact_kp_.clear(); contact_kd_.clear(); contact_ref_.clear();
+                contact_frame_.clear(); contact_kp_.clear(); contact_kd_.clear(); contact_ref_.clear(); contact_names_.clear();
                 std::vector<size_t> av_begin;
                 int off = 0;
                 bool bounds = false;
@@ -132,8 +132,11 @@ namespace inria_wbc {
                     if (!posture_user_.empty()) std::copy(posture_user_.begin(), posture_user_.end(), one.begin() + posture_ref);
                 }
                 for (size_t c = 0; c < contacts.size(); ++c) {
+                    contact_names_.push_back(contacts[c].first);
                     auto v = robot_->framePosition(q0_.data(), contact_frame_[c]).to_vector();
                     std::copy(v.begin(), v.end(), one.begin() + contact_ref_[c]);
+                    auto it = named_.find(contacts[c].first);
+                    if (it != named_.end()) std::copy(it->second.begin(), it->second.end(), one.begin() + contact_ref_[c]);
                 }
                 ref_.assign((size_t)batch_ * nref_, 0.0);
                 for (int i = 0; i < batch_; ++i) std::copy(one.begin(), one.end(), ref_.begin() + (size_t)i * nref_);
@@ -213,6 +216,15 @@ namespace inria_wbc {
                     if (names_[i] == name && tasks_[i].kind == WBCQP_T_SE3) return std::vector<double>(ref_.begin() + tasks_[i].ref, ref_.begin() + tasks_[i].ref + 12);
                 IWBC_ERROR("Task [", name, "] not found");
             }
+            // PosTracker::set_contact_se3_ref (pos_tracker.cpp:227-232): kept for contacts that are currently removed too
+            void set_contact_se3_ref(const std::string& name, const std::vector<double>& pose) override
+            {
+                IWBC_ASSERT(pose.size() == 12, "a contact reference holds 12 numbers");
+                named_[name] = pose;
+                for (size_t c = 0; c < contact_names_.size(); ++c)
+                    if (contact_names_[c] == name)
+                        for (int i = 0; i < batch_; ++i) std::copy(pose.begin(), pose.end(), ref_.begin() + (size_t)i * nref_ + contact_ref_[c]);
+            }
             void set_posture_ref(const std::vector<double>& q_actuated) override
             {
                 IWBC_ASSERT((int)q_actuated.size() == robot_->na(), "the posture reference holds na entries");
@@ -234,7 +246,7 @@ namespace inria_wbc {
             std::vector<double> q0_, ref_, posture_user_;
             wbcqp_handle* handle_ = nullptr;
             std::vector<wbcqp_task> tasks_;
-            std::vector<std::string> names_;
+            std::vector<std::string> names_, contact_names_;
             std::vector<int32_t> avoided_frames_, contact_frame_, contact_ref_;
             std::vector<double> avoided_r0_, contact_kp_, contact_kd_;
             std::map<std::string, std::vector<double>> named_;

@@ -94,6 +94,14 @@ namespace inria_wbc {
                 se3_refs_[task_name] = sample;
                 if (source_ && source_->handles_references()) source_->set_se3_ref(task_name, sample);
             }
+            bool has_task(const std::string& str) const { return full_stack_.has_task(str); }
+            bool has_contact(const std::string& str) const { return full_stack_.contact_index(str) >= 0; }
+            void set_contact_se3_ref(const std::vector<double>& pose, const std::string& contact_name)
+            {
+                IWBC_ASSERT(has_contact(contact_name), "Contact [", contact_name, "] not found");
+                IWBC_ASSERT(source_ && source_->handles_references(), "set_contact_se3_ref needs a source that holds the references (CONTROLLER.model)");
+                source_->set_contact_se3_ref(contact_name, pose);
+            }
             const std::vector<double>& get_com_ref() const { return com_init_; }
             // PosTracker::get_se3_ref (pos_tracker.cpp:211-218): the task's current reference placement, 12 numbers in
             // SE3ToVector order (translation, rotation column-major)

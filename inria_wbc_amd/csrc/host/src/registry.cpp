@@ -1,7 +1,8 @@
-// Static registrations under the reference's string keys (pos_tracker.cpp:38, move_com.cpp:6, cartesian.cpp:6, cartesian_traj.cpp:6).
+// Static registrations under the reference's string keys (pos_tracker.cpp:38, move_com.cpp:6, cartesian.cpp:6, cartesian_traj.cpp:6, walk_on_spot.cpp:7).
 #include <inria_wbc/behaviors/generic/cartesian.hpp>
 #include <inria_wbc/behaviors/generic/cartesian_traj.hpp>
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
+#include <inria_wbc/behaviors/humanoid/walk_on_spot.hpp>
 #include <inria_wbc/controllers/pos_tracker.hpp>
 
 namespace inria_wbc {
@@ -15,6 +16,7 @@ namespace inria_wbc {
         }
         namespace humanoid {
             static Register<MoveCom> __talos_move_com("humanoid::move_com");
+            static Register<WalkOnSpot> __walk_on_spot("humanoid::walk-on-spot");
         }
     } // namespace behaviors
 } // namespace inria_wbc

@@ -11,6 +11,7 @@
 
 #include <inria_wbc/behaviors/generic/cartesian.hpp>
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
+#include <inria_wbc/behaviors/humanoid/walk_on_spot.hpp>
 #include <inria_wbc/controllers/file_source.hpp>
 #include <inria_wbc/utils/timer.hpp>
 

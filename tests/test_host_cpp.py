@@ -195,3 +195,86 @@ def test_qp_timer_test_franka_cartesian_traj_files(host_build, oracle_mod, tmp_p
             step = 1
     assert max(visited) == n_samples - 1 and visited[-1] < n_samples - 1  # went to the end and is on its way back
     assert np.abs(q[0] - oq[0]).max() < 1e-8, np.abs(q[0] - oq[0]).max()
+
+
+@pytest.mark.gpu
+def test_qp_timer_test_walk_on_spot_changes_the_qp_mid_run(host_build, oracle_mod, tmp_path):
+    """humanoid::walk-on-spot (etc/talos/walk_on_spot.yaml) on the Talos-like model: the CoM goes over the right foot, the left
+    contact is removed (n 74 -> 62), the foot is lifted 0.1 m and put down, the contact comes back (SURVEY 3.4:
+    walk_on_spot.cpp:165-184, pos_tracker.cpp:246-263).  The state after 2000 and 3100 ticks is checked against the loop of the
+    three oracles driven by the same state machine, and against the physics: the foot is up, then down again, the support foot
+    never moves."""
+    from inria_wbc_amd import model as mdl, structure, trajs
+    from oracle import rbd
+    m = mdl.talos_like()
+    full = (structure.talos_structure(), mdl.talos_stack())
+    ss = (structure.talos_structure(single_support=True), [n for n in mdl.talos_stack() if n["name"] != "contact_lfoot"])
+    maps = {True: (full[0], mdl.build_taskmap(m, *full)), False: (ss[0], mdl.build_taskmap(m, *ss))}
+    lf, rf = m.frame("leg_left_6_joint"), m.frame("leg_right_6_joint")
+    Rf0, pf0 = m.frame_placements(m.q0)
+    com0 = m.com(m.q0)
+    dt, T = 1e-3, 1.0
+    n = int(np.floor(T / dt))
+    lf_low, rf_low = (Rf0[lf], pf0[lf]), (Rf0[rf], pf0[rf])
+    up = np.array([0.0, 0.0, 0.1])
+    com_rf, com_lf = np.array([pf0[rf][0], pf0[rf][1], com0[2]]), np.array([pf0[lf][0], pf0[lf][1], com0[2]])
+    const = lambda Rp: [mdl.se3_ref(*Rp)] * n
+    move = lambda a, b: [mdl.se3_ref(R, p) for R, p in zip(*trajs.min_jerk_se3(a[0], a[1], b[0], b[1], dt, T)[:2])]
+    mj = lambda a, b: list(trajs.min_jerk_trajectory(a, b, dt, T, 0))
+    lf_high = (lf_low[0], lf_low[1] + up)
+    # phases INIT, LIFT_UP_LF, LIFT_DOWN_LF, MOVE_COM_LEFT: (lf, rf, com, both feet in contact at the START of the tick)
+    phases = [(const(lf_low), const(rf_low), mj(com0, com_rf)), (move(lf_low, lf_high), const(rf_low), [com_rf] * n),
+              (move(lf_high, lf_low), const(rf_low), [com_rf] * n), (const(lf_low), const(rf_low), mj(com_rf, com_lf))]
+    w = structure.talos_structure().default_weights.copy()
+    w[structure.talos_structure().task_names.index("momentum")] = 0.0  # customize_task_weights
+
+    def oracle_loop(n_ticks):
+        both = True
+        s = mdl.sample_states(m, maps[True][1], 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+        oq, ov = s["q"], s["v"]
+        named = {}
+        for k in range(n_ticks):
+            ph, t = divmod(k, n)
+            if ph == 1 and t == 0:
+                both = False  # remove_contact("contact_lfoot")
+            if ph == 2 and t == n - 1:
+                both = True   # add_contact("contact_lfoot")
+            st, tm = maps[both]
+            named.update(lf=phases[ph][0][t], rf=phases[ph][1][t], com=phases[ph][2][t], contact_lfoot=phases[ph][0][t], contact_rfoot=phases[ph][1][t])
+            ref = mdl.sample_states(m, tm, 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)["ref"]
+            for b in tm.blocks:
+                if b.name in ("lf", "rf"):
+                    ref[0, b.ref:b.ref + 24] = 0.0
+                    ref[0, b.ref:b.ref + 12] = named[b.name]
+                elif b.kind == mdl.T_COM:
+                    ref[0, b.ref:b.ref + 9] = 0.0
+                    ref[0, b.ref:b.ref + 3] = named["com"]
+            cnames = ["contact_lfoot", "contact_rfoot"] if both else ["contact_rfoot"]
+            for c, nm in enumerate(cnames):
+                ref[0, tm.contact_ref[c]:tm.contact_ref[c] + 12] = named[nm]
+            rows = rbd.task_rows(m, tm, st, oq, ov, ref)
+            ww = w if both else w[[i for i, nm in enumerate(maps[True][0].task_names) if nm in st.task_names]]
+            oo = oracle_mod.tick_batch(st, dict(rows, tlb=-m.tau_max[None], tub=m.tau_max[None], w=ww[None]))
+            assert oo["status"][0] == 0, (k, oo["status"])
+            nxt = oracle_mod.integrate(True, dt, oq, ov, oo["x"][:, :st.nv])
+            oq, ov = nxt["q_next"], nxt["v_next"]
+        return oq[0]
+
+    results = {}
+    for n_ticks in (2000, 3100):
+        q_path = str(tmp_path / ("q%d.bin" % n_ticks))
+        r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/talos/pos_tracker_model.yaml"),
+                            os.path.join(ROOT, "configs/talos/walk_on_spot.yaml"), "-", str(n_ticks), str(tmp_path / "tau.bin"), "0", q_path],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+        q = np.fromfile(q_path, dtype=np.float64).reshape(8, m.nq)
+        assert all(np.array_equal(q[0], q[i]) for i in range(1, 8))
+        results[n_ticks] = q[0]
+        oq = oracle_loop(n_ticks)
+        assert np.abs(q[0] - oq).max() < 1e-6, (n_ticks, np.abs(q[0] - oq).max())
+    p_up = m.frame_placements(results[2000])[1]
+    p_down = m.frame_placements(results[3100])[1]
+    assert p_up[lf][2] - pf0[lf][2] > 0.05, p_up[lf][2] - pf0[lf][2]       # the left foot is up (no feed-forward in these references: it lags)
+    assert abs(p_down[lf][2] - pf0[lf][2]) < 0.03                          # and (nearly: 0.1 s after the contact came back) down again
+    assert np.abs(p_up[rf] - pf0[rf]).max() < 2e-3 and np.abs(p_down[rf] - pf0[rf]).max() < 2e-3  # the support foot stays
+    assert abs(m.com(results[2000])[1] - pf0[rf][1]) < 0.02                # the CoM is over the support foot

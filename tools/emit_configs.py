@@ -110,6 +110,10 @@ def emit_model_files():
         f.write("# (a parsed tree, see robots/robot_wrapper.hpp), `frames` / `ref_config` / `tasks` as in talos_pos_tracker.yaml\n")
         f.write("CONTROLLER:\n  name: pos-tracker\n  solver: hip-batched\n  base_path: .\n  model: talos_like.model.yaml\n  frames: frames.yaml\n")
         f.write("  ref_config: inria_start\n  tasks: tasks.yaml\n  dt: 0.001\n  floating_base: true\n  closed_loop: false\n  verbose: false\n  batch: 8\n")
+    with open(os.path.join(d, "walk_on_spot.yaml"), "w") as f:
+        f.write("# BEHAVIOR tree of the walk on the spot (schema and values of inria_wbc's etc/talos/walk_on_spot.yaml)\n")
+        f.write("BEHAVIOR:\n  name: humanoid::walk-on-spot\n  traj_com_duration: 1\n  traj_foot_duration: 1\n  step_height: 0.1\n")
+        f.write("  customize_task_weights:\n    momentum: 0.0\n")
 
 
 def emit_franka_model_files():
