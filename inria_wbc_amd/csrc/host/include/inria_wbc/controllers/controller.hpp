@@ -184,10 +184,14 @@ namespace inria_wbc {
                 const bool whole_tick = source_->handles_references();
                 if (whole_tick) {
                     // rows, QP and integration in one trip to the device: only the state and the references go up, the solution
-                    // and the integrated state come back (plus this tick's rows, which cost() reads)
+                    // and the integrated state come back.  The rows stay on the device; cost() fetches them when somebody asks.
                     wbcqp_tick_io io{};
                     io.state = {q.data.data(), dq.data.data(), source_->reference_data()};
                     io.rows = in;
+                    io.rows.M = io.rows.h = io.rows.A = io.rows.b1 = io.rows.Ac = io.rows.bc = io.rows.blb = io.rows.bub = nullptr;
+                    last_q_ = q;
+                    last_v_ = dq;
+                    rows_valid_ = false;
                     io.out = out;
                     io.q_next = qnew.data.data();
                     io.v_next = vnew.data.data();
@@ -198,6 +202,7 @@ namespace inria_wbc {
                 else {
                     int rc = wbcqp_solve_batch_host(handle_, _slot(), B, &in, &out);
                     if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_solve_batch_host failed: ", wbcqp_last_error(handle_));
+                    rows_valid_ = true;
                 }
                 for (int i = 0; i < B; ++i) {
                     if (status_[i] != WBCQP_HQP_OPTIMAL) {
@@ -250,8 +255,19 @@ namespace inria_wbc {
             std::vector<std::string> activated_contacts_, all_contacts_;
             std::unordered_map<std::string, MatrixXd> activated_contacts_forces_;
 
+            // the rows of the last tick on the host, for cost(): fetched on demand when the tick computed them on the device
+            void _ensure_rows() const
+            {
+                if (rows_valid_ || !source_ || in_.batch == 0) return;
+                auto self = const_cast<Controller*>(this);
+                self->source_->compute(t_ - dt_, last_q_, last_v_, _stack(), _layout(), self->in_);
+                self->rows_valid_ = true;
+            }
+
             std::shared_ptr<ProblemSource> source_;
             TickInputs in_;
+            MatrixXd last_q_, last_v_;
+            bool rows_valid_ = false;
             wbcqp_handle* handle_ = nullptr; // the reference's solver_ (controller.hpp:224)
         };
 

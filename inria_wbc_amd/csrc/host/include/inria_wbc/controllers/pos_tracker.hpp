@@ -117,6 +117,7 @@ namespace inria_wbc {
                 // |A ddq - b| of the first instance (controller.hpp:148-152)
                 const auto& t = stack_.task(task_name);
                 if (t.type == "posture" || in_.batch == 0) return 0.0;
+                _ensure_rows();
                 const int nv = stack_.nv();
                 double s = 0.0;
                 for (int r = 0; r < t.rows; ++r) {

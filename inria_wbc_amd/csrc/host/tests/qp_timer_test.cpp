@@ -50,6 +50,11 @@ int main(int argc, char** argv)
             timer.report(std::cout, it++, 1);
         }
         std::cout << "instances per tick: " << controller->batch_size() << std::endl;
+        if (auto pt = std::dynamic_pointer_cast<controllers::PosTracker>(controller))
+            if (pt->has_task("com")) {
+                std::cout.precision(17);
+                std::cout << "cost com: " << pt->cost("com") << std::endl; // |A ddq - b| of the CoM rows, last tick (controller.hpp:148-152)
+            }
         if (argc > 5) {
             std::ofstream f(argv[5], std::ios::binary);
             const auto& tau = controller->tau();

@@ -100,6 +100,13 @@ def test_qp_timer_test_closed_loop_on_the_model(host_build, oracle_mod, tmp_path
         oq, ov = nxt["q_next"], nxt["v_next"]
     assert np.abs(q[0] - oq[0]).max() < 1e-8, np.abs(q[0] - oq[0]).max()
     assert np.abs(tau[0] - oo["tau"][0]).max() < 1e-6 * max(1.0, np.abs(oo["tau"]).max())
+    # Controller::cost("com") = |A ddq - b| over the CoM rows of the last tick: the rows stayed on the device during the loop and
+    # are fetched when cost() is asked for
+    cr = np.where(st.dense_row_task == st.task_names.index("com"))[0]
+    A = rows["A"][0].reshape(st.n_dense, st.nv)[cr]
+    want = np.linalg.norm(A @ oo["x"][0, :st.nv] - rows["b1"][0, cr])
+    got = float([ln for ln in r.stdout.splitlines() if ln.startswith("cost com:")][0].split(":")[1])
+    assert abs(got - want) < 1e-6 * max(1.0, want), (got, want)
 
 
 @pytest.mark.gpu
