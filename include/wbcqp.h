@@ -278,7 +278,8 @@ typedef struct {
 } wbcqp_state;
 
 /* Binds a tree and its task bindings to a slot that already holds the matching structure (same nv, na, nc, n_dense,
- * n_sel, n_bound). */
+ * n_sel, n_bound).  A later wbcqp_set_structure on the slot drops the model with the old structure: bind it again (a
+ * contact added or removed changes both, pos_tracker.cpp:246-263). */
 int wbcqp_set_model(wbcqp_handle* handle, int slot, const wbcqp_model* model, const wbcqp_taskmap* map);
 /* Writes the M, h, A, b1, Ac, bc, blb, bub arrays of `rows` (DEVICE pointers, the layout wbcqp_solve_batch reads; tlb, tub
  * and w are not touched: constant limits and weights) for `batch` instances.  Asynchronous on `stream`. */
