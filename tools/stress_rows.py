@@ -11,16 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=60)
-    args = ap.parse_args()
+def run(n, tol=1e-9):
     from inria_wbc_amd import capi
     from inria_wbc_amd import model as mdl
     from oracle import rbd
     h = capi.Handle(0, capi.F64)
     worst = {}
-    for k in range(args.n):
+    for k in range(n):
         rng = np.random.default_rng(1000 + k)
         fb = bool(rng.integers(0, 2))
         nb = int(rng.integers(3, 46 if fb else 62))
@@ -43,9 +40,17 @@ def main():
             if ora[f].size:
                 e = float(np.abs(dev[f] - ora[f]).max() / max(1.0, np.abs(ora[f]).max()))
                 worst[f] = max(worst.get(f, 0.0), e)
-                assert np.isfinite(dev[f]).all() and e < 1e-9, (k, f, e, nb, fb)
-    print("cases %d, worst relative differences:" % args.n, {f: "%.1e" % e for f, e in worst.items()})
+                assert np.isfinite(dev[f]).all() and e < tol, (k, f, e, nb, fb)
     h.close()
+    return worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=60)
+    args = ap.parse_args()
+    worst = run(args.n)
+    print("cases %d, worst relative differences:" % args.n, {f: "%.1e" % e for f, e in worst.items()})
 
 
 if __name__ == "__main__":
