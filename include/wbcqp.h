@@ -265,7 +265,9 @@ typedef struct {
     const int32_t* contact_frame;   /* [n_contact] */
     const double* contact_kp;       /* [n_contact] (tasks.cpp:359-360) */
     const double* contact_kd;
-    const int32_t* contact_ref;     /* [n_contact] offset of the 12-number reference placement (tasks.cpp:361-362) */
+    const int32_t* contact_ref;     /* [n_contact] offset of the contact motion task's reference, 24 numbers like an SE3 task:
+                                       placement 12 (tasks.cpp:361-362 sets it), velocity 6, acceleration 6 (zero unless a
+                                       behaviour moves the contact: PosTracker::set_contact_se3_ref(sample), pos_tracker.cpp:240-244) */
     int32_t bounds;                 /* 1: the structure's n_bound = na joint-bounds rows are computed (tasks.cpp:274-300) */
     double dt;                      /* CONTROLLER.dt */
     int32_t nref;                   /* reference doubles per instance */

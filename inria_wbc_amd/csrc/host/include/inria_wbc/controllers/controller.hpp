@@ -85,7 +85,7 @@ namespace inria_wbc {
             virtual void set_se3_ref(const std::string&, const TrajectorySample&) {}
             virtual void set_posture_ref(const std::vector<double>&) {}
             virtual std::vector<double> get_se3_ref(const std::string&) const { return {}; } // 12 numbers, SE3ToVector order
-            virtual void set_contact_se3_ref(const std::string&, const std::vector<double>&) {}  // 12 numbers
+            virtual void set_contact_se3_ref(const std::string&, const std::vector<double>&) {}  // 12 numbers, or 24 with derivatives
             virtual const double* reference_data() const { return nullptr; }                   // [batch][nref] for wbcqp_tick_host
             virtual void fill_limits(const wbcqp_layout&, TickInputs&) const {}                // constant tlb / tub
         };

@@ -105,7 +105,7 @@ namespace inria_wbc {
                     contact_kp_.push_back(ckp[c]);
                     contact_kd_.push_back(2.0 * std::sqrt(ckp[c])); // tasks.cpp:360
                     contact_ref_.push_back(off);
-                    off += 12;
+                    off += 24; // a full sample, like an SE3 task
                 }
                 nref_ = off;
                 // references of a freshly constructed controller: every frame where it is at q0 (tasks.cpp:64-80,361), the CoM
@@ -217,9 +217,11 @@ namespace inria_wbc {
                 IWBC_ERROR("Task [", name, "] not found");
             }
             // PosTracker::set_contact_se3_ref (pos_tracker.cpp:227-232): kept for contacts that are currently removed too
-            void set_contact_se3_ref(const std::string& name, const std::vector<double>& pose) override
+            void set_contact_se3_ref(const std::string& name, const std::vector<double>& sample) override
             {
-                IWBC_ASSERT(pose.size() == 12, "a contact reference holds 12 numbers");
+                IWBC_ASSERT(sample.size() == 12 || sample.size() == 24, "a contact reference holds 12 numbers (placement) or 24 (with velocity and acceleration)");
+                std::vector<double> pose(sample);
+                pose.resize(24, 0.0); // to_sample(SE3): zero derivatives (pos_tracker.cpp:227-232)
                 named_[name] = pose;
                 for (size_t c = 0; c < contact_names_.size(); ++c)
                     if (contact_names_[c] == name)

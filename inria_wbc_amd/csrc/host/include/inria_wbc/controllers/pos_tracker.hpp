@@ -102,6 +102,15 @@ namespace inria_wbc {
                 IWBC_ASSERT(source_ && source_->handles_references(), "set_contact_se3_ref needs a source that holds the references (CONTROLLER.model)");
                 source_->set_contact_se3_ref(contact_name, pose);
             }
+            // the sample form (pos_tracker.cpp:240-244): the contact's motion task follows pose, velocity and acceleration
+            void set_contact_se3_ref(const TrajectorySample& sample, const std::string& contact_name)
+            {
+                IWBC_ASSERT(sample.pos.size() == 12 && sample.vel.size() == 6 && sample.acc.size() == 6, "an SE3 sample holds 12 + 6 + 6 numbers");
+                std::vector<double> r(sample.pos);
+                r.insert(r.end(), sample.vel.begin(), sample.vel.end());
+                r.insert(r.end(), sample.acc.begin(), sample.acc.end());
+                set_contact_se3_ref(r, contact_name);
+            }
             const std::vector<double>& get_com_ref() const { return com_init_; }
             // PosTracker::get_se3_ref (pos_tracker.cpp:211-218): the task's current reference placement, 12 numbers in
             // SE3ToVector order (translation, rotation column-major)

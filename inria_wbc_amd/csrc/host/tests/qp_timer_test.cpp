@@ -10,7 +10,9 @@
 #include <iostream>
 
 #include <inria_wbc/behaviors/generic/cartesian.hpp>
+#include <inria_wbc/behaviors/humanoid/clapping.hpp>
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
+#include <inria_wbc/behaviors/humanoid/move_feet.hpp>
 #include <inria_wbc/behaviors/humanoid/walk_on_spot.hpp>
 #include <inria_wbc/controllers/file_source.hpp>
 #include <inria_wbc/utils/timer.hpp>

@@ -695,9 +695,9 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     for (int c = 0; c < tm->n_contact; ++c) {
         const int f = tm->contact_frame[c];
         if (!frame_ok(f)) return fail(h, WBCQP_ERR_INVALID, "contact frame does not exist");
-        if (tm->contact_ref[c] < 0 || tm->contact_ref[c] + 12 > tm->nref) return fail(h, WBCQP_ERR_INVALID, "a contact reference lies outside the reference vector");
+        if (tm->contact_ref[c] < 0 || tm->contact_ref[c] + 24 > tm->nref) return fail(h, WBCQP_ERR_INVALID, "a contact reference lies outside the reference vector");
         law_body.push_back(md->frame_body[f]); law_mask.push_back(63); law_row.push_back(0); law_ref.push_back(tm->contact_ref[c]);
-        law_va.push_back(0); law_contact.push_back(c); law_kp.push_back(tm->contact_kp[c]); law_kd.push_back(tm->contact_kd[c]);
+        law_va.push_back(1); law_contact.push_back(c); law_kp.push_back(tm->contact_kp[c]); law_kd.push_back(tm->contact_kd[c]);
         law_place.insert(law_place.end(), md->frame_placement + 12 * f, md->frame_placement + 12 * f + 12);
     }
     if ((int)law_body.size() > kWave || (int)blk_kind.size() > kWave || (int)scf_frame.size() > kWave)

@@ -282,7 +282,7 @@ def build_taskmap(model: Model, st: Structure, stack: Sequence[dict], dt: float 
     cref = []
     for _ in contacts:
         cref.append(off)
-        off += 12
+        off += 24  # a full sample: placement 12, velocity 6, acceleration 6
     ckp = np.array([float(c["kp"]) for c in contacts], dtype=np.float64)
     tm = TaskMap(blocks=blocks, sel_col=st.sel_col.copy(), posture_kp=pkp, posture_kd=2.0 * np.sqrt(pkp), posture_ref=posture_ref,
                  contact_frame=np.array([model.frame(c["joint"]) for c in contacts], dtype=np.int32),

@@ -656,12 +656,13 @@ void wbco_task_rows(const wbco_model* m, const wbco_taskmap* map, const double* 
     }
     /* force regularisation rows: tsid Contact6d force regularisation task has a zero reference force */
     for (int c = 0; c < 6 * map->ncontact; ++c) b1[row++] = 0.0;
-    /* contacts: Contact6d::computeMotionTask = TaskSE3Equality in the local frame, all six rows, zero reference velocity
+    /* contacts: Contact6d::computeMotionTask = TaskSE3Equality in the local frame, all six rows; the reference is a full sample
+     * (Contact6dExt::setReference, contact-6d-ext.hpp:18-21), velocity and acceleration zero unless a behaviour sets them
      * (tasks.cpp:359-362) */
     for (int c = 0; c < map->ncontact; ++c) {
         const int f = map->contact_frame[c];
         double rhs[6];
-        se3_law(T.oMf + 12 * f, T.vf + 6 * f, T.af + 6 * f, ref + map->contact_ref[c], 0, map->contact_kp[c], map->contact_kd[c], rhs);
+        se3_law(T.oMf + 12 * f, T.vf + 6 * f, T.af + 6 * f, ref + map->contact_ref[c], 1, map->contact_kp[c], map->contact_kd[c], rhs);
         memcpy(Ac + (size_t)c * 6 * nv, T.Jl + (size_t)f * 6 * nv, sizeof(double) * 6 * nv);
         memcpy(bc + 6 * c, rhs, sizeof rhs);
     }

@@ -70,7 +70,7 @@ typedef struct {
     const int* contact_frame;  /* [ncontact] */
     const double* contact_kp;  /* [ncontact] */
     const double* contact_kd;
-    const int* contact_ref;    /* [ncontact] offset of the 12-number reference placement */
+    const int* contact_ref;    /* [ncontact] offset of the 24-number reference sample */
     int n_bound;               /* 0 or na */
     double dt;                 /* CONTROLLER.dt (tasks.cpp:283) */
     int nref;                  /* reference doubles per instance */
@@ -82,7 +82,8 @@ typedef struct {
  *   CoM:       pos 3, vel 3, acc 3                                                          ->  9
  *   momentum:  reference momentum 6, its derivative 6 (TrajectorySample vel / acc)          -> 12
  *   posture:   na reference positions (vel = acc = 0: tasks.cpp:217 sets the value only)    -> na
- *   contact:   12 = reference placement (vel = acc = 0, tasks.cpp:361-362)                  -> 12 */
+ *   contact:   like SE3: placement 12 (tasks.cpp:361-362), vel 6, acc 6 (zero unless a behaviour
+ *              moves the contact, pos_tracker.cpp:240-244)                                  -> 24 */
 
 typedef struct {
     double* M;     /* [nv][nv] */

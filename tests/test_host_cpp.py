@@ -285,3 +285,89 @@ def test_qp_timer_test_walk_on_spot_changes_the_qp_mid_run(host_build, oracle_mo
     assert abs(p_down[lf][2] - pf0[lf][2]) < 0.03                          # and (nearly: 0.1 s after the contact came back) down again
     assert np.abs(p_up[rf] - pf0[rf]).max() < 2e-3 and np.abs(p_down[rf] - pf0[rf]).max() < 2e-3  # the support foot stays
     assert abs(m.com(results[2000])[1] - pf0[rf][1]) < 0.02                # the CoM is over the support foot
+
+
+def _talos_model_loop(oracle_mod, n_ticks, fill_ref):
+    """The oracle loop of the Talos-like model with the full stack: fill_ref(k, ref, tm) writes the references of tick k."""
+    from inria_wbc_amd import model as mdl, structure
+    from oracle import rbd
+    m = mdl.talos_like()
+    st = structure.talos_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    s = mdl.sample_states(m, tm, 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+    oq, ov, ref = s["q"], s["v"], s["ref"]
+    for k in range(n_ticks):
+        fill_ref(k, ref, tm)
+        rows = rbd.task_rows(m, tm, st, oq, ov, ref)
+        oo = oracle_mod.tick_batch(st, dict(rows, tlb=-m.tau_max[None], tub=m.tau_max[None], w=st.default_weights[None]))
+        assert oo["status"][0] == 0, (k, oo["status"])
+        nxt = oracle_mod.integrate(True, tm.dt, oq, ov, oo["x"][:, :st.nv])
+        oq, ov = nxt["q_next"], nxt["v_next"]
+    return m, tm, oq[0]
+
+
+def _run_model_harness(host_build, tmp_path, behavior_yaml, n_ticks):
+    q_path = str(tmp_path / "q.bin")
+    r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/talos/pos_tracker_model.yaml"), behavior_yaml, "-", str(n_ticks),
+                        str(tmp_path / "tau.bin"), "0", q_path], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    q = np.fromfile(q_path, dtype=np.float64).reshape(8, -1)
+    assert all(np.array_equal(q[0], q[i]) for i in range(1, 8))
+    return q[0]
+
+
+@pytest.mark.gpu
+def test_qp_timer_test_move_feet_moves_the_contacts(host_build, oracle_mod, tmp_path):
+    """humanoid::move-feet (etc/talos/move_feet.yaml): the feet tasks AND the contacts' motion tasks follow the same min-jerk
+    sample (pose, velocity, acceleration): PosTracker::set_contact_se3_ref(sample, name), pos_tracker.cpp:240-244."""
+    from inria_wbc_amd import model as mdl, trajs
+    n_ticks = 700
+    q = _run_model_harness(host_build, tmp_path, os.path.join(ROOT, "configs/talos/move_feet.yaml"), n_ticks)
+    m0 = mdl.talos_like()
+    Rf0, pf0 = m0.frame_placements(m0.q0)
+    streams = {nm: trajs.cartesian_stream(Rf0[m0.frame(fr)], pf0[m0.frame(fr)], [0.05, 0.05, 0.05], 1e-3, 4.0, loop=False, rel_rpy=[0.0, 0.0, 0.0])
+               for nm, fr in (("lf", "leg_left_6_joint"), ("rf", "leg_right_6_joint"))}
+
+    def fill(k, ref, tm):
+        for b in tm.blocks:
+            if b.name in streams:
+                Rs, ps, d1, d2 = streams[b.name]
+                sample = np.concatenate([mdl.se3_ref(Rs[k], ps[k]), d1[k], d2[k]])
+                ref[0, b.ref:b.ref + 24] = sample
+                c = 0 if b.name == "lf" else 1
+                ref[0, tm.contact_ref[c]:tm.contact_ref[c] + 24] = sample
+
+    m, tm, oq = _talos_model_loop(oracle_mod, n_ticks, fill)
+    assert np.abs(q - oq).max() < 1e-7, np.abs(q - oq).max()
+    lf = m.frame("leg_left_6_joint")
+    moved = m.frame_placements(q)[1][lf] - pf0[lf]
+    want = streams["lf"][1][n_ticks - 1] - pf0[lf]
+    assert np.abs(moved - want).max() < 2e-3 and want[0] > 1e-3, (moved, want)  # the contact constraint drags the foot along its sample
+
+
+@pytest.mark.gpu
+def test_qp_timer_test_clapping(host_build, oracle_mod, tmp_path):
+    """humanoid::clapping (etc/talos/clapping.yaml): both hands move along y towards each other, pose-only references."""
+    from inria_wbc_amd import model as mdl, trajs
+    n_ticks = 500
+    q = _run_model_harness(host_build, tmp_path, os.path.join(ROOT, "configs/talos/clapping.yaml"), n_ticks)
+    m0 = mdl.talos_like()
+    Rf0, pf0 = m0.frame_placements(m0.q0)
+    streams = {}
+    for nm, fr, dy in (("lh", "gripper_left_joint", -0.1), ("rh", "gripper_right_joint", 0.1)):
+        f = m0.frame(fr)
+        streams[nm] = trajs.cartesian_stream(Rf0[f], pf0[f], [0.0, dy, 0.0], 1e-3, 1.0, loop=True)
+
+    def fill(k, ref, tm):
+        for b in tm.blocks:
+            if b.name in streams:
+                Rs, ps, _, _ = streams[b.name]
+                ref[0, b.ref:b.ref + 24] = 0.0
+                ref[0, b.ref:b.ref + 12] = mdl.se3_ref(Rs[k], ps[k])
+
+    m, tm, oq = _talos_model_loop(oracle_mod, n_ticks, fill)
+    assert np.abs(q - oq).max() < 1e-7, np.abs(q - oq).max()
+    lh, rh = m.frame("gripper_left_joint"), m.frame("gripper_right_joint")
+    p = m.frame_placements(q)[1]
+    # the hands came closer: weight 10 against posture, self-collision and 1000-weight tasks, and no feed-forward -- by millimetres
+    assert (pf0[lh][1] - pf0[rh][1]) - (p[lh][1] - p[rh][1]) > 0.005

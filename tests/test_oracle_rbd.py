@@ -145,7 +145,7 @@ def _talos_setup():
 def test_taskmap_matches_structure():
     m, st, tm = _talos_setup()
     assert tm.n_dense == st.n_dense == 41 and tm.ncontact == 2 and tm.n_bound == 44
-    assert tm.nref == 8 * 24 + 9 + 12 + 44 + 24
+    assert tm.nref == 8 * 24 + 9 + 12 + 44 + 2 * 24
     m2 = mdl.franka_like()
     st2 = structure.franka_structure()
     tm2 = mdl.build_taskmap(m2, st2, mdl.franka_stack())

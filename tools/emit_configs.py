@@ -114,6 +114,14 @@ def emit_model_files():
         f.write("# BEHAVIOR tree of the walk on the spot (schema and values of inria_wbc's etc/talos/walk_on_spot.yaml)\n")
         f.write("BEHAVIOR:\n  name: humanoid::walk-on-spot\n  traj_com_duration: 1\n  traj_foot_duration: 1\n  step_height: 0.1\n")
         f.write("  customize_task_weights:\n    momentum: 0.0\n")
+    with open(os.path.join(d, "clapping.yaml"), "w") as f:
+        f.write("# BEHAVIOR tree of the clapping (schema of inria_wbc's etc/talos/clapping.yaml; motion_size sized for the Talos-like arms)\n")
+        f.write("BEHAVIOR:\n  name: humanoid::clapping\n  trajectory_duration: 1.0\n  motion_size: 0.1\n")
+    with open(os.path.join(d, "move_feet.yaml"), "w") as f:
+        f.write("# BEHAVIOR tree of the feet move (schema and values of inria_wbc's etc/talos/move_feet.yaml)\n")
+        f.write("BEHAVIOR:\n  name: humanoid::move-feet\n  task_names: [lf, rf]\n  contact_names: [contact_lfoot, contact_rfoot]\n")
+        f.write("  relative_targets_pos: [[0.05, 0.05, 0.05], [0.05, 0.05, 0.05]]\n  relative_targets_rpy: [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]\n")
+        f.write("  trajectory_duration: 4\n  loop: false\n")
 
 
 def emit_franka_model_files():
