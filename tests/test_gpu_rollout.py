@@ -151,3 +151,39 @@ def test_tick_host_equals_the_device_tick():
         assert np.array_equal(got["rows"][k], rows[k].cpu().numpy()), k
     assert np.abs(got["q_solver"][:, 6:] - got["q_next"][:, 7:]).max() == 0.0
     h.close()
+
+
+def test_tick_f32_boundary_stays_close_to_f64():
+    """BASELINE config 3's boundary (f32 arrays, f64 arithmetic inside) through the whole tick on the iCub-like robot: the f32
+    record between the rows kernel and the solve costs precision, not correctness (1e-3 relative on ddq / tau)."""
+    import torch
+    m = mdl.icub_like()
+    st = structure.icub_structure()
+    tm = mdl.build_taskmap(m, st, mdl.icub_stack())
+    B = 64
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    s = mdl.sample_states(m, tm, B, 93_000, q_noise=0.005, v_noise=0.02, ref_noise=0.005)
+    L = st.field_lengths()
+    res = {}
+    for dtype, tdt in ((capi.F64, torch.float64), (capi.F32, torch.float32)):
+        h = capi.Handle(0, dtype)
+        h.set_structure(0, st)
+        h.set_model(0, m, tm)
+        state = {k: torch.from_numpy(s[k]).to(dev).to(tdt) for k in ("q", "v", "ref")}
+        rows = {k: torch.zeros(B, L[k], dtype=tdt, device=dev) for k in capi.ROW_FIELDS}
+        rows["w"] = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev).to(tdt)
+        out = dict(x=torch.zeros(B, st.n, dtype=tdt, device=dev), tau=torch.zeros(B, st.na, dtype=tdt, device=dev),
+                   status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+        qn, vn = torch.zeros_like(state["q"]), torch.zeros_like(state["v"])
+        h.tick(0, B, state, rows, out, qn, vn, tm.dt, stream=stream)
+        torch.cuda.synchronize()
+        res[dtype] = {k: v.double().cpu().numpy() for k, v in out.items()} | {"q": qn.double().cpu().numpy()}
+        h.close()
+    a, b = res[capi.F64], res[capi.F32]
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    nv = m.nv
+    scale_dv, scale_tau = max(1.0, np.abs(a["x"][:, :nv]).max()), max(1.0, np.abs(a["tau"]).max())
+    assert np.abs(a["x"][:, :nv] - b["x"][:, :nv]).max() / scale_dv < 1e-3
+    assert np.abs(a["tau"] - b["tau"]).max() / scale_tau < 1e-3
+    assert np.abs(a["q"] - b["q"]).max() < 1e-5
