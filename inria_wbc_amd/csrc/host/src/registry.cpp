@@ -4,6 +4,7 @@
 #include <inria_wbc/behaviors/humanoid/clapping.hpp>
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
 #include <inria_wbc/behaviors/humanoid/move_feet.hpp>
+#include <inria_wbc/behaviors/humanoid/walk.hpp>
 #include <inria_wbc/behaviors/humanoid/walk_on_spot.hpp>
 #include <inria_wbc/controllers/pos_tracker.hpp>
 
@@ -20,6 +21,7 @@ namespace inria_wbc {
         namespace humanoid {
             static Register<Clapping> __talos_clapping("humanoid::clapping");
             static Register<MoveCom> __talos_move_com("humanoid::move_com");
+            static Register<Walk> __walk("humanoid::walk");
             static Register<WalkOnSpot> __walk_on_spot("humanoid::walk-on-spot");
         }
     } // namespace behaviors

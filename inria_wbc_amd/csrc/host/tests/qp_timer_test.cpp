@@ -13,6 +13,7 @@
 #include <inria_wbc/behaviors/humanoid/clapping.hpp>
 #include <inria_wbc/behaviors/humanoid/move_com.hpp>
 #include <inria_wbc/behaviors/humanoid/move_feet.hpp>
+#include <inria_wbc/behaviors/humanoid/walk.hpp>
 #include <inria_wbc/behaviors/humanoid/walk_on_spot.hpp>
 #include <inria_wbc/controllers/file_source.hpp>
 #include <inria_wbc/utils/timer.hpp>

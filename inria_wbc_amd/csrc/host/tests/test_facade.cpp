@@ -74,7 +74,7 @@ int main(int argc, char** argv)
     UTEST_CHECK(behaviors::Factory::instance().has("humanoid::move_com"));
     UTEST_CHECK(behaviors::Factory::instance().has("generic::cartesian") && behaviors::Factory::instance().has("generic::cartesian_traj"));
     UTEST_CHECK(behaviors::Factory::instance().has("humanoid::walk-on-spot") && behaviors::Factory::instance().has("humanoid::move-feet") &&
-                behaviors::Factory::instance().has("humanoid::clapping"));
+                behaviors::Factory::instance().has("humanoid::clapping") && behaviors::Factory::instance().has("humanoid::walk"));
     UTEST_CHECK_EXCEPTION(controllers::Factory::instance().create("no-such-controller", yaml::Node()), "is not in the factory");
     // ---- solver switch (pos_tracker.cpp:88-100) ----
     {

@@ -371,3 +371,121 @@ def test_qp_timer_test_clapping(host_build, oracle_mod, tmp_path):
     p = m.frame_placements(q)[1]
     # the hands came closer: weight 10 against posture, self-collision and 1000-weight tasks, and no feed-forward -- by millimetres
     assert (pf0[lh][1] - pf0[rh][1]) - (p[lh][1] - p[rh][1]) > 0.005
+
+
+@pytest.mark.gpu
+def test_qp_timer_test_walk_takes_steps(host_build, oracle_mod, tmp_path):
+    """humanoid::walk (walk.cpp:8-246) on the Talos-like model: one cycle = two steps forward plus the closing half step, eight
+    contact switches; the final state against the loop of the three oracles driven by a Python restatement of the same state
+    machine, and against the point of it: both feet and the CoM end 2 x step_length further."""
+    from inria_wbc_amd import model as mdl, structure, trajs
+    from oracle import rbd
+    Tc = Tf = 0.5
+    H, Lstep, dt = 0.05, 0.1, 1e-3
+    beh = tmp_path / "walk.yaml"
+    beh.write_text("BEHAVIOR:\n  name: humanoid::walk\n  traj_com_duration: %g\n  traj_foot_duration: %g\n  step_height: %g\n  step_length: %g\n"
+                   "  num_of_cycles: 1\n  customize_task_weights:\n    momentum: 0.0\n" % (Tc, Tf, H, Lstep))
+    m = mdl.talos_like()
+    full_st = structure.talos_structure()
+    stacks = {"both": mdl.talos_stack(), "no_l": [n for n in mdl.talos_stack() if n["name"] != "contact_lfoot"],
+              "no_r": [n for n in mdl.talos_stack() if n["name"] != "contact_rfoot"]}
+    sts = {"both": full_st, "no_l": structure.talos_structure(single_support=True), "no_r": structure.talos_structure(single_support=True)}
+    # the single-support structure of structure.py keeps the RIGHT contact; the stack without the right one has the same shape
+    maps = {k: mdl.build_taskmap(m, sts[k], stacks[k]) for k in stacks}
+    fid = {nm: m.frame(fr) for nm, fr in (("lf", "leg_left_6_joint"), ("rf", "leg_right_6_joint"), ("lh", "gripper_left_joint"), ("rh", "gripper_right_joint"))}
+    Rf0, pf0 = m.frame_placements(m.q0)
+    R = {k: Rf0[f] for k, f in fid.items()}
+    n = int(np.floor(Tc / dt))
+    const = lambda nm, p: [mdl.se3_ref(R[nm], p)] * n
+    move = lambda nm, a, b: [mdl.se3_ref(R[nm], p) for p in trajs.min_jerk_trajectory(a, b, dt, Tc, 0)]  # no rotation in this walk
+    mj = lambda a, b: list(trajs.min_jerk_trajectory(a, b, dt, Tc, 0))
+    up = np.array([0.0, 0.0, H])
+    lf_low, rf_low = pf0[fid["lf"]].copy(), pf0[fid["rf"]].copy()
+    lf_high, rf_high = lf_low + up, rf_low + up
+    com_init = m.com(m.q0).copy()
+    com_lf, com_rf = np.array([lf_low[0], lf_low[1], com_init[2]]), np.array([rf_low[0], rf_low[1], com_init[2]])
+    lh_init, rh_init = pf0[fid["lh"]].copy(), pf0[fid["rh"]].copy()
+    lh_fwd, rh_fwd = lh_init.copy(), rh_init.copy()
+    ex = np.array([1.0, 0.0, 0.0])
+    phases = []  # (name, lf, rf, com, lh, rh)
+    cycle = ["INIT", "LF_INIT", "LIFT_DOWN_LF", "MOVE_COM_LEFT", "LIFT_UP_RF", "LIFT_DOWN_RF", "MOVE_COM_RIGHT", "LIFT_UP_LF", "LIFT_DOWN_LF_FINAL",
+             "MOVE_COM_CENTER_FINAL"]
+    for c in cycle:
+        if c == "INIT":
+            phases.append((c, const("lf", lf_low), const("rf", rf_low), mj(com_init, com_rf), const("lh", lh_init), const("rh", rh_init)))
+        elif c == "LF_INIT":
+            phases.append((c, move("lf", lf_low, lf_high), const("rf", rf_low), [com_rf.copy()] * n, const("lh", lh_init), const("rh", rh_init)))
+        elif c == "LIFT_DOWN_LF":
+            diff = rf_low[0] - lf_low[0]
+            lf_low = lf_low + (diff + Lstep) * ex
+            lh_fwd = lh_init + (diff + Lstep) * ex
+            phases.append((c, move("lf", lf_high, lf_low), const("rf", rf_low), [com_rf.copy()] * n, move("lh", lh_init, lh_fwd), const("rh", rh_init)))
+            lh_init = lh_fwd
+        elif c == "MOVE_COM_LEFT":
+            com_lf = com_lf.copy(); com_lf[0] = lf_low[0]
+            phases.append((c, const("lf", lf_low), const("rf", rf_low), mj(com_rf, com_lf), const("lh", lh_init), const("rh", rh_init)))
+        elif c == "LIFT_UP_RF":
+            rf_high = rf_high.copy(); rf_high[0] = lf_low[0]
+            phases.append((c, const("lf", lf_low), move("rf", rf_low, rf_high), [com_lf.copy()] * n, const("lh", lh_init), const("rh", rh_init)))
+        elif c == "LIFT_DOWN_RF":
+            rf_low = rf_low + 2 * Lstep * ex
+            rh_fwd = rh_init + 2 * Lstep * ex
+            phases.append((c, const("lf", lf_low), move("rf", rf_high, rf_low), [com_lf.copy()] * n, const("lh", lh_init), move("rh", rh_init, rh_fwd)))
+            rh_init = rh_fwd
+        elif c == "MOVE_COM_RIGHT":
+            com_rf = com_rf.copy(); com_rf[0] = rf_low[0]
+            phases.append((c, const("lf", lf_low), const("rf", rf_low), mj(com_lf, com_rf), const("lh", lh_init), const("rh", rh_init)))
+        elif c == "LIFT_UP_LF":
+            lf_high = lf_high.copy(); lf_high[0] = rf_low[0]
+            phases.append((c, move("lf", lf_low, lf_high), const("rf", rf_low), [com_rf.copy()] * n, const("lh", lh_init), const("rh", rh_init)))
+        elif c == "LIFT_DOWN_LF_FINAL":
+            lf_low = lf_low + Lstep * ex
+            lh_fwd = lh_init + Lstep * ex
+            phases.append((c, move("lf", lf_high, lf_low), const("rf", rf_low), [com_rf.copy()] * n, move("lh", lh_init, lh_fwd), const("rh", rh_init)))
+        else:
+            com_c = com_init.copy(); com_c[:2] = (rf_low[:2] + lf_low[:2]) / 2.0
+            phases.append((c, const("lf", lf_low), const("rf", rf_low), mj(com_rf, com_c), const("lh", lh_fwd), const("rh", rh_fwd)))
+    n_ticks = len(phases) * n
+    q = _run_model_harness(host_build, tmp_path, str(beh), n_ticks)
+    w_full = full_st.default_weights.copy()
+    w_full[full_st.task_names.index("momentum")] = 0.0
+    s = mdl.sample_states(m, maps["both"], 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+    oq, ov = s["q"], s["v"]
+    mode, switches = "both", 0
+    for k in range(n_ticks):
+        ph, t = divmod(k, n)
+        name, lfp, rfp, comp, lhp, rhp = phases[ph]
+        before = mode
+        if t == 0 and name in ("LIFT_UP_LF", "LF_INIT"):
+            mode = "no_l"
+        if t == 0 and name == "LIFT_UP_RF":
+            mode = "no_r"
+        if t == n - 1 and name in ("LIFT_DOWN_LF", "LIFT_DOWN_LF_FINAL", "LIFT_DOWN_RF"):
+            mode = "both"
+        switches += mode != before
+        st, tm = sts[mode], maps[mode]
+        ref = mdl.sample_states(m, tm, 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)["ref"]
+        poses = dict(lf=lfp[t], rf=rfp[t], lh=lhp[t], rh=rhp[t])
+        for b in tm.blocks:
+            if b.name in poses:
+                ref[0, b.ref:b.ref + 24] = 0.0
+                ref[0, b.ref:b.ref + 12] = poses[b.name]
+            elif b.kind == mdl.T_COM:
+                ref[0, b.ref:b.ref + 9] = 0.0
+                ref[0, b.ref:b.ref + 3] = comp[t]
+        cnames = {"both": ["contact_lfoot", "contact_rfoot"], "no_l": ["contact_rfoot"], "no_r": ["contact_lfoot"]}[mode]
+        for c, nm in enumerate(cnames):
+            ref[0, tm.contact_ref[c]:tm.contact_ref[c] + 24] = 0.0
+            ref[0, tm.contact_ref[c]:tm.contact_ref[c] + 12] = poses["lf" if nm == "contact_lfoot" else "rf"]
+        ww = w_full if mode == "both" else np.array([w_full[full_st.task_names.index(nm)] if nm in full_st.task_names else structure.W_FORCE_FEET
+                                                      for nm in st.task_names])
+        rows = rbd.task_rows(m, tm, st, oq, ov, ref)
+        oo = oracle_mod.tick_batch(st, dict(rows, tlb=-m.tau_max[None], tub=m.tau_max[None], w=ww[None]))
+        assert oo["status"][0] == 0, (k, name, oo["status"])
+        nxt = oracle_mod.integrate(True, dt, oq, ov, oo["x"][:, :st.nv])
+        oq, ov = nxt["q_next"], nxt["v_next"]
+    assert switches == 6  # lf off/on, rf off/on, lf off/on
+    assert np.abs(q - oq[0]).max() < 1e-5, np.abs(q - oq[0]).max()
+    pf = m.frame_placements(q)[1]
+    assert abs(pf[fid["lf"]][0] - pf0[fid["lf"]][0] - 2 * Lstep) < 5e-3 and abs(pf[fid["rf"]][0] - pf0[fid["rf"]][0] - 2 * Lstep) < 5e-3
+    assert abs(m.com(q)[0] - m.com(m.q0)[0] - 2 * Lstep) < 0.02

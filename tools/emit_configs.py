@@ -114,6 +114,10 @@ def emit_model_files():
         f.write("# BEHAVIOR tree of the walk on the spot (schema and values of inria_wbc's etc/talos/walk_on_spot.yaml)\n")
         f.write("BEHAVIOR:\n  name: humanoid::walk-on-spot\n  traj_com_duration: 1\n  traj_foot_duration: 1\n  step_height: 0.1\n")
         f.write("  customize_task_weights:\n    momentum: 0.0\n")
+    with open(os.path.join(d, "walk.yaml"), "w") as f:
+        f.write("# BEHAVIOR tree of the walk (schema of inria_wbc's etc/talos/walk.yaml; two cycles instead of ten)\n")
+        f.write("BEHAVIOR:\n  name: humanoid::walk\n  traj_com_duration: 1\n  traj_foot_duration: 1\n  step_height: 0.1\n  step_length: 0.2\n")
+        f.write("  num_of_cycles: 2\n  customize_task_weights:\n    momentum: 0.0\n")
     with open(os.path.join(d, "clapping.yaml"), "w") as f:
         f.write("# BEHAVIOR tree of the clapping (schema of inria_wbc's etc/talos/clapping.yaml; motion_size sized for the Talos-like arms)\n")
         f.write("BEHAVIOR:\n  name: humanoid::clapping\n  trajectory_duration: 1.0\n  motion_size: 0.1\n")
