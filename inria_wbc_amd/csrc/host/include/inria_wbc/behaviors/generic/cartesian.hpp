@@ -1,12 +1,12 @@
 // generic::cartesian -- SE(3) reference streams for the tasks named in BEHAVIOR.task_names (BASELINE configs 1-2:
-// /root/reference/src/behaviors/generic/cartesian.cpp:8-94, /root/reference/etc/franka/cartesian_line.yaml): for every task a
-// min-jerk move from the task's current reference to it displaced by relative_targets_pos / rotated by relative_targets_rpy,
-// and back when looping; one sample (pose, velocity, acceleration) per tick goes to PosTracker::set_se3_ref.
+// /root/reference/src/behaviors/generic/cartesian.cpp:8-94, /root/reference/etc/franka/cartesian_line.yaml): each task goes
+// from its current reference to that reference displaced by relative_targets_pos / relative_targets_rpy on a min-jerk path
+// (and back when looping); pose, velocity and acceleration of the current sample go to PosTracker::set_se3_ref every tick.
 #ifndef IWBC_HIP_CARTESIAN_HPP
 #define IWBC_HIP_CARTESIAN_HPP
 
 #include <inria_wbc/behaviors/behavior.hpp>
-#include <inria_wbc/trajs/trajectory_generator.hpp>
+#include <inria_wbc/behaviors/reference_streams.hpp>
 
 namespace inria_wbc {
     namespace behaviors {
@@ -15,77 +15,45 @@ namespace inria_wbc {
             public:
                 Cartesian(const controller_ptr_t& controller, const yaml::Node& config) : Behavior(controller, config)
                 {
-                    auto tracker = std::dynamic_pointer_cast<controllers::PosTracker>(controller_);
-                    IWBC_ASSERT(tracker, "Need a PosTracker for Cartesian");
-                    auto c = IWBC_CHECK(config["BEHAVIOR"]);
-                    trajectory_duration_ = IWBC_CHECK(c["trajectory_duration"].as<double>());
-                    behavior_type_ = this->behavior_type();
-                    controller_->set_behavior_type(behavior_type_);
+                    tracker_ = std::dynamic_pointer_cast<controllers::PosTracker>(controller_);
+                    IWBC_ASSERT(tracker_, "Need a PosTracker for ", name_in_errors());
+                    const yaml::Node c = IWBC_CHECK(config["BEHAVIOR"]);
+                    const double duration = IWBC_CHECK(c["trajectory_duration"].as<double>());
                     loop_ = IWBC_CHECK(c["loop"].as<bool>());
                     task_names_ = IWBC_CHECK(c["task_names"].as<std::vector<std::string>>());
-                    auto ts = IWBC_CHECK(c["relative_targets_pos"].as<std::vector<std::vector<double>>>());
-                    auto to = IWBC_CHECK(c["relative_targets_rpy"].as<std::vector<std::vector<double>>>());
-                    if (task_names_.size() != ts.size()) IWBC_ERROR("cartesian behavior needs the same number of tasks and targets");
+                    const auto rel_pos = IWBC_CHECK(c["relative_targets_pos"].as<std::vector<std::vector<double>>>());
+                    const auto rel_rpy = IWBC_CHECK(c["relative_targets_rpy"].as<std::vector<std::vector<double>>>());
+                    if (task_names_.size() != rel_pos.size()) IWBC_ERROR(name_in_errors(), " behavior needs the same number of tasks and targets");
+                    behavior_type_ = controllers::behavior_types::FIXED_BASE;
+                    controller_->set_behavior_type(behavior_type_);
                     for (size_t i = 0; i < task_names_.size(); ++i) {
-                        const trajs::Vec task_init = tracker->get_se3_ref(task_names_[i]);
-                        trajs::Vec task_final = task_init;
-                        if (ts[i].size() == 3)
-                            for (int k = 0; k < 3; ++k) task_final[k] = ts[i][k] + task_init[k];
-                        if (i < to.size() && to[i].size() == 3) {
-                            // rot = Rz(yaw) Ry(pitch) Rx(roll); final rotation = rot * initial rotation (cartesian.cpp:35-41)
-                            const double cr = std::cos(to[i][0]), sr = std::sin(to[i][0]), cp = std::cos(to[i][1]), sp = std::sin(to[i][1]),
-                                         cy = std::cos(to[i][2]), sy = std::sin(to[i][2]);
-                            const double rot[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr,
-                                                   sy * sp * cr - cy * sr, -sp, cp * sr, cp * cr};
-                            for (int col = 0; col < 3; ++col)
-                                for (int r = 0; r < 3; ++r) {
-                                    double v = 0.0;
-                                    for (int k = 0; k < 3; ++k) v += rot[3 * r + k] * task_init[3 + 3 * col + k];
-                                    task_final[3 + 3 * col + r] = v;
-                                }
-                        }
-                        std::vector<std::vector<trajs::Vec>> tr, tr_d, tr_dd;
-                        const double dt = controller_->dt();
-                        tr.push_back(trajs::min_jerk_trajectory_se3(task_init, task_final, dt, trajectory_duration_));
-                        tr_d.push_back(trajs::min_jerk_trajectory_se3_d<trajs::d_order::FIRST>(task_init, task_final, dt, trajectory_duration_));
-                        tr_dd.push_back(trajs::min_jerk_trajectory_se3_d<trajs::d_order::SECOND>(task_init, task_final, dt, trajectory_duration_));
-                        if (loop_) {
-                            tr.push_back(trajs::min_jerk_trajectory_se3(task_final, task_init, dt, trajectory_duration_));
-                            tr_d.push_back(trajs::min_jerk_trajectory_se3_d<trajs::d_order::FIRST>(task_final, task_init, dt, trajectory_duration_));
-                            tr_dd.push_back(trajs::min_jerk_trajectory_se3_d<trajs::d_order::SECOND>(task_final, task_init, dt, trajectory_duration_));
-                        }
-                        trajectories_.push_back(tr);
-                        trajectories_d_.push_back(tr_d);
-                        trajectories_dd_.push_back(tr_dd);
+                        const trajs::Vec start = tracker_->get_se3_ref(task_names_[i]);
+                        const trajs::Vec goal = displaced(start, rel_pos[i], i < rel_rpy.size() ? rel_rpy[i] : std::vector<double>());
+                        Se3Stream s(controller_->dt(), true);
+                        s.move(start, goal, duration);
+                        if (loop_) s.move(goal, start, duration);
+                        streams_.push_back(s);
                     }
                 }
                 void update(const controllers::SensorData& sensor_data = {}) override
                 {
-                    auto tracker = std::static_pointer_cast<controllers::PosTracker>(controller_);
-                    for (size_t i = 0; i < task_names_.size(); ++i)
-                        if (traj_selector_ < trajectories_[i].size()) {
-                            controllers::TrajectorySample sample_ref(0);
-                            sample_ref.pos = trajectories_[i][traj_selector_][time_];
-                            sample_ref.vel = trajectories_d_[i][traj_selector_][time_];
-                            sample_ref.acc = trajectories_dd_[i][traj_selector_][time_];
-                            tracker->set_se3_ref(sample_ref, task_names_[i]);
-                        }
+                    const size_t n_seg = streams_.empty() ? 0 : streams_[0].segments();
+                    if (!cursor_.finished(n_seg))
+                        for (size_t i = 0; i < streams_.size(); ++i) apply(i, streams_[i].sample(cursor_.segment, cursor_.tick));
                     controller_->update(sensor_data);
-                    ++time_;
-                    if (!trajectories_.empty() && traj_selector_ < trajectories_[0].size() && time_ == trajectories_[0][traj_selector_].size()) {
-                        time_ = 0;
-                        ++traj_selector_;
-                        if (loop_) traj_selector_ = traj_selector_ % trajectories_[0].size();
-                    }
+                    if (!cursor_.finished(n_seg)) cursor_.step(streams_[0].length(cursor_.segment), n_seg, loop_);
                 }
-                std::string behavior_type() const override { return controllers::behavior_types::FIXED_BASE; }
+                std::string behavior_type() const override { return behavior_type_; }
 
-            private:
-                size_t time_ = 0, traj_selector_ = 0;
-                double trajectory_duration_ = 0.0;
-                bool loop_ = false;
+            protected:
+                virtual const char* name_in_errors() const { return "cartesian"; }
+                virtual void apply(size_t i, const controllers::TrajectorySample& sample) { tracker_->set_se3_ref(sample, task_names_[i]); }
+
+                std::shared_ptr<controllers::PosTracker> tracker_;
                 std::vector<std::string> task_names_;
-                std::vector<std::vector<std::vector<trajs::Vec>>> trajectories_, trajectories_d_, trajectories_dd_;
+                std::vector<Se3Stream> streams_;
+                SegmentCursor cursor_;
+                bool loop_ = false;
             };
         } // namespace generic
     } // namespace behaviors

@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def configs():
+    """configs/ is generated, not committed: tools/emit_configs.py writes the task stacks, CONTROLLER / BEHAVIOR trees and model
+    files the C++ facade reads from the constants in inria_wbc_amd/ (the directory is git-ignored)."""
+    from tools import emit_configs
+    emit_configs.main()
+    return os.path.join(ROOT, "configs")
+
+
 @pytest.fixture(scope="session")
 def built_lib():
     """libwbcqp.so, (re)built in-tree with hipcc when sources changed (cross-compiles without a GPU)."""
