@@ -97,6 +97,7 @@ def emit_model_files():
     schema (etc/talos/frames.yaml) and a CONTROLLER tree that uses them."""
     from inria_wbc_amd import model as mdl
     d = os.path.join(ROOT, "configs", "talos")
+    os.makedirs(d, exist_ok=True)
     m = mdl.talos_like()
     virtual = ["v_leg_right_3", "v_leg_left_3", "v_base_link_left", "v_base_link_right"]
     mdl.to_yaml(m, os.path.join(d, "talos_like.model.yaml"), skip_frames=virtual, ref_name="inria_start")
