@@ -28,7 +28,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     L = st.field_lengths()
     res = []
-    for B in (1, 4, 16, 64, 256, 1024):
+    for B in (1, 4, 16, 64, 256, 1024, 4096, 8192):
         h = capi.Handle(0, capi.F64)
         h.set_structure(0, st)
         h.set_model(0, m, tm)
@@ -67,6 +67,7 @@ def main():
         row["graph_us"] = run(lambda: h.tick_graph_launch(g, stream=stream), True)
         row["graph_back_to_back_us"] = run(lambda: h.tick_graph_launch(g, stream=stream), False)
         row["tick_back_to_back_us"] = run(lambda: h.tick(0, B, state, rows, out, qn, vn, tm.dt, stream=stream), False)
+        row["ticks_per_s_back_to_back"] = B / (row["tick_back_to_back_us"] * 1e-6)
         row["iters_mean"] = float(out["iters"].float().mean().item())
         row["status_optimal"] = int((out["status"] == 0).sum().item())
         print(json.dumps(row))
