@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """One-off larger parity sweep on the GPU box: every structure, easy and hard active sets, thousands of QPs against the
-CPU oracle (x, tau to TOL, status and iteration counts).      python tools/stress_parity.py [batch]"""
+CPU oracle (x, tau to TOL, status and iteration counts).      python tests/stress/stress_parity.py [batch]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

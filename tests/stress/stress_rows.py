@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Fuzz of the rows kernel (wbcqp_problem_data) against oracle/rbd_oracle.c: random trees (every joint type, random
-branching, depth up to a chain), random task stacks, large states.  Usage (GPU box): python tools/stress_rows.py [--n 60]"""
+branching, depth up to a chain), random task stacks, large states.  Usage (GPU box): python tests/stress/stress_rows.py [--n 60]"""
 import argparse
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -221,8 +221,8 @@ def test_mixed_robots_rows_then_one_ragged_solve(rbd):
 
 
 def test_problem_data_random_trees_and_stacks():
-    """A short run of tools/stress_rows.py: random branching trees and pure chains up to 61 bodies, every joint type, random
+    """A short run of tests/stress/stress_rows.py: random branching trees and pure chains up to 61 bodies, every joint type, random
     masks, contacts, self-collision tasks, large states."""
-    from tools import stress_rows
+    from tests.stress import stress_rows
     worst = stress_rows.run(24, tol=TOL_ROWS)
     assert worst and max(worst.values()) < TOL_ROWS

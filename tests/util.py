@@ -29,7 +29,7 @@ def assert_parity(st, got, ref, tol=TOL_F64, what=""):
     """got/ref: dicts with x, tau, status, iters ([B, ...]).  dv, the contact wrenches T f and tau must agree to `tol`
     (relative to max(1, |.|inf)); the raw contact-point forces f only to TOL_RAW_FORCE: H_ff = w F'F + 1e-8 I has rank-6
     F'F, so six directions of f per contact are conditioned like 1e12 (seen: |df| 1.6e-3 on |f| 215 with dv, T f and tau
-    equal to 1e-9, tools/stress_parity.py)."""
+    equal to 1e-9, tests/stress/stress_parity.py)."""
     assert np.array_equal(got["status"], ref["status"]), (what, got["status"], ref["status"])
     ok = ref["status"] == 0
     nv = st.nv
