@@ -536,7 +536,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
                     const double sn = dot(diff, diff), norm = sqrt(sn);
                     const double x = k5 * (norm - aa + s_p);
                     const double e_p = exp(-x), e1 = e_p + 1.0;
-                    const double pw1 = pow(e1, -mm_ - 1.0);         // (1 + e)^(-m-1); the two neighbouring powers follow from it
+                    const double pw1 = exp((-mm_ - 1.0) * log(e1)); // (1 + e)^(-m-1), e1 >= 1; the two neighbouring powers follow from it
                     const double C = 1.0 - pw1 * e1;
                     const double gscale = -1.0 / norm * k5 * mm_ * e_p * pw1;
                     const double hh = 1.0 / sn * k5 * k5 * (-mm_ - 1.0) * mm_ * (e_p * e_p) * (pw1 / e1)
