@@ -49,13 +49,15 @@ namespace inria_wbc {
         struct TickInputs {
             int batch = 0;
             std::vector<double> M, h, A, b1, Ac, bc, blb, bub, tlb, tub, w;
+            // sizes the arrays for B instances; contents are left alone when nothing changed (every tick overwrites what it uses)
             void resize(int B, const wbcqp_layout& L)
             {
                 batch = B;
-                M.assign((size_t)B * L.len_M, 0.0); h.assign((size_t)B * L.len_h, 0.0); A.assign((size_t)B * L.len_A, 0.0);
-                b1.assign((size_t)B * L.len_b1, 0.0); Ac.assign((size_t)B * L.len_Ac, 0.0); bc.assign((size_t)B * L.len_bc, 0.0);
-                blb.assign((size_t)B * L.len_blb, 0.0); bub.assign((size_t)B * L.len_bub, 0.0);
-                tlb.assign((size_t)B * L.len_tlb, 0.0); tub.assign((size_t)B * L.len_tub, 0.0); w.assign((size_t)B * L.len_w, 0.0);
+                auto fit = [B](std::vector<double>& a, int len) {
+                    if (a.size() != (size_t)B * len) a.assign((size_t)B * len, 0.0);
+                };
+                fit(M, L.len_M); fit(h, L.len_h); fit(A, L.len_A); fit(b1, L.len_b1); fit(Ac, L.len_Ac); fit(bc, L.len_bc);
+                fit(blb, L.len_blb); fit(bub, L.len_bub); fit(tlb, L.len_tlb); fit(tub, L.len_tub); fit(w, L.len_w);
             }
         };
 
