@@ -1,5 +1,5 @@
 // wbcqp_terms.hpp -- the step BEFORE the QP: from (q, v, task references) to the rows of the
-// QP record, one wavefront per robot instance.
+// QP record, one workgroup of four wavefronts per robot instance.
 //
 // What it replaces: the upstream half of tsid_->computeProblemData(t, q, dq) (/root/reference/src/controllers/controller.cpp:244):
 // pinocchio's computeAllTerms / centerOfMass / ccrba / frame Jacobians (call set listed by RobotModel::update,
@@ -13,12 +13,13 @@
 // Then a spatial quantity of a subtree is a plain sum over its bodies, bodies are numbered depth-first so a subtree is a
 // contiguous lane range, and every composite (inertia for CRBA, bias force for the non-linear effects, momentum) is one
 // wave-wide prefix sum and a difference of two entries:
-//   (wave 0) lanes = bodies:   joint transform, placement / velocity / bias acceleration down the tree (one step per depth level),
-//                     world inertia, momentum, bias force, prefix sums
-//   lanes = tasks:    frame placement, velocity, classical acceleration, SE(3) error (log3), right-hand sides
-//   lanes = pairs:    self-collision repulsors (one lane per tracked / avoided pair)
-//   lanes = columns:  S_j, F_j = Y_subtree S_j, M (row by row, straight into the packed triangle), h, the Jacobian rows of
-//                     every task (local frame), CoM and centroidal-momentum rows, self-collision rows
+//   lanes = bodies  (wave 0):    joint transform; placement, velocity and bias acceleration down the tree by ancestor doubling
+//                                (ceil(log2(depth + 1)) rounds of ds_bpermute); world inertia, momentum, bias force, prefix sums
+//   lanes = tasks   (wave 1):    frame placement, velocity, classical acceleration, SE(3) error (log3), right-hand sides
+//   lanes = frames, then pairs (wave 2): the distinct self-collision frames, then one repulsor per tracked / avoided pair
+//   lanes = joints  (wave 3):    posture right-hand side, joint bounds
+//   lanes = columns (every wave, a quarter of the rows each): S_j, F_j = Y_subtree S_j, M (row by row, straight into the packed
+//                                triangle), h, the Jacobian rows of every task (local frame), CoM / momentum / self-collision rows
 // HBM traffic per instance = state + references in, QP record out; nothing else leaves the CU.
 #pragma once
 
@@ -172,7 +173,8 @@ constexpr int kTermsThreads = 256; // four wavefronts per instance: one runs the
 
 // One workgroup of four wavefronts per instance.
 //   phase 1  wave 0: joint transforms and the sweep down the tree;  wave 3 meanwhile: posture right-hand side, joint bounds
-//   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames and their laws;  wave 2: self-collision pairs
+//   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames and their laws;  wave 2: self-collision frames
+//            and pairs
 //   phase 3  every wave: S_j and F_j of its lanes' columns (registers), then a quarter of the output rows each -- rows of M,
 //            Jacobian rows of the framed tasks, CoM / momentum / self-collision rows
 template <typename TI>
