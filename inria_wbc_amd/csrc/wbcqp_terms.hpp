@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     // no rotation of the roles: the hardware itself starts co-resident workgroups on different SIMDs (measured with
     // tools/ubench/wave_placement.hip: wave 0 of the four workgroups of a CU lands on SIMD 2, 1, 3, 0), so their tree waves
     // already sit on four different SIMDs
-    const int wave = tid >> 6;
+    const int wave = uni(tid >> 6); // told to the compiler as wave-uniform: scalar branches on the role, scalar row counters
     if (inst >= args.batch) return;
 #ifdef WBCQP_STAMPS
     long long tacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
