@@ -61,7 +61,7 @@ struct TermsDev {
     int d_blk_kp, d_blk_kd;                                  // [nblock]
     int d_qlb, d_qub, d_dqmax;                               // [na]
     // LDS layout (doubles)
-    int o_state, o_kin, o_scan, o_tot, o_law, o_pair, o_scf, o_b1, o_bc;
+    int o_state, o_kin, o_scan, o_tot, o_law, o_law3, o_pair, o_scf, o_b1, o_bc;
     int lds_doubles;
 };
 
@@ -169,14 +169,62 @@ __device__ __forceinline__ double scan_incl_dpp(double v, int lane)
 }
 __device__ __forceinline__ int rl(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
+// Column j of the world-aligned joint Jacobian: the joint's motion subspace column in its own axes, moved by oMi.act(.)
+struct ColumnAxis { int body, last; V3 Sv, Sw; };
+__device__ __forceinline__ ColumnAxis column_axis(const TermsDev& T, const double* kin, int cj)
+{
+    const int* ip = T.ipool;
+    ColumnAxis c;
+    c.body = ip[T.i_bodyof + cj];
+    const int kj = ip[T.i_kof + cj];
+    c.last = ip[T.i_last + c.body];
+    const double* K = kin + kKinStride * c.body;
+    const int jtj = ip[T.i_jtype + c.body];
+    const int a = (jtj == J_FREEFLYER) ? (kj % 3) : (jtj <= J_RZ) ? jtj - J_RX : jtj - J_PX;
+    const bool ang = (jtj == J_FREEFLYER) ? (kj >= 3) : (jtj <= J_RZ);
+    const V3 ax = col(K, 0), ay = col(K, 1), az = col(K, 2);
+    const V3 wa = (a == 0) ? ax : (a == 1) ? ay : az; // world direction of the axis
+    const V3 pj = ld3(K + 9);
+    if (ang) { c.Sw = wa; c.Sv = cross(pj, wa); }
+    else { c.Sv = wa; c.Sw = {0, 0, 0}; }
+    return c;
+}
+
+// Jacobian rows of the framed tasks l = first, first + step, ...: local frame, rows picked by the mask (ex_task.cpp:233-236).
+// Lane = column; lane l of the calling wave holds task l's table entries, the loop reads them back as uniform values.
+template <typename TI>
+__device__ __forceinline__ void jacobian_rows(const TermsDev& T, const double* law, const ColumnAxis& c, bool colv, int lane, int first, int step,
+                                              TI* Ao, TI* Aco, int nv)
+{
+    const int* ip = T.ipool;
+    const int ll = min(lane, max(T.nlaw - 1, 0));
+    const int t_body = ip[T.i_law_body + ll], t_mask = ip[T.i_law_mask + ll], t_ct = ip[T.i_law_contact + ll], t_row = ip[T.i_law_row + ll];
+    for (int l = first; l < T.nlaw; l += step) {
+        const double* Lw = law + kLawStride * l;
+        const int bl = rl(t_body, l), mask = rl(t_mask, l), ct = rl(t_ct, l), row = rl(t_row, l);
+        const bool sup = c.body <= bl && bl <= c.last;
+        const V3 pf = ld3(Lw + 9);
+        const V3 jl = mtv(Lw, c.Sv + cross(c.Sw, pf)), ja = mtv(Lw, c.Sw);
+        const double e[6] = {jl.x, jl.y, jl.z, ja.x, ja.y, ja.z};
+        TI* out = (ct >= 0) ? Aco + (size_t)ct * 6 * nv : Ao + (size_t)row * nv;
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if ((mask >> i) & 1) {
+                if (colv) out[(size_t)o * nv + lane] = (TI)(sup ? e[i] : 0.0);
+                ++o;
+            }
+    }
+}
+
 constexpr int kTermsThreads = 256; // four wavefronts per instance: one runs the tree, all four share the rows
 
 // One workgroup of four wavefronts per instance.
 //   phase 1  wave 0: joint transforms and the sweep down the tree;  wave 3 meanwhile: posture right-hand side, joint bounds
-//   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames and their laws;  wave 2: self-collision frames
-//            and pairs
-//   phase 3  every wave: S_j and F_j of its lanes' columns (registers), then a quarter of the output rows each -- rows of M,
-//            Jacobian rows of the framed tasks, CoM / momentum / self-collision rows
+//   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames, their laws, half of their Jacobian rows;
+//            wave 2: self-collision frames and pairs;  wave 3: the other half of the Jacobian rows
+//   phase 3  every wave: S_j and F_j of its lanes' columns (registers), then a quarter of the remaining rows each -- rows of M,
+//            CoM / momentum / self-collision rows
 template <typename TI>
 __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs<TI> args)
 {
@@ -440,7 +488,31 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
             args.blb[(size_t)inst * T.n_bound + j] = (TI)lb;
             args.bub[(size_t)inst * T.n_bound + j] = (TI)ub;
         }
-        __syncthreads(); // barrier 1
+        // ---- phase 2 on this wave: the Jacobian rows of every second framed task (wave 1 takes the others).  The frames are
+        //      recomputed here into this wave's own copy of the table: cheaper than waiting for wave 1 to publish them ----------
+        const int ll = min(lane, max(T.nlaw - 1, 0));
+        const int l_body = ip[T.i_law_body + ll];
+        double l_place[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) l_place[r] = dp[T.d_law_place + 12 * ll + r];
+        __syncthreads(); // barrier 1: kin is complete
+        double* law3 = lds + T.o_law3;
+        if (lane < T.nlaw) {
+            FrameKin f;
+            frame_kin(kin + kKinStride * l_body, l_place, f);
+            double* Lw = law3 + kLawStride * lane;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) Lw[r] = f.R[r];
+            st3(Lw + 9, f.p);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const bool colv = lane < nv;
+            const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
+            jacobian_rows<TI>(T, law3, c, colv, lane, 1, 2, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
+        }
     }
     else if (wave == 1) {
         // ---- lanes = tasks with a frame (SE(3) blocks, then contacts): the law of ex_task.cpp:175-247, local frame ---------
@@ -486,6 +558,17 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
                     if ((mask >> i) & 1) out[o++] = rhs[i];
+            }
+            // the same wave, lanes = columns now: the Jacobian rows of those tasks.  They need the frames just written and the
+            // bodies' placements, not the prefix sums, so two thirds of the record's bytes leave here, while wave 0 is still
+            // scanning, instead of in one burst at the end of the kernel
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                const bool colv = lane < nv;
+                const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
+                jacobian_rows<TI>(T, law, c, colv, lane, 0, 2, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
             }
             TSTAMP(4)
         }
@@ -576,22 +659,9 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     const V3 com = imass * ld3(tot + 1);
     const V3 htl = ld3(tots), hta = ld3(tots + 3);
     const bool colv = lane < nv;
-    const int cj = colv ? lane : 0;
-    const int bj = ip[T.i_bodyof + cj], kj = ip[T.i_kof + cj];
-    const int lastj = ip[T.i_last + bj];
-    V3 Sv, Sw;
-    {
-        const double* K = kin + kKinStride * bj;
-        const int jtj = ip[T.i_jtype + bj];
-        // the column of the joint's motion subspace in its own axes, then oMi.act(.)
-        const int a = (jtj == J_FREEFLYER) ? (kj % 3) : (jtj <= J_RZ) ? jtj - J_RX : jtj - J_PX;
-        const bool ang = (jtj == J_FREEFLYER) ? (kj >= 3) : (jtj <= J_RZ);
-        const V3 ax = col(K, 0), ay = col(K, 1), az = col(K, 2);
-        const V3 wa = (a == 0) ? ax : (a == 1) ? ay : az; // world direction of the axis
-        const V3 pj = ld3(K + 9);
-        if (ang) { Sw = wa; Sv = cross(pj, wa); }
-        else { Sv = wa; Sw = {0, 0, 0}; }
-    }
+    const ColumnAxis cax = column_axis(T, kin, colv ? lane : 0);
+    const int bj = cax.body, lastj = cax.last;
+    const V3 Sv = cax.Sv, Sw = cax.Sw;
     V3 Fv, Fw;
     {
         // composite of the subtree of body bj: prefix(last + 1) - prefix(bj)
@@ -624,30 +694,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
         }
     }
     TSTAMP(8)
-    // Jacobian rows of the tasks with a frame: local frame, rows picked by the mask (ex_task.cpp:233-236)
-    TI* Ao = args.A + (size_t)inst * T.n_dense * nv;
-    {
-        TI* Aco = args.Ac + (size_t)inst * T.nc * 6 * nv;
-        // lane l holds the table entries of task l; the loop reads them back as uniform values
-        const int ll = min(lane, max(T.nlaw - 1, 0));
-        const int t_body = ip[T.i_law_body + ll], t_mask = ip[T.i_law_mask + ll], t_ct = ip[T.i_law_contact + ll], t_row = ip[T.i_law_row + ll];
-        for (int l = wave; l < T.nlaw; l += kWaves) {
-            const double* Lw = law + kLawStride * l;
-            const int bl = rl(t_body, l), mask = rl(t_mask, l), ct = rl(t_ct, l), row = rl(t_row, l);
-            const bool sup = bj <= bl && bl <= lastj;
-            const V3 pf = ld3(Lw + 9);
-            const V3 jl = mtv(Lw, Sv + cross(Sw, pf)), ja = mtv(Lw, Sw);
-            const double e[6] = {jl.x, jl.y, jl.z, ja.x, ja.y, ja.z};
-            TI* out = (ct >= 0) ? Aco + (size_t)ct * 6 * nv : Ao + (size_t)row * nv;
-            int o = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                if ((mask >> i) & 1) {
-                    if (colv) out[(size_t)o * nv + lane] = (TI)(sup ? e[i] : 0.0);
-                    ++o;
-                }
-        }
-    }
+    TI* Ao = args.A + (size_t)inst * T.n_dense * nv; // (the Jacobian rows of the framed tasks left in phase 2, from wave 1)
     TSTAMP(9)
     // CoM, momentum and self-collision rows and the CoM / momentum right-hand sides, one block per wave in turn
     {
