@@ -221,8 +221,8 @@ constexpr int kTermsThreads = 256; // four wavefronts per instance: one runs the
 
 // One workgroup of four wavefronts per instance.
 //   phase 1  wave 0: joint transforms and the sweep down the tree;  wave 3 meanwhile: posture right-hand side, joint bounds
-//   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames, their laws, half of their Jacobian rows;
-//            wave 2: self-collision frames and pairs;  wave 3: the other half of the Jacobian rows
+//   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames, their laws, a third of their Jacobian
+//            rows;  wave 2: self-collision frames and pairs;  wave 3: the other two thirds of the Jacobian rows
 //   phase 3  every wave: S_j and F_j of its lanes' columns (registers), then a quarter of the remaining rows each -- rows of M,
 //            CoM / momentum / self-collision rows
 template <typename TI>
@@ -430,10 +430,10 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = scan_incl_dpp(sc[r], lane);
-#pragma unroll
         for (int r = 0; r < 6; ++r) hm[r] = wave_sum(hm[r]);
-        // entry 0 of the table is the empty prefix, entry i + 1 the sum over bodies 0..i
+        // Prefix sums over the bodies through the table itself: entry 0 is the empty prefix, entry i + 1 the sum over bodies
+        // 0..i.  The raw values go in first; then lane (r = lane & 15, chunk = lane >> 4) runs the sum of value r over the 16
+        // bodies of its chunk, the chunk totals are exchanged, and the offsets of the earlier chunks are added on the way back.
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) scan[r] = 0.0;
@@ -443,6 +443,33 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
         if (body) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) scan[kScanStride * (lane + 1) + r] = sc[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const int r = lane & 15, chunk = lane >> 4;
+            double vals[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int b = 16 * chunk + k;
+                vals[k] = scan[kScanStride * (min(b, nb - 1) + 1) + r];
+            }
+            double run = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                run += (16 * chunk + k < nb) ? vals[k] : 0.0;
+                vals[k] = run;
+            }
+            const double t0 = __shfl(run, r, kWave), t1 = __shfl(run, 16 + r, kWave), t2 = __shfl(run, 32 + r, kWave);
+            const double off = (chunk == 0) ? 0.0 : (chunk == 1) ? t0 : (chunk == 2) ? (t0 + t1) : ((t0 + t1) + t2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int b = 16 * chunk + k;
+                if (b < nb) scan[kScanStride * (b + 1) + r] = vals[k] + off;
+            }
         }
         TSTAMP(3)
     }
@@ -488,7 +515,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
             args.blb[(size_t)inst * T.n_bound + j] = (TI)lb;
             args.bub[(size_t)inst * T.n_bound + j] = (TI)ub;
         }
-        // ---- phase 2 on this wave: the Jacobian rows of every second framed task (wave 1 takes the others).  The frames are
+        // ---- phase 2 on this wave: the Jacobian rows of two framed tasks in three (wave 1 takes the others).  The frames are
         //      recomputed here into this wave's own copy of the table: cheaper than waiting for wave 1 to publish them ----------
         const int ll = min(lane, max(T.nlaw - 1, 0));
         const int l_body = ip[T.i_law_body + ll];
@@ -511,7 +538,9 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
         {
             const bool colv = lane < nv;
             const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
-            jacobian_rows<TI>(T, law3, c, colv, lane, 1, 2, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
+            // two tasks in three here, one in three on wave 1, which also evaluates the laws
+            jacobian_rows<TI>(T, law3, c, colv, lane, 1, 3, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
+            jacobian_rows<TI>(T, law3, c, colv, lane, 2, 3, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
         }
     }
     else if (wave == 1) {
@@ -568,7 +597,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
             {
                 const bool colv = lane < nv;
                 const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
-                jacobian_rows<TI>(T, law, c, colv, lane, 0, 2, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
+                jacobian_rows<TI>(T, law, c, colv, lane, 0, 3, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
             }
             TSTAMP(4)
         }
