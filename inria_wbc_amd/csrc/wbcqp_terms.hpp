@@ -155,18 +155,6 @@ __device__ __forceinline__ void frame_kin(const double* kin_b, const double* pla
 #define TSTAMP(i)
 #endif
 
-// inclusive prefix sum over the 64 lanes: four DPP row shifts inside each row of 16, then the row totals by readlane
-__device__ __forceinline__ double scan_incl_dpp(double v, int lane)
-{
-    v += dpp_get<0x111>(v);
-    v += dpp_get<0x112>(v);
-    v += dpp_get<0x114>(v);
-    v += dpp_get<0x118>(v);
-    const double t0 = bcast_lane(v, 15), t1 = bcast_lane(v, 31), t2 = bcast_lane(v, 47);
-    const int row = lane >> 4;
-    const double add = (row == 0) ? 0.0 : (row == 1) ? t0 : (row == 2) ? (t0 + t1) : ((t0 + t1) + t2);
-    return v + add;
-}
 __device__ __forceinline__ int rl(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 // Column j of the world-aligned joint Jacobian: the joint's motion subspace column in its own axes, moved by oMi.act(.)
