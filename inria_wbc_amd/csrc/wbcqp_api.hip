@@ -757,6 +757,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     T.o_kin = take(nb * kKinStride);
     T.o_scan = take((nb + 1) * kScanStride);
     T.o_tot = take(8); // momentum totals
+    T.o_sf = take(nv * kSFStride);
     T.o_law = take(T.nlaw * kLawStride);
     T.o_law3 = take(T.nlaw * kLawStride); // wave 3's own copy of the task frames
     T.o_pair = take(T.npair * kPairStride);

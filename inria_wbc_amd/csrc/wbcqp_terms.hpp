@@ -32,6 +32,7 @@ enum { T_SE3 = 0, T_COM = 1, T_MOMENTUM = 2, T_SELFCOLLISION = 3 };
 
 constexpr int kKinStride = 25; // per body: R (9) p (3) v (6) a (6), odd stride
 constexpr int kScanStride = 17; // per body: m, m c (3), inertia about the origin (6), bias force (6)
+constexpr int kSFStride = 13;   // per column: S (6), F (6)
 constexpr int kLawStride = 13;  // per task frame: R (9) p (3)
 constexpr int kPairStride = 7;  // per self-collision pair: grad (3), rhs share, tracked body, avoided body
 constexpr int kScfStride = 7;   // per self-collision frame: position (3), classical linear acceleration in its own axes (3)
@@ -61,7 +62,7 @@ struct TermsDev {
     int d_blk_kp, d_blk_kd;                                  // [nblock]
     int d_qlb, d_qub, d_dqmax;                               // [na]
     // LDS layout (doubles)
-    int o_state, o_kin, o_scan, o_tot, o_law, o_law3, o_pair, o_scf, o_b1, o_bc;
+    int o_state, o_kin, o_scan, o_tot, o_sf, o_law, o_law3, o_pair, o_scf, o_b1, o_bc;
     int lds_doubles;
 };
 
@@ -211,7 +212,7 @@ constexpr int kTermsThreads = 256; // four wavefronts per instance: one runs the
 //   phase 1  wave 0: joint transforms and the sweep down the tree;  wave 3 meanwhile: posture right-hand side, joint bounds
 //   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames, their laws, a third of their Jacobian
 //            rows;  wave 2: self-collision frames and pairs;  wave 3: the other two thirds of the Jacobian rows
-//   phase 3  every wave: S_j and F_j of its lanes' columns (registers), then a quarter of the remaining rows each -- rows of M,
+//   phase 3  every wave: S_j and F_j of its lanes' columns (from wave 0, through LDS), then a quarter of the remaining rows each -- rows of M,
 //            CoM / momentum / self-collision rows
 template <typename TI>
 __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs<TI> args)
@@ -459,6 +460,32 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
                 if (b < nb) scan[kScanStride * (b + 1) + r] = vals[k] + off;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lanes = columns: S_j, the composite of the subtree under it, F_j = Y S_j, and the non-linear effects h_j; into LDS for
+        // the four waves of phase 3 (this wave has time to spare here: the task-law wave is the long one in phase 2)
+        {
+            const bool colv = lane < nv;
+            const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
+            const double* hi = scan + kScanStride * (c.last + 1); // prefix(last + 1) - prefix(body)
+            const double* lo = scan + kScanStride * c.body;
+            double Y[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[r] = hi[r] - lo[r];
+            const V3 hc = {Y[1], Y[2], Y[3]};
+            const V3 Fv = Y[0] * c.Sv + cross(c.Sw, hc);
+            const V3 Fw = symv(Y + 4, c.Sw) + cross(hc, c.Sv);
+            if (colv) {
+                double* SF = lds + T.o_sf + kSFStride * lane;
+                st3(SF, c.Sv); st3(SF + 3, c.Sw); st3(SF + 6, Fv); st3(SF + 9, Fw);
+                // bias force of the subtree + its weight, projected on the joint axis
+                const V3 gvec = {T.g[0], T.g[1], T.g[2]};
+                const V3 gl = ld3(Y + 10) - Y[0] * gvec;
+                const V3 ga = ld3(Y + 13) - cross(hc, gvec);
+                args.h[(size_t)inst * nv + lane] = (TI)(dot(c.Sv, gl) + dot(c.Sw, ga));
+            }
+        }
         TSTAMP(3)
     }
     else if (wave == 3) {
@@ -676,28 +703,11 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     const V3 com = imass * ld3(tot + 1);
     const V3 htl = ld3(tots), hta = ld3(tots + 3);
     const bool colv = lane < nv;
-    const ColumnAxis cax = column_axis(T, kin, colv ? lane : 0);
-    const int bj = cax.body, lastj = cax.last;
-    const V3 Sv = cax.Sv, Sw = cax.Sw;
-    V3 Fv, Fw;
-    {
-        // composite of the subtree of body bj: prefix(last + 1) - prefix(bj)
-        const double* hi = scan + kScanStride * (lastj + 1);
-        const double* lo = scan + kScanStride * bj;
-        double Y[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Y[r] = hi[r] - lo[r];
-        const V3 hc = {Y[1], Y[2], Y[3]};
-        Fv = Y[0] * Sv + cross(Sw, hc);
-        Fw = symv(Y + 4, Sw) + cross(hc, Sv);
-        // non-linear effects: bias force of the subtree + its weight, projected on the joint axis
-        if (wave == 0) {
-            const V3 gvec = {T.g[0], T.g[1], T.g[2]};
-            const V3 gl = ld3(Y + 10) - Y[0] * gvec;
-            const V3 ga = ld3(Y + 13) - cross(hc, gvec);
-            if (colv) args.h[(size_t)inst * nv + lane] = (TI)(dot(Sv, gl) + dot(Sw, ga));
-        }
-    }
+    const int cj = colv ? lane : 0;
+    const int bj = ip[T.i_bodyof + cj], lastj = ip[T.i_last + bj];
+    // S_j and F_j = Y_subtree(j) S_j of this lane's column: formed once, by wave 0 at the end of phase 2
+    const double* SF = lds + T.o_sf + kSFStride * cj;
+    const V3 Sv = ld3(SF), Sw = ld3(SF + 3), Fv = ld3(SF + 6), Fw = ld3(SF + 9);
     TSTAMP(7)
     // M, row by row into the packed lower triangle: M(i, j) = S_j . F_i for j an ancestor dof of i (crba); F_i by readlane
     {
