@@ -226,3 +226,26 @@ def test_problem_data_random_trees_and_stacks():
     from tests.stress import stress_rows
     worst = stress_rows.run(24, tol=TOL_ROWS)
     assert worst and max(worst.values()) < TOL_ROWS
+
+
+def test_problem_data_minimal_stack(handle, rbd):
+    """A stack with nothing optional: two SE(3) tasks on a fixed-base tree -- no posture, no CoM, no contacts, no bounds, no
+    self-collision (every optional table of the kernel is empty)."""
+    from inria_wbc_amd import structure as S
+    m = mdl.random_tree(77, 11, False, nframe=9)
+    stack = [dict(name="a", type="se3", tracked="f2", kp=20.0, mask="111000"), dict(name="b", type="se3", tracked="f5", kp=5.0, mask="000111")]
+    st = S._mk("minimal", m.nv, m.na, [], [("a", 3, 1.0), ("b", 3, 2.0)], None, [], False, False, [])
+    tm = mdl.build_taskmap(m, st, stack)
+    assert tm.n_bound == 0 and tm.ncontact == 0 and tm.sel_col.size == 0 and tm.nref == 48
+    handle.set_structure(6, st)
+    handle.set_model(6, m, tm)
+    s = mdl.sample_states(m, tm, 5, 35_000, q_noise=0.4, v_noise=0.8, ref_noise=0.2)
+    dev = handle.problem_data_host(6, s["q"], s["v"], s["ref"])
+    ora = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"])
+    _compare(dev, ora)
+    # and the solve on those rows: an unconstrained QP, x = -H^-1 g
+    from oracle import oracle as orc
+    B = 5
+    got = handle.solve_batch_host(6, dict(dev, tlb=np.zeros((B, 0)), tub=np.zeros((B, 0)), w=np.tile(st.default_weights, (B, 1))))
+    ref = orc.tick_batch(st, dict(ora, tlb=np.zeros((B, 0)), tub=np.zeros((B, 0)), w=np.tile(st.default_weights, (B, 1))))
+    assert (got["status"] == 0).all() and np.abs(got["x"] - ref["x"]).max() <= 1e-8 * max(1.0, np.abs(ref["x"]).max())
