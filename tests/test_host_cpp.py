@@ -489,3 +489,37 @@ def test_qp_timer_test_walk_takes_steps(host_build, oracle_mod, tmp_path):
     pf = m.frame_placements(q)[1]
     assert abs(pf[fid["lf"]][0] - pf0[fid["lf"]][0] - 2 * Lstep) < 5e-3 and abs(pf[fid["rf"]][0] - pf0[fid["rf"]][0] - 2 * Lstep) < 5e-3
     assert abs(m.com(q)[0] - m.com(m.q0)[0] - 2 * Lstep) < 0.02
+
+
+@pytest.mark.gpu
+def test_qp_timer_test_icub_squat(host_build, oracle_mod, tmp_path):
+    """The iCub stack (etc/icub/tasks.yaml: posture in mid-stack, no actuation bounds, contact normal -z on z-down ankle frames,
+    virtual frames of etc/icub/frames.yaml) through the facade on the iCub-like model: a 5 cm squat, closed loop, against the
+    oracle loop."""
+    from inria_wbc_amd import model as mdl, structure, trajs
+    from oracle import rbd
+    n_ticks = 400
+    q_path = str(tmp_path / "q.bin")
+    r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/icub/pos_tracker_model.yaml"),
+                        os.path.join(ROOT, "configs/icub/squat.yaml"), "-", str(n_ticks), str(tmp_path / "tau.bin"), "0", q_path],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    m = mdl.icub_like()
+    st = structure.icub_structure()
+    tm = mdl.build_taskmap(m, st, mdl.icub_stack())
+    q = np.fromfile(q_path, dtype=np.float64).reshape(4, m.nq)
+    assert all(np.array_equal(q[0], q[i]) for i in range(1, 4))
+    s = mdl.sample_states(m, tm, 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+    oq, ov, oref = s["q"], s["v"], s["ref"]
+    blk = next(b for b in tm.blocks if b.kind == mdl.T_COM)
+    pos, vel, acc = trajs.move_com_stream(m.com(m.q0), [[0.0, 0.0, -0.05]], "001", tm.dt, 1.0, loop=True, absolute=False)
+    empty, w = np.zeros((1, 0)), st.default_weights[None]
+    for k in range(n_ticks):
+        oref[0, blk.ref:blk.ref + 9] = np.concatenate([pos[k], vel[k], acc[k]])
+        rows = rbd.task_rows(m, tm, st, oq, ov, oref)
+        oo = oracle_mod.tick_batch(st, dict(rows, tlb=empty, tub=empty, w=w))
+        assert oo["status"][0] == 0
+        nxt = oracle_mod.integrate(True, tm.dt, oq, ov, oo["x"][:, :st.nv])
+        oq, ov = nxt["q_next"], nxt["v_next"]
+    assert np.abs(q[0] - oq[0]).max() < 1e-8, np.abs(q[0] - oq[0]).max()
+    assert abs(m.com(q[0])[2] - pos[n_ticks - 1][2]) < 5e-3 and m.com(m.q0)[2] - m.com(q[0])[2] > 0.005
