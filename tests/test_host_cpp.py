@@ -523,3 +523,20 @@ def test_qp_timer_test_icub_squat(host_build, oracle_mod, tmp_path):
         oq, ov = nxt["q_next"], nxt["v_next"]
     assert np.abs(q[0] - oq[0]).max() < 1e-8, np.abs(q[0] - oq[0]).max()
     assert abs(m.com(q[0])[2] - pos[n_ticks - 1][2]) < 5e-3 and m.com(m.q0)[2] - m.com(q[0])[2] > 0.005
+
+
+@pytest.mark.gpu
+def test_two_runs_are_bitwise_equal(host_build, tmp_path):
+    """The reference's determinism bar (tests/test_determinism.cpp:44-57: two controllers fed the same inputs agree below 1e-8)
+    -- here two separate processes running 300 closed-loop ticks of the walk on the spot (with a contact switch inside) must
+    agree bit for bit, in the joint state and in the torques."""
+    outs = []
+    for run in range(2):
+        q_path, tau_path = str(tmp_path / ("q%d.bin" % run)), str(tmp_path / ("tau%d.bin" % run))
+        beh = tmp_path / "wos.yaml"
+        beh.write_text("BEHAVIOR:\n  name: humanoid::walk-on-spot\n  traj_com_duration: 0.2\n  traj_foot_duration: 0.2\n  step_height: 0.03\n")
+        r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/talos/pos_tracker_model.yaml"), str(beh), "-", "300", tau_path,
+                            "0", q_path], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+        outs.append((open(q_path, "rb").read(), open(tau_path, "rb").read()))
+    assert outs[0] == outs[1]
