@@ -7,6 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $ROOT
+python3 -c "from inria_wbc_amd import build; build.build(); build.build_stamps()" > $OUT/build.log 2>&1
 python3 bench.py --steps 20 --warmup 3 --sweep $OUT/sweep.json > $OUT/bench.json 2> $OUT/bench.err
 python3 tools/phase_profile.py --out $OUT/phase.json > $OUT/phase.txt 2>&1
 python3 tools/phase_profile.py --model > $OUT/phase_model.txt 2>&1
