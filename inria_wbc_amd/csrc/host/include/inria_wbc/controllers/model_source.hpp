@@ -14,6 +14,25 @@
 namespace inria_wbc {
     namespace controllers {
         class ModelSource : public ProblemSource {
+            // what one (slot, task stack) pair needs: the task table handed to wbcqp_set_model and the reference vector laid out
+            // for it.  One per slot: a controller that switches between contact sets keeps them all and only re-points.
+            struct Bound {
+                int nref_ = 0, posture_ref_ = 0;
+                std::vector<double> ref_;
+                std::vector<wbcqp_task> tasks_;
+                std::vector<std::string> names_, contact_names_;
+                std::vector<int32_t> avoided_frames_, contact_frame_, contact_ref_;
+                std::vector<double> avoided_r0_, contact_kp_, contact_kd_;
+            };
+#define IWBC_BOUND_ALIASES(B)                                                                                                         \
+    auto& nref_ = (B).nref_; auto& posture_ref_ = (B).posture_ref_; auto& ref_ = (B).ref_; auto& tasks_ = (B).tasks_;                  \
+    auto& names_ = (B).names_; auto& contact_names_ = (B).contact_names_; auto& avoided_frames_ = (B).avoided_frames_;                 \
+    auto& contact_frame_ = (B).contact_frame_; auto& contact_ref_ = (B).contact_ref_; auto& avoided_r0_ = (B).avoided_r0_;             \
+    auto& contact_kp_ = (B).contact_kp_; auto& contact_kd_ = (B).contact_kd_;                                                         \
+    (void)nref_; (void)posture_ref_; (void)ref_; (void)tasks_; (void)names_; (void)contact_names_; (void)avoided_frames_;              \
+    (void)contact_frame_; (void)contact_ref_; (void)avoided_r0_; (void)contact_kp_; (void)contact_kd_;
+
+
         public:
             // q0: the configuration the task references are initialised at (the controller's ref_config, pos_tracker.cpp:60-67)
             ModelSource(const std::shared_ptr<robots::RobotWrapper>& robot, int batch, const std::vector<double>& q0)
@@ -30,6 +49,14 @@ namespace inria_wbc {
             {
                 handle_ = h;
                 slot_ = slot;
+                auto known = bounds_.find(slot);
+                if (known != bounds_.end()) {
+                    cur_ = &known->second;
+                    refresh(*cur_);
+                    return;
+                }
+                cur_ = &bounds_[slot];
+                IWBC_BOUND_ALIASES(*cur_)
                 const int na = robot_->na();
                 IWBC_ASSERT(stack.nv() == robot_->nv() && stack.na() == na, "task stack and robot disagree on nv / na");
                 tasks_.clear(); avoided_frames_.clear(); avoided_r0_.clear(); names_.clear();
@@ -161,8 +188,17 @@ namespace inria_wbc {
                     for (int d = 0; d < 3; ++d) com_pos_(i, d) = c0[d];
             }
 
+            // the controller re-set the structure of a slot (wbcqp_set_structure drops the model): build again on the next bind
+            void forget(int slot)
+            {
+                if (cur_ && bounds_.count(slot) && cur_ == &bounds_[slot]) cur_ = nullptr;
+                bounds_.erase(slot);
+            }
+
             void compute(double, const MatrixXd& q, const MatrixXd& v, const tasks::TaskStack& stack, const wbcqp_layout& L, TickInputs& in) override
             {
+                IWBC_ASSERT(cur_, "ModelSource is not bound to a solver");
+                IWBC_BOUND_ALIASES(*cur_)
                 IWBC_ASSERT(handle_, "ModelSource is not bound to a solver");
                 IWBC_ASSERT(q.rows == batch_ && q.cols == robot_->nq() && v.rows == batch_ && v.cols == robot_->nv(), "one state row per instance");
                 wbcqp_state st = {q.data.data(), v.data.data(), ref_.data()};
@@ -184,11 +220,13 @@ namespace inria_wbc {
                         in.tub[(size_t)i * L.len_tub + j] = tmax[j];
                     }
             }
-            const double* reference_data() const override { return ref_.data(); }
+            const double* reference_data() const override { return cur_ ? cur_->ref_.data() : nullptr; }
             void com(MatrixXd& pos, MatrixXd& vel) const override { pos = com_pos_; vel = com_vel_; }
 
             void set_com_ref(const TrajectorySample& s) override
             {
+                IWBC_ASSERT(cur_, "ModelSource is not bound to a solver");
+                IWBC_BOUND_ALIASES(*cur_)
                 for (size_t i = 0; i < tasks_.size(); ++i)
                     if (tasks_[i].kind == WBCQP_T_COM) {
                         std::vector<double> r(9);
@@ -199,6 +237,8 @@ namespace inria_wbc {
             // sample.pos: 12 numbers (translation, rotation column-major), vel / acc: 6 each (PosTracker::set_se3_ref, pos_tracker.cpp:221-237)
             void set_se3_ref(const std::string& name, const TrajectorySample& s) override
             {
+                IWBC_ASSERT(cur_, "ModelSource is not bound to a solver");
+                IWBC_BOUND_ALIASES(*cur_)
                 for (size_t i = 0; i < tasks_.size(); ++i)
                     if (names_[i] == name && tasks_[i].kind == WBCQP_T_SE3) {
                         IWBC_ASSERT(s.pos.size() == 12 && s.vel.size() == 6 && s.acc.size() == 6, "an SE3 sample holds 12 + 6 + 6 numbers");
@@ -212,6 +252,8 @@ namespace inria_wbc {
             }
             std::vector<double> get_se3_ref(const std::string& name) const override
             {
+                IWBC_ASSERT(cur_, "ModelSource is not bound to a solver");
+                IWBC_BOUND_ALIASES(*cur_)
                 for (size_t i = 0; i < tasks_.size(); ++i)
                     if (names_[i] == name && tasks_[i].kind == WBCQP_T_SE3) return std::vector<double>(ref_.begin() + tasks_[i].ref, ref_.begin() + tasks_[i].ref + 12);
                 IWBC_ERROR("Task [", name, "] not found");
@@ -219,6 +261,8 @@ namespace inria_wbc {
             // PosTracker::set_contact_se3_ref (pos_tracker.cpp:227-232): kept for contacts that are currently removed too
             void set_contact_se3_ref(const std::string& name, const std::vector<double>& sample) override
             {
+                IWBC_ASSERT(cur_, "ModelSource is not bound to a solver");
+                IWBC_BOUND_ALIASES(*cur_)
                 IWBC_ASSERT(sample.size() == 12 || sample.size() == 24, "a contact reference holds 12 numbers (placement) or 24 (with velocity and acceleration)");
                 std::vector<double> pose(sample);
                 pose.resize(24, 0.0); // to_sample(SE3): zero derivatives (pos_tracker.cpp:227-232)
@@ -229,28 +273,48 @@ namespace inria_wbc {
             }
             void set_posture_ref(const std::vector<double>& q_actuated) override
             {
+                IWBC_ASSERT(cur_, "ModelSource is not bound to a solver");
+                IWBC_BOUND_ALIASES(*cur_)
                 IWBC_ASSERT((int)q_actuated.size() == robot_->na(), "the posture reference holds na entries");
                 posture_user_ = q_actuated;
                 for (int i = 0; i < batch_; ++i) std::copy(q_actuated.begin(), q_actuated.end(), ref_.begin() + (size_t)i * nref_ + posture_ref_);
             }
-            const std::vector<double>& references() const { return ref_; }
-            int nref() const { return nref_; }
+            const std::vector<double>& references() const { return cur_->ref_; }
+            int nref() const { return cur_ ? cur_->nref_ : 0; }
 
         private:
             void store(const std::string& name, int off, const std::vector<double>& r)
             {
+                IWBC_ASSERT(cur_, "ModelSource is not bound to a solver");
+                IWBC_BOUND_ALIASES(*cur_)
                 named_[name] = r;
                 for (int i = 0; i < batch_; ++i) std::copy(r.begin(), r.end(), ref_.begin() + (size_t)i * nref_ + off);
             }
 
+            // a slot seen before: nothing goes to the device, the references set meanwhile are laid out for this stack
+            void refresh(Bound& b)
+            {
+                IWBC_BOUND_ALIASES(b)
+                auto put = [&](int off, const std::vector<double>& r) {
+                    for (int i = 0; i < batch_; ++i) std::copy(r.begin(), r.end(), ref_.begin() + (size_t)i * nref_ + off);
+                };
+                for (size_t i = 0; i < tasks_.size(); ++i) {
+                    auto it = named_.find(names_[i]);
+                    if (it != named_.end() && tasks_[i].kind != WBCQP_T_SELFCOLLISION) put(tasks_[i].ref, it->second);
+                }
+                for (size_t c = 0; c < contact_names_.size(); ++c) {
+                    auto it = named_.find(contact_names_[c]);
+                    if (it != named_.end()) put(contact_ref_[c], it->second);
+                }
+                if (!posture_user_.empty()) put(posture_ref_, posture_user_);
+            }
+
             std::shared_ptr<robots::RobotWrapper> robot_;
-            int batch_ = 0, slot_ = 0, nref_ = 0, posture_ref_ = 0;
-            std::vector<double> q0_, ref_, posture_user_;
+            int batch_ = 0, slot_ = 0;
+            std::vector<double> q0_, posture_user_;
             wbcqp_handle* handle_ = nullptr;
-            std::vector<wbcqp_task> tasks_;
-            std::vector<std::string> names_, contact_names_;
-            std::vector<int32_t> avoided_frames_, contact_frame_, contact_ref_;
-            std::vector<double> avoided_r0_, contact_kp_, contact_kd_;
+            std::map<int, Bound> bounds_;
+            Bound* cur_ = nullptr;
             std::map<std::string, std::vector<double>> named_;
             MatrixXd com_pos_, com_vel_;
         };

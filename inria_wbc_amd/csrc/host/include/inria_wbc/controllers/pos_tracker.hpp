@@ -185,14 +185,27 @@ namespace inria_wbc {
                 }
             }
 
+            // One library slot per set of active contacts: the first time a set is seen its structure goes to the device (the
+            // analogue of solver_->resize(nVar, nEq, nIn), pos_tracker.cpp:102, which tsid repeats on every contact change);
+            // coming back to a set seen before costs nothing on the device.
             void _install_stack()
             {
-                wbcqp_structure s = stack_.c_struct();
-                // the analogue of solver_->resize(nVar, nEq, nIn) (pos_tracker.cpp:102)
-                int rc = wbcqp_set_structure(handle_, 0, &s);
-                if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_set_structure failed: ", wbcqp_last_error(handle_));
-                rc = wbcqp_layout_of(&s, &layout_);
-                if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_layout_of failed");
+                std::string key;
+                for (const auto& c : stack_.contacts()) key += c.name + ";";
+                auto known = slots_.find(key);
+                if (known == slots_.end()) {
+                    const int slot = (int)slots_.size();
+                    IWBC_ASSERT(slot < WBCQP_MAX_STRUCTURES, "more contact sets than the library has slots");
+                    wbcqp_structure s = stack_.c_struct();
+                    int rc = wbcqp_set_structure(handle_, slot, &s);
+                    if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_set_structure failed: ", wbcqp_last_error(handle_));
+                    wbcqp_layout L;
+                    rc = wbcqp_layout_of(&s, &L);
+                    if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_layout_of failed");
+                    known = slots_.emplace(key, std::make_pair(slot, L)).first;
+                }
+                slot_ = known->second.first;
+                layout_ = known->second.second;
                 std::vector<double> w = stack_.default_weights();
                 if (!weights_.empty()) // keep user-updated weights across a contact switch, by name
                     for (size_t i = 0; i < w.size(); ++i)
@@ -203,7 +216,7 @@ namespace inria_wbc {
                 activated_contacts_.clear();
                 for (const auto& c : stack_.contacts()) activated_contacts_.push_back(c.name);
                 if (all_contacts_.empty()) all_contacts_ = activated_contacts_;
-                if (source_ && source_->handles_references()) source_->bind(handle_, 0, stack_, dt_); // set_structure dropped the model
+                if (source_ && source_->handles_references()) source_->bind(handle_, slot_, stack_, dt_);
             }
 
             void _reset() override
@@ -216,7 +229,7 @@ namespace inria_wbc {
                 }
                 else if (floating_base_)
                     for (int i = 0; i < batch_; ++i) q_tsid_(i, 6) = 1.0; // unit quaternion
-                if (source_->handles_references()) source_->bind(handle_, 0, stack_, dt_);
+                if (source_->handles_references()) source_->bind(handle_, slot_, stack_, dt_);
                 v_tsid_ = MatrixXd(batch_, nv);
                 a_tsid_ = MatrixXd(batch_, nv);
                 MatrixXd cp, cv;
@@ -256,7 +269,7 @@ namespace inria_wbc {
                 }
             }
             const tasks::TaskStack& _stack() const override { return stack_; }
-            int _slot() const override { return 0; }
+            int _slot() const override { return slot_; }
             const wbcqp_layout& _layout() const override { return layout_; }
 
         public:
@@ -276,6 +289,8 @@ namespace inria_wbc {
             TrajectorySample com_ref_{3};
             bool com_ref_set_ = false;
             std::vector<double> com_init_, q0_;
+            std::map<std::string, std::pair<int, wbcqp_layout>> slots_; // active-contact set -> (library slot, layout)
+            int slot_ = 0;
             std::shared_ptr<robots::RobotWrapper> robot_;
             std::map<std::string, TrajectorySample> se3_refs_;
         };
