@@ -318,6 +318,7 @@ namespace inria_wbc {
             std::map<std::string, std::vector<double>> named_;
             MatrixXd com_pos_, com_vel_;
         };
+#undef IWBC_BOUND_ALIASES
     } // namespace controllers
 } // namespace inria_wbc
 #endif
