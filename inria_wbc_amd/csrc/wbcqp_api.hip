@@ -639,7 +639,10 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
         const int cnt = (md->jtype[i] == WBCQP_J_FREEFLYER) ? 6 : 1;
         for (int k = 0; k < cnt; ++k) { bodyof[idxv[i] + k] = i; kof[idxv[i] + k] = k; }
     }
-    auto frame_ok = [&](int f) { return f >= 0 && f < md->nframe && md->frame_body[f] >= 0 && md->frame_body[f] < nb; };
+    if (md->nframe < 0 || (md->nframe > 0 && (!md->frame_body || !md->frame_placement))) return fail(h, WBCQP_ERR_INVALID, "bad frame tables");
+    for (int f = 0; f < md->nframe; ++f)
+        if (md->frame_body[f] < 0 || md->frame_body[f] >= nb) return fail(h, WBCQP_ERR_INVALID, "a frame hangs on a body that does not exist");
+    auto frame_ok = [&](int f) { return f >= 0 && f < md->nframe; };
     // tasks -> law lanes (SE3 blocks then contacts), self-collision pairs, blocks
     std::vector<int> law_body, law_mask, law_row, law_ref, law_va, law_contact, pair_bt, pair_ba;
     std::vector<int> blk_kind, blk_mask, blk_row, blk_ref, blk_pair0, blk_npair;

@@ -249,3 +249,30 @@ def test_problem_data_minimal_stack(handle, rbd):
     got = handle.solve_batch_host(6, dict(dev, tlb=np.zeros((B, 0)), tub=np.zeros((B, 0)), w=np.tile(st.default_weights, (B, 1))))
     ref = orc.tick_batch(st, dict(ora, tlb=np.zeros((B, 0)), tub=np.zeros((B, 0)), w=np.tile(st.default_weights, (B, 1))))
     assert (got["status"] == 0).all() and np.abs(got["x"] - ref["x"]).max() <= 1e-8 * max(1.0, np.abs(ref["x"]).max())
+
+
+def test_set_model_rejects_bad_tables(handle):
+    """Every table that indexes another one is checked before anything goes to the device: an error code, not a fault."""
+    import copy
+    m, st, tm = CASES["talos"]()
+    handle.set_structure(7, st)
+
+    def expect_refusal(mutate_model=None, mutate_map=None):
+        mm, tt = copy.deepcopy(m), copy.deepcopy(tm)
+        if mutate_model:
+            mutate_model(mm)
+        if mutate_map:
+            mutate_map(tt)
+        with pytest.raises(capi.WbcqpError):
+            handle.set_model(7, mm, tt)
+
+    expect_refusal(mutate_map=lambda t: setattr(t.blocks[3], "frame", m.nframe + 5))          # tracked frame out of range
+    expect_refusal(mutate_map=lambda t: t.blocks[-1].avoided.__setitem__(0, (-1, 0.1)))       # avoided frame out of range
+    expect_refusal(mutate_map=lambda t: setattr(t, "dt", 0.0))                                # no time step
+    expect_refusal(mutate_map=lambda t: t.contact_ref.__setitem__(1, t.nref - 3))             # contact sample past the end
+    expect_refusal(mutate_map=lambda t: setattr(t, "posture_ref", t.nref))                    # posture reference past the end
+    expect_refusal(mutate_map=lambda t: setattr(t.blocks[-1], "m", 0.0))                      # 5PL exponent must be positive
+    expect_refusal(mutate_map=lambda t: t.blocks.pop(0))                                      # rows no longer add up to n_dense
+    expect_refusal(mutate_model=lambda x: x.jtype.__setitem__(5, 9))                          # unknown joint type
+    expect_refusal(mutate_model=lambda x: x.frame_body.__setitem__(2, 99))                    # frame on a body that does not exist
+    handle.set_model(7, m, tm)  # and the untouched pair is accepted
