@@ -283,6 +283,10 @@ typedef struct {
  * n_sel, n_bound).  A later wbcqp_set_structure on the slot drops the model with the old structure: bind it again (a
  * contact added or removed changes both, pos_tracker.cpp:246-263). */
 int wbcqp_set_model(wbcqp_handle* handle, int slot, const wbcqp_model* model, const wbcqp_taskmap* map);
+/* The checks of wbcqp_set_model without a device (pure host computation, like wbcqp_layout_of): is this tree + these task
+ * bindings a valid companion of that structure, and how much LDS does one instance of the rows kernel need.  Error text through
+ * wbcqp_last_error(NULL). */
+int wbcqp_check_model(const wbcqp_structure* st, const wbcqp_model* model, const wbcqp_taskmap* map, int32_t* lds_bytes);
 /* Writes the M, h, A, b1, Ac, bc, blb, bub arrays of `rows` (DEVICE pointers, the layout wbcqp_solve_batch reads; tlb, tub
  * and w are not touched: constant limits and weights) for `batch` instances.  Asynchronous on `stream`. */
 int wbcqp_problem_data(wbcqp_handle* handle, int slot, int batch, const wbcqp_state* state, const wbcqp_inputs* rows,

@@ -24,7 +24,7 @@ FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
 # every symbol include/wbcqp.h declares
 EXPORTS = ("wbcqp_version", "wbcqp_last_error", "wbcqp_create", "wbcqp_destroy", "wbcqp_set_structure",
            "wbcqp_layout_of", "wbcqp_solve_batch", "wbcqp_solve_batch_host", "wbcqp_solve_ragged",
-           "wbcqp_allgather_tau", "wbcqp_integrate", "wbcqp_integrate_host", "wbcqp_set_model", "wbcqp_problem_data",
+           "wbcqp_allgather_tau", "wbcqp_integrate", "wbcqp_integrate_host", "wbcqp_set_model", "wbcqp_check_model", "wbcqp_problem_data",
            "wbcqp_problem_data_host", "wbcqp_tick", "wbcqp_tick_host", "wbcqp_tick_graph_create", "wbcqp_tick_graph_launch", "wbcqp_tick_graph_destroy",
            "wbcqp_sync")
 ROW_FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub")  # what wbcqp_problem_data writes
@@ -134,6 +134,7 @@ def load_library(path: Optional[str] = None):
     lib.wbcqp_integrate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.wbcqp_set_model.argtypes = [C.c_void_p, C.c_int, C.POINTER(CModel), C.POINTER(CTaskMap)]
+    lib.wbcqp_check_model.argtypes = [C.POINTER(CStructure), C.POINTER(CModel), C.POINTER(CTaskMap), C.POINTER(C.c_int32)]
     lib.wbcqp_problem_data.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CState), C.POINTER(CInputs), C.c_void_p]
     lib.wbcqp_problem_data_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CState), C.POINTER(CInputs)]
     lib.wbcqp_tick.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CTickIO), C.c_void_p]
@@ -238,6 +239,18 @@ def layout_of(st: Structure) -> Dict[str, int]:
     if rc != WBCQP_OK:
         raise WbcqpError(rc, (lib.wbcqp_last_error(None) or b"").decode())
     return {k: getattr(L, k) for k, _ in CLayout._fields_}
+
+
+def check_model(st: Structure, model, tm) -> int:
+    """wbcqp_check_model: validates (structure, tree, task bindings) on the host -- no GPU needed -- and returns the LDS bytes one
+    instance of the rows kernel needs.  Raises WbcqpError with the library's message otherwise."""
+    lib = load_library()
+    sb, mb = StructureBuffers(st), ModelBuffers(model, tm)
+    lds = C.c_int32(0)
+    rc = lib.wbcqp_check_model(C.byref(sb.c), C.byref(mb.model), C.byref(mb.taskmap), C.byref(lds))
+    if rc != WBCQP_OK:
+        raise WbcqpError(rc, (lib.wbcqp_last_error(None) or b"").decode())
+    return int(lds.value)
 
 
 FLAG_INDEX_ORDER = 1  # wbcqp_desc.flags: launch in index order (default: longest-first, see include/wbcqp.h)

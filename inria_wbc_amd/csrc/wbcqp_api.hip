@@ -599,13 +599,12 @@ int wbcqp_integrate_host(wbcqp_handle* h, int batch, int nv, int floating_base, 
     return WBCQP_OK;
 }
 
-int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcqp_taskmap* tm)
+// Validates a tree + task bindings against a structure and derives the rows kernel's tables and LDS layout.  Pure host code
+// (wbcqp_check_model runs it without a device; wbcqp_set_model uploads what it returns).
+static int derive_terms(wbcqp_handle* h, const DevStruct& D, const wbcqp_model* md, const wbcqp_taskmap* tm, TermsDev& T,
+                        std::vector<int>& ipool, std::vector<double>& dpool)
 {
-    if (!h) return WBCQP_ERR_INVALID;
-    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES || !h->slots[slot].set) return fail(h, WBCQP_ERR_INVALID, "slot has no structure");
     if (!md || !tm) return fail(h, WBCQP_ERR_INVALID, "model / taskmap is NULL");
-    Slot& s = h->slots[slot];
-    const DevStruct& D = s.host;
     const int nb = md->nbody, fb = md->floating_base ? 1 : 0;
     if (nb <= 0 || !md->parent || !md->jtype || !md->placement || !md->inertia) return fail(h, WBCQP_ERR_INVALID, "empty model");
     if (nb > kWave) return fail(h, WBCQP_ERR_UNSUPPORTED, "more than 64 bodies (one lane per body)");
@@ -708,7 +707,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     if (D.n_sel > 0 && (tm->posture_ref < 0 || tm->posture_ref + na > tm->nref)) return fail(h, WBCQP_ERR_INVALID, "the posture reference lies outside the reference vector");
     if (D.n_bound > 0 && (!md->q_lb || !md->q_ub || !md->dq_max)) return fail(h, WBCQP_ERR_INVALID, "bounds need q_lb / q_ub / dq_max");
 
-    TermsDev T{};
+    T = TermsDev{};
     T.nb = nb; T.nq = nq; T.nv = nv; T.na = na; T.floating_base = fb;
     int nrounds = 0;
     while ((1 << nrounds) < maxdepth + 1) ++nrounds;
@@ -724,8 +723,8 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     T.n_dense = D.n_dense; T.n_sel = D.n_sel; T.n_bound = D.n_bound; T.r1 = D.r1; T.nref = tm->nref;
     T.posture_ref = tm->posture_ref; T.posture_kp = tm->posture_kp; T.posture_kd = tm->posture_kd; T.dt = tm->dt;
     for (int k = 0; k < 3; ++k) T.g[k] = md->gravity[k];
-    std::vector<int> ipool;
-    std::vector<double> dpool;
+    ipool.clear();
+    dpool.clear();
     auto puti = [&](const int* a, size_t n) { int at = (int)ipool.size(); ipool.insert(ipool.end(), a, a + n); ipool.push_back(0); return at; };
     auto putd = [&](const double* a, size_t n) { int at = (int)dpool.size(); dpool.insert(dpool.end(), a, a + n); dpool.push_back(0.0); return at; };
     std::vector<int> sel(D.n_sel);
@@ -769,6 +768,36 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     T.o_bc = take(6 * D.nc);
     T.lds_doubles = o;
     if ((size_t)o * 8 > 160 * 1024) return fail(h, WBCQP_ERR_UNSUPPORTED, "the working set of one instance exceeds the LDS");
+    return WBCQP_OK;
+}
+
+int wbcqp_check_model(const wbcqp_structure* st, const wbcqp_model* md, const wbcqp_taskmap* tm, int32_t* lds_bytes)
+{
+    DevStruct D;
+    HostBlocks HB;
+    wbcqp_layout L;
+    std::string why;
+    int rc = derive(st, D, HB, L, why);
+    if (rc != WBCQP_OK) return fail(nullptr, rc, why);
+    TermsDev T{};
+    std::vector<int> ipool;
+    std::vector<double> dpool;
+    rc = derive_terms(nullptr, D, md, tm, T, ipool, dpool);
+    if (rc == WBCQP_OK && lds_bytes) *lds_bytes = T.lds_doubles * 8;
+    return rc;
+}
+
+int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcqp_taskmap* tm)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES || !h->slots[slot].set) return fail(h, WBCQP_ERR_INVALID, "slot has no structure");
+    Slot& s = h->slots[slot];
+    TermsDev T{};
+    std::vector<int> ipool;
+    std::vector<double> dpool;
+    int rc = derive_terms(h, s.host, md, tm, T, ipool, dpool);
+    if (rc != WBCQP_OK) return rc;
+    const int o = T.lds_doubles;
     HIP_TRY(h, hipSetDevice(h->device));
     release_model(s);
     void *di = nullptr, *dd = nullptr;

@@ -123,3 +123,34 @@ def test_synthetic_batches_are_feasible_and_order_independent():
     rows = np.where(st.dense_row_task == st.task_names.index("com"))[0]
     d = sq["b1"][:, rows] - pl["b1"][:, rows]
     assert np.allclose(d[0], synth.squat_com_rhs(st, 1000, 30.0)) and abs(d[0, 2]) > 0 and d[0, 0] == 0
+
+
+def test_check_model_on_the_host(built_lib):
+    """wbcqp_check_model: the validation wbcqp_set_model applies, without a device -- the shipped stacks pass and size their LDS,
+    broken tables are refused with a message."""
+    import copy
+    from inria_wbc_amd import capi, structure
+    from inria_wbc_amd import model as mdl
+    for m, st, stack in ((mdl.talos_like(), structure.talos_structure(), mdl.talos_stack()), (mdl.icub_like(), structure.icub_structure(), mdl.icub_stack()),
+                         (mdl.franka_like(), structure.franka_structure(), mdl.franka_stack())):
+        lds = capi.check_model(st, m, mdl.build_taskmap(m, st, stack))
+        assert 1024 < lds < 40 * 1024, lds  # four workgroups per CU need less than 40 KB each
+    m, st = mdl.talos_like(), structure.talos_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    cases = [
+        (lambda mm, tt: setattr(tt.blocks[3], "frame", m.nframe + 5), "does not exist"),
+        (lambda mm, tt: setattr(tt, "dt", 0.0), "bad taskmap"),
+        (lambda mm, tt: tt.blocks.pop(0), "n_dense"),
+        (lambda mm, tt: mm.jtype.__setitem__(5, 9), "joint type"),
+        (lambda mm, tt: mm.parent.__setitem__(20, 3), "depth-first"),
+        (lambda mm, tt: mm.frame_body.__setitem__(2, 99), "does not exist"),
+        (lambda mm, tt: setattr(tt, "posture_ref", tt.nref), "posture reference"),
+    ]
+    for mutate, text in cases:
+        mm, tt = copy.deepcopy(m), copy.deepcopy(tm)
+        mutate(mm, tt)
+        with pytest.raises(capi.WbcqpError) as e:
+            capi.check_model(st, mm, tt)
+        assert text in str(e.value), (text, str(e.value))
+    with pytest.raises(capi.WbcqpError):
+        capi.check_model(structure.icub_structure(), m, tm)  # another robot's structure
