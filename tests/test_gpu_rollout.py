@@ -187,3 +187,29 @@ def test_tick_f32_boundary_stays_close_to_f64():
     assert np.abs(a["x"][:, :nv] - b["x"][:, :nv]).max() / scale_dv < 1e-3
     assert np.abs(a["tau"] - b["tau"]).max() / scale_tau < 1e-3
     assert np.abs(a["q"] - b["q"]).max() < 1e-5
+
+
+def test_tick_keeps_the_state_of_an_instance_whose_qp_fails():
+    """One robot of the batch gets torque limits that contradict each other (lower above upper): its QP is infeasible, the tick
+    reports that status for it
+    (the reference throws there, controller.cpp:284-307) and leaves ITS state where it was; the others go on."""
+    import torch
+    m = mdl.talos_like()
+    st = structure.talos_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    B, bad = 8, 5
+    dev = torch.device("cuda", 0)
+    h = capi.Handle(0, capi.F64)
+    h.set_structure(0, st)
+    h.set_model(0, m, tm)
+    state, rows, out, qn, vn = _tick_buffers(m, st, tm, B, 95_000, dev, torch)
+    rows["tlb"][bad] = 1.0
+    rows["tub"][bad] = -1.0
+    h.tick(0, B, state, rows, out, qn, vn, tm.dt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    status = out["status"].cpu().numpy()
+    assert status[bad] != 0 and (np.delete(status, bad) == 0).all(), status
+    assert torch.equal(qn[bad], state["q"][bad]) and torch.equal(vn[bad], state["v"][bad])
+    others = [i for i in range(B) if i != bad]
+    assert not torch.equal(qn[others], state["q"][others])
+    h.close()
