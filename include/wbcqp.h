@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define WBCQP_VERSION 100 /* 0.1.0 */
+#define WBCQP_VERSION 120 /* 0.1.2: + wbcqp_integrate (0.1.1), wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions (0.1.2) */
 #define WBCQP_MAX_STRUCTURES 16
 #define WBCQP_MAX_INEQ_BLOCKS 16
 #define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: every per-QP vector fits one 128-entry LDS slot, n + 2 <= 128 */
