@@ -680,7 +680,7 @@ def sample_states(model: Model, tm: TaskMap, batch: int, seed: int, q_noise: flo
     return dict(q=q, v=v, ref=ref)
 
 
-def random_stack(model: Model, seed: int) -> Tuple[Structure, List[dict]]:
+def random_stack(model: Model, seed: int, n_contacts: int = 2) -> Tuple[Structure, List[dict]]:
     """A task stack over `model`'s frames that uses every kind of task with random masks and gains (stress input for the
     parity tests; not a shipped inria_wbc stack)."""
     from . import structure as S
@@ -705,7 +705,7 @@ def random_stack(model: Model, seed: int) -> Tuple[Structure, List[dict]]:
     contacts = []
     if model.floating_base:
         pts = S.contact6d_points(lxn=0.06, lyn=0.045, lxp=0.14, lyp=0.045, lz=0.065)
-        for c in range(2):
+        for c in range(n_contacts):
             contacts.append(S.Contact("contact_%d" % c, pts, (0.0, 0.0, 1.0), 0.4, 5.0, 1200.0))
             stack.append(dict(name="contact_%d" % c, type="contact", joint=fr(), kp=30.0))
         dense.append(("__contacts__",))

@@ -36,14 +36,27 @@ def _cases():
         st = structure.icub_structure()
         return m, st, mdl.build_taskmap(m, st, mdl.icub_stack())
 
-    def tree(seed, nb, fb):
+    def tree(seed, nb, fb, n_contacts=2):
         def f():
             m = mdl.random_tree(seed, nb, fb, nframe=12)
-            st, stack = mdl.random_stack(m, seed + 100)
+            st, stack = mdl.random_stack(m, seed + 100, n_contacts)
             return m, st, mdl.build_taskmap(m, st, stack, dt=2e-3)
         return f
 
-    return {"talos": talos, "talos_single_support": talos_ss, "icub": icub, "franka": franka, "tree_fb": tree(21, 30, True), "tree_fixed": tree(22, 19, False), "tree_big": tree(23, 62, False)}
+    def three_limbs():
+        """A floating base with three chains of seven joints and a contact at the end of each: the contact Jacobians are
+        independent (six joints and more between any two contact frames), so the 24 equalities have full rank."""
+        m = mdl.random_tree(24, 22, True, nframe=12)
+        m.parent = np.array([-1] + [0 if k % 7 == 0 else 1 + k - 1 for k in range(21)], dtype=np.int32)
+        m.frame_body[0:3] = [7, 14, 21]
+        m.validate()
+        st, stack = mdl.random_stack(m, 124, 3)
+        for node in stack:
+            if node["type"] == "contact":
+                node["joint"] = "f%d" % int(node["name"][-1])
+        return m, st, mdl.build_taskmap(m, st, stack, dt=2e-3)
+
+    return {"talos": talos, "talos_single_support": talos_ss, "icub": icub, "franka": franka, "tree_fb": tree(21, 30, True), "tree_fixed": tree(22, 19, False), "tree_big": tree(23, 62, False), "tree_three_contacts": three_limbs}
 
 
 CASES = _cases()
@@ -276,3 +289,25 @@ def test_set_model_rejects_bad_tables(handle):
     expect_refusal(mutate_model=lambda x: x.jtype.__setitem__(5, 9))                          # unknown joint type
     expect_refusal(mutate_model=lambda x: x.frame_body.__setitem__(2, 99))                    # frame on a body that does not exist
     handle.set_model(7, m, tm)  # and the untouched pair is accepted
+
+
+def test_three_contacts_rows_then_solve(handle, rbd):
+    """An odd number of contacts (24 equalities: the solver's sequential equality path) with rows from a random tree: rows kernel,
+    then the QP, against the oracle pipeline."""
+    from oracle import oracle as orc
+    m, st, tm = CASES["tree_three_contacts"]()
+    assert st.nc == 3 and st.neq == 24
+    handle.set_structure(8, st)
+    handle.set_model(8, m, tm)
+    B = 24
+    s = mdl.sample_states(m, tm, B, 36_000, q_noise=0.02, v_noise=0.05, ref_noise=0.01)
+    dev = handle.problem_data_host(8, s["q"], s["v"], s["ref"])
+    ora = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"], n_threads=4)
+    _compare(dev, ora)
+    extra = dict(tlb=np.zeros((B, 0)), tub=np.zeros((B, 0)), w=np.tile(st.default_weights, (B, 1)))
+    got = handle.solve_batch_host(8, dict(dev, **extra))
+    ref = orc.tick_batch(st, dict(ora, **extra), nthreads=4)
+    assert np.array_equal(got["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert ok.sum() >= B // 2  # random contact frames on a random tree: some instances may be infeasible, the statuses must agree
+    assert np.abs(got["x"][ok][:, :m.nv] - ref["x"][ok][:, :m.nv]).max() <= 1e-7 * max(1.0, np.abs(ref["x"][ok]).max())
