@@ -24,6 +24,15 @@ def test_facade_cpu_checks(host_build, tmp_path):
     assert "OK (0 failures)" in r.stdout
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/etc"), reason="the reference tree is not on this machine")
+def test_facade_reads_the_references_own_task_files(host_build, tmp_path):
+    """the YAML-subset reader and TaskStack on the reference's OWN etc/<robot>/tasks.yaml files (comments,
+    indentation and key order as shipped) give the sizes of SURVEY Appendix B.  CPU only, and only where /root/reference exists."""
+    r = subprocess.run([host_build["test_facade"], "/root/reference/etc", str(tmp_path), "stacks-only"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK (0 failures)" in r.stdout
+
+
 def test_hip_batched_solver_refuses_without_gpu(host_build, tmp_path):
     import torch
     if torch.cuda.is_available():
