@@ -35,8 +35,8 @@ ALGORITHMIC_BYTES = {"talos": 35152, "icub": 23872, "franka": 1152}
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--batch", type=int, default=1024, help="QPs per GPU per step")
     p.add_argument("--robot", default="talos", choices=["talos", "icub", "franka"])
     p.add_argument("--squat", action="store_true", help="CoM reference follows etc/talos/squat.yaml (BASELINE config 4)")
@@ -44,7 +44,7 @@ def parse():
                    help="N > 1: also all-gather the joint torques over RCCL inside every step (BASELINE config 4's optional\n"
                         "exchange; the path itself has none -- the QPs of a batch are independent)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-compare", action="store_true", help="skip the extra index-order run reported beside `value`")
+    p.add_argument("--no-compare", action="store_true", help="skip the extra index-order and hardware-dispatch runs reported beside `value`")
     p.add_argument("--index-order", action="store_true",
                    help="launch the QPs in index order instead of longest-first (WBCQP_FLAG_INDEX_ORDER)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
@@ -178,22 +178,24 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # one HIP event pair over the timed region, on the stream the kernels are launched on: per-launch duration = region / K
+    # (it includes the two order kernels of every 4th step).  Not one pair per step: measured with rocprofv3, every event
+    # record left a 10 us bubble in front of the next solve kernel -- 3.5 % of a step spent on the measurement itself.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
-        ev[i][0].record()
         h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
-        ev[i][1].record()
         if gather_state["ok"]:
             dist.all_gather_into_tensor(tau_all, d_out["tau"])
+    ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    kern_avg_s = float(np.mean(kernel_ms)) * 1e-3
+    kern_avg_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
 
     status = d_out["status"].cpu().numpy()
     iters = d_out["iters"].cpu().numpy()
@@ -223,12 +225,12 @@ def main():
             "config": {"workload": "%s_pos_tracker%s_b%d_fp64_one_workgroup_per_qp" % (args.robot, "_squat" if args.squat else "", B),
                        "batch_per_gpu": B, "n": st.n, "neq": st.neq, "nin": st.nin, "level1_rows": st.r1,
                        "parallelism": "batch-shard x%d" % world,
-                       "schedule": "index-order" if args.index_order else "longest-first (iteration counts of the previous step)",
+                       "schedule": "index-order" if args.index_order else "queue of resident workgroups; order bin-packed from the iteration counts of an earlier step, renewed every 4th launch",
                        "allgather_tau": bool(gather_state["ok"]), "lds_bytes_per_qp": layout["lds_bytes"],
                        "qps_resident_per_cu": layout["waves_per_cu"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "wbcqp::solve_kernel<double>", "kernel_ms": kern_avg_s * 1e3,
+                         "kernel": "wbcqp::solve_queue_kernel<double>", "kernel_ms": kern_avg_s * 1e3,
                          "algorithmic_bytes_per_qp": abytes},
             "active_set": {"iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
                            "iters_hist": np.bincount(np.minimum(iters, 15), minlength=16).tolist(),
@@ -267,19 +269,26 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result["before_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.index_order and not args.no_compare:
-            # the same K steps with the launch in plain index order (WBCQP_FLAG_INDEX_ORDER), reported beside `value`
-            h2 = capi.Handle(device=local_rank, dtype=capi.F64, flags=capi.FLAG_INDEX_ORDER)
-            h2.set_structure(0, st)
-            for _ in range(args.warmup):
-                h2.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                h2.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-            result["index_order"] = {"value": B * args.steps / (time.perf_counter() - t1), "unit": "QP/s",
-                                     "note": "same batch, QPs launched in index order (no schedule from the previous step)"}
-            h2.close()
+            # the same K steps (a) in plain index order, (b) longest-first but one workgroup per QP through the hardware's
+            # dispatcher instead of resident workgroups and a queue -- both reported beside `value`
+            for key, flags, note in (
+                    ("index_order", capi.FLAG_INDEX_ORDER, "same batch, QPs taken in index order (no schedule from the previous step)"),
+                    ("hw_dispatch", capi.FLAG_HW_DISPATCH, "same batch, longest-first, one workgroup per QP dealt out by the hardware "
+                                                           "(XCD i % 8, shader engine (i / 8) % 4, in order) instead of the queue"),
+                    ("queue_longest_first", capi.FLAG_NO_PACKING, "same batch, queue, plain longest-first order (no bin packing)"),
+                    ("refresh_every_launch", capi.flag_refresh(1), "same batch, queue, packed order renewed after every launch "
+                                                                    "(default: every 4th, WBCQP_FLAG_REFRESH)")):
+                h2 = capi.Handle(device=local_rank, dtype=capi.F64, flags=flags)
+                h2.set_structure(0, st)
+                for _ in range(args.warmup):
+                    h2.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    h2.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                result[key] = {"value": B * args.steps / (time.perf_counter() - t1), "unit": "QP/s", "note": note}
+                h2.close()
 
         if not args.no_cpu_baseline and world == 1:
             # the oracle is the checker here and the reported CPU baseline -- never the thing shipped

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define WBCQP_VERSION 120 /* 0.1.2: + wbcqp_integrate (0.1.1), wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions (0.1.2) */
+#define WBCQP_VERSION 121 /* 0.1.2: + wbcqp_integrate (0.1.1), wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions (0.1.2); 121: queue + packed launch order, wbcqp_launch_order */
 #define WBCQP_MAX_STRUCTURES 16
 #define WBCQP_MAX_INEQ_BLOCKS 16
 #define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: every per-QP vector fits one 128-entry LDS slot, n + 2 <= 128 */
@@ -148,6 +148,19 @@ typedef struct {
 #define WBCQP_FLAG_INDEX_ORDER 1 /* launch the QPs of a batch in index order.  Default (0): longest-first -- a launch is
                                     ordered by the active-set iteration counts of the previous launch of the same shape on
                                     the same stream (control ticks change little); results do not depend on the order */
+#define WBCQP_FLAG_HW_DISPATCH 2 /* one workgroup per QP, handed to the CUs by the hardware's dispatcher.  Default (0): as
+                                    many workgroups as the chip holds take QPs from a queue in the launch order (the
+                                    dispatcher binds workgroup i to one shader engine of XCD i % 8 and waits for it; the
+                                    queue does not); results do not depend on it */
+#define WBCQP_FLAG_NO_PACKING 4  /* keep the plain longest-first order for the queue.  Default (0): when a launch holds between
+                                    one and eight QPs per resident workgroup, the order is bin-packed from the predicted costs
+                                    (setup + iterations of the previous launch) so that the workgroups finish together */
+
+#define WBCQP_FLAG_REFRESH_SHIFT 8
+#define WBCQP_FLAG_REFRESH(n) (((n) & 0xff) << WBCQP_FLAG_REFRESH_SHIFT) /* renew the launch order every n-th launch of a shape
+                                    (1: after every launch; 0: the default, 4).  Between renewals the same order is used:
+                                    iteration counts drift slowly between control ticks and the queue absorbs the drift.
+                                    A captured tick (wbcqp_tick_graph_create) renews it on every replay */
 
 typedef struct {
     int32_t device;   /* HIP device ordinal */
@@ -326,6 +339,12 @@ int wbcqp_tick_graph_launch(wbcqp_handle* handle, wbcqp_graph* graph, void* stre
 int wbcqp_tick_graph_destroy(wbcqp_handle* handle, wbcqp_graph* graph);
 
 int wbcqp_sync(wbcqp_handle* handle, void* stream);
+
+/* Diagnostics: the launch order the next solve of the last launch's shape will use (what the schedule kernels left),
+   copied to host memory after a device synchronisation.  Returns the number of entries written (0: no order yet, the next
+   launch runs in index order), or a negative wbcqp_error.  *packed (may be NULL): 1 if this is the bin-packed order,
+   0 if plain longest-first.  Nothing in the reference corresponds to it; tests compare it with a host model. */
+int wbcqp_launch_order(wbcqp_handle* handle, int32_t* order, int32_t capacity, int32_t* packed);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ EXPORTS = ("wbcqp_version", "wbcqp_last_error", "wbcqp_create", "wbcqp_destroy",
            "wbcqp_layout_of", "wbcqp_solve_batch", "wbcqp_solve_batch_host", "wbcqp_solve_ragged",
            "wbcqp_allgather_tau", "wbcqp_integrate", "wbcqp_integrate_host", "wbcqp_set_model", "wbcqp_check_model", "wbcqp_problem_data",
            "wbcqp_problem_data_host", "wbcqp_tick", "wbcqp_tick_host", "wbcqp_tick_graph_create", "wbcqp_tick_graph_launch", "wbcqp_tick_graph_destroy",
-           "wbcqp_sync")
+           "wbcqp_sync", "wbcqp_launch_order")
 ROW_FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub")  # what wbcqp_problem_data writes
 
 c_i32_p = C.POINTER(C.c_int32)
@@ -254,6 +254,13 @@ def check_model(st: Structure, model, tm) -> int:
 
 
 FLAG_INDEX_ORDER = 1  # wbcqp_desc.flags: launch in index order (default: longest-first, see include/wbcqp.h)
+FLAG_NO_PACKING = 4   # wbcqp_desc.flags: plain longest-first order for the queue (default: bin-packed order for small launches)
+FLAG_HW_DISPATCH = 2  # wbcqp_desc.flags: one workgroup per QP through the hardware dispatcher (default: resident workgroups + queue)
+
+
+def flag_refresh(n: int) -> int:
+    """wbcqp_desc.flags: renew the launch order every n-th launch (WBCQP_FLAG_REFRESH; 0 = default 4)"""
+    return (n & 0xff) << 8
 
 
 class Handle:
@@ -421,6 +428,15 @@ class Handle:
 
     def tick_graph_destroy(self, graph: int):
         self.lib.wbcqp_tick_graph_destroy(self._h, C.c_void_p(graph))
+
+    def launch_order(self):
+        """(order, packed): the launch order the next solve of the last launch's shape will use; order is None before any"""
+        buf = np.zeros(1 << 16, dtype=np.int32)
+        packed = C.c_int32(0)
+        n = self.lib.wbcqp_launch_order(self._h, buf.ctypes.data_as(c_i32_p), C.c_int32(buf.size), C.byref(packed))
+        if n < 0:
+            self._check(n)
+        return (buf[:n].copy() if n else None), bool(packed.value)
 
     def sync(self, stream: int = 0):
         self._check(self.lib.wbcqp_sync(self._h, C.c_void_p(stream)))

@@ -42,6 +42,9 @@ struct Staging {
 
 } // namespace
 
+constexpr size_t kMaxQueues = 16;
+constexpr int kOrderRefresh = 4; // default period of the launch-order renewal (WBCQP_FLAG_REFRESH)
+
 struct wbcqp_handle {
     int device = 0;
     int dtype = WBCQP_F64;
@@ -52,11 +55,23 @@ struct wbcqp_handle {
     long long* dbg = nullptr; // diagnostic builds only (wbcqp_debug_set_stamp_buffer)
     // longest-first schedule (schedule_kernel): launch order for the next solve of the same shape on the same stream
     int flags = 0;
-    int* order = nullptr;
+    int* order = nullptr;        // [2][order_cap]: longest-first, then the packed order (pack_order_kernel)
+    bool order_packed = false;   // the second half is valid for order_total / order_sig / order_stream
+    int order_age = 0;           // launches that have used the order since it was computed
+    bool capturing = false;      // wbcqp_tick_graph_create: a captured tick always renews its order
     int order_cap = 0;
     int order_total = 0;              // 0: no valid order
     unsigned long long order_sig = 0; // shape of the launch the order belongs to
     hipStream_t order_stream = nullptr;
+    // solve_queue_kernel: one counter pair per stream this handle has launched on (two launches in flight on two streams
+    // must not share one); more streams than kMaxQueues fall back to the hardware's dispatch
+    struct Queue {
+        hipStream_t stream;
+        int* ctr;
+    };
+    std::vector<Queue> queues;
+    int n_cu = 0;
+    int queue_lds = -1, queue_occ = 0; // occupancy of solve_queue_kernel at queue_lds bytes of LDS
 };
 
 namespace {
@@ -247,21 +262,63 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         sa.iters[g] = tab.g[g].iters;
         sa.count[g] = tab.g[g].count;
     }
-    tab.order = (sched && h->order_total == total && h->order_sig == sig && h->order_stream == stream) ? h->order : nullptr;
-    hipLaunchKernelGGL(solve_kernel<TI>, dim3(total), dim3(kThreads), lds_bytes, stream, tab);
+    tab.order = (sched && h->order_total == total && h->order_sig == sig && h->order_stream == stream)
+                    ? h->order + (h->order_packed ? h->order_cap : 0) : nullptr;
+    int* queue = nullptr;
+    if (!(h->flags & WBCQP_FLAG_HW_DISPATCH)) {
+        for (auto& q : h->queues)
+            if (q.stream == stream) queue = q.ctr;
+        if (!queue && h->queues.size() < kMaxQueues) {
+            HIP_TRY(h, hipMalloc(&queue, 2 * sizeof(int)));
+            HIP_TRY(h, hipMemset(queue, 0, 2 * sizeof(int)));
+            h->queues.push_back({stream, queue});
+        }
+    }
+    if (queue) {
+        if (h->queue_lds != lds_bytes) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel<TI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds));
+            int occ = 0;
+            HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI>, kThreads, (size_t)lds_bytes));
+            if (occ < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel: no workgroup fits a CU");
+            h->queue_occ = occ;
+            h->queue_lds = lds_bytes;
+        }
+        const long long resident = (long long)h->queue_occ * h->n_cu;
+        hipLaunchKernelGGL(solve_queue_kernel<TI>, dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
+                           stream, tab, queue, total);
+    }
+    else
+        hipLaunchKernelGGL(solve_kernel<TI>, dim3(total), dim3(kThreads), lds_bytes, stream, tab);
     HIP_TRY(h, hipGetLastError());
-    if (sched) {
+    // the order is renewed every `period` launches: iteration counts drift slowly from tick to tick, the queue absorbs what
+    // drift there is, and the two order kernels (4.5 + 15 us) are then a fraction of a launch instead of a twentieth
+    const int asked = (h->flags >> WBCQP_FLAG_REFRESH_SHIFT) & 0xff;
+    const int period = h->capturing ? 1 : (asked ? asked : kOrderRefresh);
+    if (sched && tab.order && h->order_age + 1 < period)
+        ++h->order_age;
+    else if (sched) {
+        h->order_age = 0;
         if (total > h->order_cap) { // first launch of a larger shape: the only allocation on this path
             HIP_TRY(h, hipStreamSynchronize(stream));
             if (h->order) (void)hipFree(h->order);
             h->order = nullptr;
             h->order_cap = 0;
             h->order_total = 0;
-            HIP_TRY(h, hipMalloc(&h->order, sizeof(int) * (size_t)total));
+            HIP_TRY(h, hipMalloc(&h->order, 2 * sizeof(int) * (size_t)total));
             h->order_cap = total;
         }
         hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, stream, sa, h->order, total);
         HIP_TRY(h, hipGetLastError());
+        // a few QPs per resident workgroup, one structure, taken from the queue: pack the order (pack_order_kernel)
+        const long long resident = queue ? (long long)h->queue_occ * h->n_cu : 0;
+        h->order_packed = queue && !(h->flags & WBCQP_FLAG_NO_PACKING) && tab.n == 1 && resident % kPackSubs == 0 &&
+                          total % kPackSubs == 0 && total > resident && total <= 8 * resident && total / kPackSubs <= kPackMaxItems;
+        if (h->order_packed) {
+            PackArgs pa{tab.g[0].iters, h->order, h->order + h->order_cap, total, (int)(resident / kPackSubs)};
+            hipLaunchKernelGGL(pack_order_kernel, dim3(kPackSubs), dim3(256), 0, stream, pa);
+            HIP_TRY(h, hipGetLastError());
+        }
         h->order_total = total;
         h->order_sig = sig;
         h->order_stream = stream;
@@ -320,6 +377,7 @@ int wbcqp_create(const wbcqp_desc* desc, wbcqp_handle** out)
     h->device = desc->device;
     h->dtype = desc->dtype;
     h->flags = desc->flags;
+    h->n_cu = prop.multiProcessorCount;
     *out = h;
     return WBCQP_OK;
 }
@@ -332,6 +390,7 @@ int wbcqp_destroy(wbcqp_handle* h)
     if (h->stage_in.dev) (void)hipFree(h->stage_in.dev);
     if (h->stage_out.dev) (void)hipFree(h->stage_out.dev);
     if (h->order) (void)hipFree(h->order);
+    for (auto& q : h->queues) (void)hipFree(q.ctr);
     delete h;
     return WBCQP_OK;
 }
@@ -531,6 +590,19 @@ int wbcqp_allgather_tau(wbcqp_handle* h, void* comm, const void* send, void* rec
 
 // Diagnostic hook, not part of include/wbcqp.h: per-QP phase cycle counters ([batch][20] int64, device memory)
 // are written only by a library built with -DWBCQP_STAMPS (inria_wbc_amd/build.py --stamps); single group only.
+int wbcqp_launch_order(wbcqp_handle* h, int32_t* order, int32_t capacity, int32_t* packed)
+{
+    if (!h || !order || capacity < 0) return WBCQP_ERR_INVALID;
+    if (packed) *packed = 0;
+    if (!h->order || h->order_total <= 0) return 0;
+    if (capacity < h->order_total) return fail(h, WBCQP_ERR_INVALID, "wbcqp_launch_order: capacity below the order's length");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(order, h->order + (h->order_packed ? h->order_cap : 0), sizeof(int) * (size_t)h->order_total, hipMemcpyDeviceToHost));
+    if (packed) *packed = h->order_packed ? 1 : 0;
+    return h->order_total;
+}
+
 int wbcqp_debug_set_stamp_buffer(wbcqp_handle* h, void* dev_ptr)
 {
     if (!h) return WBCQP_ERR_INVALID;
@@ -1018,7 +1090,9 @@ int wbcqp_tick_graph_create(wbcqp_handle* h, int slot, int batch, const wbcqp_ti
     if (rc != WBCQP_OK) { wbcqp_tick_graph_destroy(h, g); return rc; }
     e = hipStreamBeginCapture(g->capture, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { wbcqp_tick_graph_destroy(h, g); return fail(h, WBCQP_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
+    h->capturing = true;
     rc = wbcqp_tick(h, slot, batch, io, g->capture);
+    h->capturing = false;
     e = hipStreamEndCapture(g->capture, &g->graph);
     if (rc != WBCQP_OK || e != hipSuccess || !g->graph) {
         wbcqp_tick_graph_destroy(h, g);

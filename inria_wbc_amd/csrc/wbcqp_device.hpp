@@ -33,9 +33,8 @@ namespace wbcqp {
 // one QP on one workgroup of 256 threads
 // ------------------------------------------------------------------------------------------------
 template <typename TI>
-__device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStruct& S, const int b, double* lds)
+__device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStruct& S, const int b, double* lds, const int tid)
 {
-    const int tid = threadIdx.x;
     Ctx c;
     c.S = &S;
     c.tid = tid;
@@ -836,7 +835,51 @@ __global__ __launch_bounds__(kThreads) void solve_kernel(const GroupTable<TI> ta
     }
     const GroupArgs<TI>& ga = tab.g[gi];
     const DevStruct& S = ga.st;
-    solve_one<TI>(ga, S, b, lds);
+    solve_one<TI>(ga, S, b, lds, threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the same, with the workgroups handing out the QPs themselves: grid = as many workgroups as the chip holds at once, each
+// takes the next entry of the launch order from a counter in HBM until the order is exhausted.
+// Why: measured (tools/ubench/dispatch_order.hip), the hardware deals workgroup i to XCD i % 8 and, inside the XCD, to
+// shader engine (i / 8) % 4, strictly in index order -- a workgroup waits for a CU of *its* engine (8 CUs) while CUs of
+// the other engines stand free, and everything behind it in that XCD waits with it.  A queue is list scheduling over
+// all 256 CUs.  *queue: positions handed out beyond the first one of each workgroup; the last fetch of a launch zeroes it
+// for the next launch (stream order makes that visible; no memset on the path, and a captured launch replays as it is).
+// ------------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<TI> tab, int* queue, const int total)
+{
+    extern __shared__ __align__(16) double lds[];
+    __shared__ int next_qp;
+    for (bool first = true;; first = false) {
+        if (threadIdx.x == 0) {
+            // a workgroup's first position is its own index: 256 atomics on one address at the start of the launch go
+            // through one at a time (measured: 6 us per launch).  Every workgroup ends on exactly one fetch past the end,
+            // so the counter stops at `total`; whoever draws total - 1 made the last fetch of the launch and zeroes it.
+            int pos = (int)blockIdx.x;
+            if (!first) {
+                const int c = atomicAdd(queue, 1);
+                pos = (int)gridDim.x + c;
+                if (c == total - 1) *queue = 0;
+            }
+            next_qp = pos < total ? (tab.order ? tab.order[pos] : pos) : -1;
+        }
+        __syncthreads();
+        int b = uni(next_qp), gi = 0;
+        if (b < 0) break;
+        while (gi + 1 < tab.n && b >= tab.g[gi].count) {
+            b -= tab.g[gi].count;
+            ++gi;
+        }
+        const GroupArgs<TI>& ga = tab.g[gi];
+        // the thread index is made opaque once per QP: otherwise every per-thread offset of solve_one is hoisted out of
+        // this loop and stays live across it (measured: 256 VGPRs + 146 AGPRs instead of 240 + 0; build.py refuses that)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        solve_one<TI>(ga, ga.st, b, lds, tid);
+        __syncthreads(); // the next QP reuses every byte of LDS, next_qp included
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -873,6 +916,150 @@ __global__ __launch_bounds__(1024) void schedule_kernel(const ScheduleArgs sa, i
     }
     __syncthreads();
     for (int i = tid; i < total; i += 1024) order[atomicAdd(&start[key_of(i)], 1)] = i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed launch order for the queue (host model, same integer arithmetic: inria_wbc_amd/launch_order.py).
+// Longest-first is list scheduling; with about four QPs per CU its makespan sits up to one short QP above the mean
+// (measured on the bench batch: 1.15 x the perfect split).  A QP costs about kSetupIters + iterations units, so the batch
+// is bin-packed instead: 32 sub-problems (the longest-first order dealt out boustrophedon, so that they are alike),
+// each packing its share into its 32nd of the resident workgroups for a capacity C -- a bin takes the largest QP left,
+// then QPs nearest to room / (number of QPs the room holds at the mean size left), the last two chosen to fill the room
+// exactly when such a pair exists.  Four capacities are tried at once (one wave each, all scalar: the class counts live
+// in the lanes of one register, the classes in play in a 64-bit mask), the smallest that fits wins, and the QPs are
+// emitted by start time, the sub-problems interleaved.  The queue then reproduces the packing, or does better where
+// the real costs differ from the predicted ones.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSetupIters = 7;   // setup of a Talos QP in units of one active-set iteration (115.8 k against 14.7 k cycles)
+constexpr int kPackSubs = 32, kPackTrials = 4, kPackMaxItems = 128;
+
+struct PackArgs {
+    const int* iters;     // iteration counts of the launch just finished
+    const int* order_in;  // longest-first order (schedule_kernel)
+    int* order_out;       // packed order
+    int total;            // multiple of kPackSubs, total / kPackSubs <= kPackMaxItems
+    int bins;             // resident workgroups / kPackSubs
+};
+
+namespace pack {
+using u64 = unsigned long long;
+__device__ __forceinline__ int hi(u64 m) { return m ? 63 - __builtin_clzll(m) : -1; }
+__device__ __forceinline__ int lo(u64 m) { return m ? __builtin_ctzll(m) : -1; }
+__device__ __forceinline__ u64 below(int k) { return k < 0 ? 0ull : (k >= 63 ? ~0ull : ((1ull << (k + 1)) - 1ull)); }
+// the set bit nearest to t2 / 2, the larger one on a tie; -1 if none
+__device__ __forceinline__ int nearest(u64 m, int t2)
+{
+    const int fl = min(t2 >> 1, 63);
+    const int kl = hi(m & below(fl)), kh = lo(m & ~below(fl));
+    if (kl < 0) return kh;
+    if (kh < 0) return kl;
+    return (2 * kh - t2 <= t2 - 2 * kl) ? kh : kl;
+}
+// x / j for 0 <= x < 8192, 1 <= j <= 8 without the divider sequence (exact in that range)
+__device__ __forceinline__ int div_small(int x, int j)
+{
+    const int r = j == 1 ? 65536 : j == 2 ? 32768 : j == 3 ? 21846 : j == 4 ? 16384 : j == 5 ? 13108 : j == 6 ? 10923 : j == 7 ? 9363 : 8192;
+    return (x * r) >> 16;
+}
+} // namespace pack
+
+// grid = kPackSubs, block = 256: one sub-problem per workgroup, one capacity per wave.  One wave per SIMD matters: the
+// packing is scalar code, a CU has one scalar unit, and with sixteen such waves on a CU (the first version) each of them
+// issued once in sixteen cycles -- 63 us for what takes a fraction of that spread over 32 CUs.
+__global__ __launch_bounds__(256) void pack_order_kernel(const PackArgs pa)
+{
+    using namespace pack;
+    __shared__ int s_job[kPackMaxItems];
+    __shared__ int s_cls[kPackMaxItems];
+    __shared__ unsigned s_ev[kPackTrials][kPackMaxItems];
+    __shared__ int s_ok[kPackTrials];
+    constexpr int A = kSetupIters;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int trial = uni(tid >> 6);
+    const int sub = blockIdx.x, nw = pa.total / kPackSubs;
+    if (tid < nw) {
+        // entry e of sub-problem `sub`: rank 32 e + sub on even rounds, 32 e + 31 - sub on odd ones
+        const int job = pa.order_in[kPackSubs * tid + ((tid & 1) ? kPackSubs - 1 - sub : sub)];
+        s_job[tid] = job;
+        s_cls[tid] = min(max(pa.iters[job], 0), 63);
+    }
+    __syncthreads();
+    // class counts in the lanes (lane k: class k), gend(k) = number of entries of class >= k (the entries are sorted)
+    int cnt = 0;
+    for (int e = 0; e < nw; ++e) cnt += (s_cls[e] == lane);
+    int gend = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_down(gend, d);
+        if (lane + d < 64) gend += v;
+    }
+    int tot = cnt * (lane + A);
+    for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d);
+    tot = uni(tot);
+    u64 avail = __ballot(cnt > 0);
+    const int c0 = max((tot + pa.bins - 1) / pa.bins, hi(avail) + A);
+    const int cap = c0 + trial;
+    int n = nw, ne = 0;
+    for (int bin = 0; bin < pa.bins && n > 0; ++bin) {
+        int room = cap;
+        bool first = true;
+        while (n > 0) {
+            const int kmin = lo(avail);
+            if (room < kmin + A) break;
+            const int kmax = min(63, room - A);
+            int k;
+            if (first) {
+                k = hi(avail & below(kmax));
+                first = false;
+            }
+            else {
+                int j = 1;
+                while (j < 8 && (2 * j + 1) * tot <= 2 * room * n) ++j;
+                while (j > 1 && j * (kmin + A) > room) --j;
+                if (j == 1) k = hi(avail & below(kmax));
+                else {
+                    const int lim = min(kmax, room - (j - 1) * (kmin + A) - A);
+                    const int t2 = div_small(2 * room, j) - 2 * A;
+                    k = nearest(avail & below(lim), t2);
+                    if (j == 2) {
+                        // a pair that fills the room exactly: k2 + k3 = need, both in play (twice if k2 == k3)
+                        const int need = room - 2 * A;
+                        if (need >= 0 && need <= 126) {
+                            const u64 rev = __builtin_bitreverse64(avail); // bit (63 - k) of rev = bit k of avail
+                            u64 cand = avail & (need <= 63 ? rev >> (63 - need) : rev << (need - 63));
+                            if (!(need & 1) && (need >> 1) <= 63 && __builtin_amdgcn_readlane(cnt, need >> 1) < 2)
+                                cand &= ~(1ull << (need >> 1));
+                            const int bp = nearest(cand, t2);
+                            if (bp >= 0) k = max(bp, need - bp);
+                        }
+                    }
+                }
+            }
+            if (k < 0) break;
+            const int left = __builtin_amdgcn_readlane(cnt, k);
+            const int li = __builtin_amdgcn_readlane(gend, k) - left;
+            if (lane == 0) s_ev[trial][ne] = ((unsigned)(cap - room) << 16) | ((unsigned)ne << 8) | (unsigned)li;
+            ++ne;
+            cnt -= (lane == k);
+            if (left == 1) avail &= ~(1ull << k);
+            --n;
+            tot -= k + A;
+            room -= k + A;
+        }
+    }
+    if (lane == 0) s_ok[trial] = (n == 0);
+    __syncthreads();
+    int win = -1;
+    for (int t = kPackTrials - 1; t >= 0; --t)
+        if (s_ok[t]) win = t;
+    if (tid < nw) {
+        if (win < 0) pa.order_out[kPackSubs * tid + sub] = s_job[tid]; // no capacity fitted: longest-first, dealt out
+        else {
+            const unsigned key = s_ev[win][tid];
+            int rank = 0;
+            for (int e = 0; e < nw; ++e) rank += (s_ev[win][e] < key);
+            pa.order_out[kPackSubs * rank + sub] = s_job[key & 255u];
+        }
+    }
 }
 
 #endif // __HIPCC__

@@ -1,0 +1,80 @@
+"""The launch order (queue, longest-first, bin-packed) never changes a result, and the device packer agrees with its host
+model (inria_wbc_amd/launch_order.py) class by class.  Nothing here has a counterpart in the reference: the reference solves
+one QP per process; how a batch is dealt out to the CUs is this library's own business, so the checks are invariance,
+permutation validity and agreement with the model."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(st, inputs, flags, launches, want_order=False):
+    import torch
+    from inria_wbc_amd import capi
+    B = next(iter(inputs.values())).shape[0]
+    dev = torch.device("cuda", 0)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
+    h = capi.Handle(0, capi.F64, flags=flags)
+    h.set_structure(0, st)
+    outs, orders = [], []
+    for _ in range(launches):
+        d_out = dict(x=torch.full((B, st.n), float("nan"), dtype=torch.float64, device=dev),
+                     tau=torch.full((B, st.na), float("nan"), dtype=torch.float64, device=dev),
+                     status=torch.full((B,), -99, dtype=torch.int32, device=dev),
+                     iters=torch.full((B,), -1, dtype=torch.int32, device=dev))
+        h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append({k: v.cpu().numpy() for k, v in d_out.items()})
+        if want_order:
+            orders.append(h.launch_order())
+    h.close()
+    return (outs, orders) if want_order else outs
+
+
+@pytest.mark.parametrize("batch", [1, 17, 256, 300, 512, 1024, 1040, 2048, 2100])
+def test_every_dispatch_gives_the_same_bits(batch):
+    """queue + packed order (default), queue + longest-first, queue + index order, hardware dispatch: bitwise the same."""
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.talos_structure()
+    inputs = synth.generate(st, batch, synth.SEED_BASE["talos"] + 31 * batch)
+    plain = _run(st, inputs, capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH, 1)[0]
+    assert (plain["status"] != -99).all()
+    for flags in (0, capi.FLAG_NO_PACKING, capi.FLAG_INDEX_ORDER, capi.FLAG_HW_DISPATCH):
+        for o in _run(st, inputs, flags, 3):
+            for k in ("x", "tau", "status", "iters"):
+                assert np.array_equal(o[k], plain[k], equal_nan=True), (flags, k)
+
+
+@pytest.mark.parametrize("batch,noise", [(1024, 1.0), (1024, 2.0), (512, 1.0), (2048, 1.0), (1536, 0.3), (272, 1.0)])
+def test_packed_order_matches_the_host_model(batch, noise):
+    from inria_wbc_amd import capi, launch_order, structure, synth
+    import torch
+    st = structure.talos_structure()
+    inputs = synth.generate(st, batch, synth.SEED_BASE["talos"] + 5, task_noise=noise)
+    outs, orders = _run(st, inputs, 0, 2, want_order=True)
+    iters = outs[0]["iters"]
+    order, packed = orders[0]
+    resident = torch.cuda.get_device_properties(0).multi_processor_count  # one Talos QP per CU
+    assert packed == launch_order.packs(batch, resident)
+    assert sorted(order.tolist()) == list(range(batch))
+    cls = np.clip(iters, 0, launch_order.MAX_CLASS)
+    if not packed:
+        assert np.all(np.diff(cls[order]) <= 0)
+        return
+    lpt = np.argsort(-cls, kind="stable")
+    model = launch_order.pack_order(lpt, iters, resident)
+    assert np.array_equal(cls[order], cls[model])
+    # and it is worth it on the model's own terms: list scheduling of the predicted costs
+    cost = launch_order.SETUP_ITERS + cls.astype(float)
+    assert launch_order.makespan(cost[order], resident) <= launch_order.makespan(cost[lpt], resident) * 1.03
+
+
+def test_small_structures_share_a_cu():
+    """Franka QPs are small: several workgroups are resident per CU, the queue's grid follows the occupancy."""
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.franka_structure()
+    inputs = synth.generate(st, 5000, synth.SEED_BASE["franka"] + 3)
+    plain = _run(st, inputs, capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH, 1)[0]
+    for o in _run(st, inputs, 0, 3):
+        for k in ("x", "tau", "status", "iters"):
+            assert np.array_equal(o[k], plain[k], equal_nan=True), k

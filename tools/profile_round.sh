@@ -8,13 +8,13 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $ROOT
 python3 -c "from inria_wbc_amd import build; build.build(); build.build_stamps()" > $OUT/build.log 2>&1
-python3 bench.py --steps 20 --warmup 3 --sweep $OUT/sweep.json > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --sweep $OUT/sweep.json > $OUT/bench.json 2> $OUT/bench.err
 python3 tools/phase_profile.py --out $OUT/phase.json > $OUT/phase.txt 2>&1
 python3 tools/phase_profile.py --model > $OUT/phase_model.txt 2>&1
 python3 tools/terms_profile.py > $OUT/terms_phase.txt 2>&1
 python3 tools/tick_latency.py --reps 100 --out $OUT/tick_latency.json > $OUT/tick_latency.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-compare > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-compare > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/write.log 2>&1
 cd $OUT
