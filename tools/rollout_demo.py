@@ -17,6 +17,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--ticks", type=int, default=2000)
+    ap.add_argument("--flags", type=lambda x: int(x, 0), default=0, help="wbcqp_desc.flags (launch-order variants, include/wbcqp.h)")
+    ap.add_argument("--desync", action="store_true", help="every robot at its own phase of the squat (iteration counts spread and drift)")
     args = ap.parse_args()
     import torch
     from inria_wbc_amd import capi, structure, trajs
@@ -26,7 +28,7 @@ def main():
     tm = mdl.build_taskmap(m, st, mdl.talos_stack())
     B, dt = args.batch, tm.dt
     dev = torch.device("cuda", 0)
-    h = capi.Handle(0, capi.F64)
+    h = capi.Handle(0, capi.F64, flags=args.flags)
     h.set_structure(0, st)
     h.set_model(0, m, tm)
     s = mdl.sample_states(m, tm, B, 123_000, q_noise=0.002, v_noise=0.01, ref_noise=0.0)
@@ -43,9 +45,13 @@ def main():
     pos, vel, acc = trajs.move_com_stream(m.com(m.q0), [[0.0, 0.0, -0.2]], "001", dt, 2.0, loop=True, absolute=False)
     stream9 = torch.from_numpy(np.concatenate([pos, vel, acc], axis=1)).to(dev)
     sp = torch.cuda.current_stream().cuda_stream
+    phase = torch.from_numpy(np.random.default_rng(5).integers(0, stream9.shape[0], B)).to(dev) if args.desync else None
     t0 = time.perf_counter()
     for k in range(args.ticks):
-        ref[:, blk.ref:blk.ref + 9] = stream9[k % stream9.shape[0]]
+        if phase is None:
+            ref[:, blk.ref:blk.ref + 9] = stream9[k % stream9.shape[0]]
+        else:
+            ref[:, blk.ref:blk.ref + 9] = stream9[(phase + k) % stream9.shape[0]]
         h.tick(0, B, dict(q=q, v=v, ref=ref), rows, out, qn, vn, dt, stream=sp)
         q, qn = qn, q
         v, vn = vn, v
