@@ -225,7 +225,10 @@ def main():
             "config": {"workload": "%s_pos_tracker%s_b%d_fp64_one_workgroup_per_qp" % (args.robot, "_squat" if args.squat else "", B),
                        "batch_per_gpu": B, "n": st.n, "neq": st.neq, "nin": st.nin, "level1_rows": st.r1,
                        "parallelism": "batch-shard x%d" % world,
-                       "schedule": "index-order" if args.index_order else "queue of resident workgroups; order bin-packed from the iteration counts of an earlier step, renewed every 4th launch",
+                       "schedule": "index-order" if args.index_order else
+                       ("queue of resident workgroups; order bin-packed from the iteration counts of an earlier step, renewed every 4th launch"
+                        if layout["waves_per_cu"] == 1 else
+                        "hardware dispatch (several workgroups per CU), longest-first from the iteration counts of an earlier step"),
                        "allgather_tau": bool(gather_state["ok"]), "lds_bytes_per_qp": layout["lds_bytes"],
                        "qps_resident_per_cu": layout["waves_per_cu"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -149,9 +149,12 @@ typedef struct {
                                     ordered by the active-set iteration counts of the previous launch of the same shape on
                                     the same stream (control ticks change little); results do not depend on the order */
 #define WBCQP_FLAG_HW_DISPATCH 2 /* one workgroup per QP, handed to the CUs by the hardware's dispatcher.  Default (0): as
-                                    many workgroups as the chip holds take QPs from a queue in the launch order (the
+                                    many workgroups as the chip holds take QPs from a queue in the launch order when one
+                                    workgroup fills a CU (the
                                     dispatcher binds workgroup i to one shader engine of XCD i % 8 and waits for it; the
                                     queue does not); results do not depend on it */
+#define WBCQP_FLAG_QUEUE 8       /* the queue also for structures small enough that several workgroups share a CU (default: those
+                                    go through the hardware's dispatcher, which has slack there and no hand-over cost) */
 #define WBCQP_FLAG_NO_PACKING 4  /* keep the plain longest-first order for the queue.  Default (0): when a launch holds between
                                     one and eight QPs per resident workgroup, the order is bin-packed from the predicted costs
                                     (setup + iterations of the previous launch) so that the workgroups finish together */

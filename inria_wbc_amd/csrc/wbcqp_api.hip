@@ -264,8 +264,20 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     }
     tab.order = (sched && h->order_total == total && h->order_sig == sig && h->order_stream == stream)
                     ? h->order + (h->order_packed ? h->order_cap : 0) : nullptr;
+    // The queue pays when a workgroup fills a CU: then the dispatcher's binding of a workgroup to one shader engine leaves
+    // CUs idle.  Small QPs (several workgroups per CU: Franka, 3) give the dispatcher slack, and one hand-over (1 us) is a
+    // tenth of such a QP -- measured 27 M QP/s through the queue against 36 M through the hardware.  WBCQP_FLAG_QUEUE forces it.
+    if (h->queue_lds != lds_bytes) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel<TI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds));
+        int occ = 0;
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI>, kThreads, (size_t)lds_bytes));
+        if (occ < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel: no workgroup fits a CU");
+        h->queue_occ = occ;
+        h->queue_lds = lds_bytes;
+    }
     int* queue = nullptr;
-    if (!(h->flags & WBCQP_FLAG_HW_DISPATCH)) {
+    if (!(h->flags & WBCQP_FLAG_HW_DISPATCH) && (h->queue_occ == 1 || (h->flags & WBCQP_FLAG_QUEUE))) {
         for (auto& q : h->queues)
             if (q.stream == stream) queue = q.ctr;
         if (!queue && h->queues.size() < kMaxQueues) {
@@ -275,15 +287,6 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         }
     }
     if (queue) {
-        if (h->queue_lds != lds_bytes) {
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel<TI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds));
-            int occ = 0;
-            HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI>, kThreads, (size_t)lds_bytes));
-            if (occ < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel: no workgroup fits a CU");
-            h->queue_occ = occ;
-            h->queue_lds = lds_bytes;
-        }
         const long long resident = (long long)h->queue_occ * h->n_cu;
         hipLaunchKernelGGL(solve_queue_kernel<TI>, dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
                            stream, tab, queue, total);

@@ -70,11 +70,12 @@ def test_packed_order_matches_the_host_model(batch, noise):
 
 
 def test_small_structures_share_a_cu():
-    """Franka QPs are small: several workgroups are resident per CU, the queue's grid follows the occupancy."""
+    """Franka QPs are small: several workgroups are resident per CU; forced through the queue, its grid follows the occupancy."""
     from inria_wbc_amd import capi, structure, synth
     st = structure.franka_structure()
     inputs = synth.generate(st, 5000, synth.SEED_BASE["franka"] + 3)
     plain = _run(st, inputs, capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH, 1)[0]
-    for o in _run(st, inputs, 0, 3):
-        for k in ("x", "tau", "status", "iters"):
-            assert np.array_equal(o[k], plain[k], equal_nan=True), k
+    for flags in (0, capi.FLAG_QUEUE, capi.FLAG_QUEUE | capi.FLAG_NO_PACKING):  # default there: hardware dispatch
+        for o in _run(st, inputs, flags, 3):
+            for k in ("x", "tau", "status", "iters"):
+                assert np.array_equal(o[k], plain[k], equal_nan=True), (flags, k)
