@@ -2,19 +2,23 @@
 """bench.py -- QP solves/sec of the batched whole-body-QP tick on MI355X.
 
 One "step" = one pass of the hot path (assemble H,g -> GI active-set solve -> torque decode, i.e.
-controller.cpp:244-251 of the reference for every instance) over one batch of synthetic Talos QPs
-that is already resident in HBM.  Default workload = BASELINE.json configs[1]:
-Talos pos-tracker, batch 1024, fp64, one wavefront per QP, 1 x MI355X.
+controller.cpp:244-251 of the reference for every instance) over one batch of synthetic QPs that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]: Talos pos-tracker, batch 1024, fp64, 1 x MI355X.
+
+The timed steps are a STREAM, not a replay: instance i at step t solves tick (i + t) of the squat reference stream
+(etc/talos/squat.yaml through move_com.cpp:22-45, BASELINE config 4's own definition), so the launch order the library
+derives from earlier launches never comes from the batch it schedules.  The replayed-batch figure (perfect foresight),
+the index-order figure (no schedule) and a run over unrelated batches stand beside `value`.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --robot icub --batch 4096 --dtype f32          (BASELINE config 3)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: the batch shards embarrassingly -- every rank owns `--batch` QPs of the same seeded stream
-(weak scaling), no collective on the solve path (the QPs of a batch are independent).  `--allgather`
-adds the optional exchange step of BASELINE config 4 (all-gather of joint torques over RCCL/xGMI)
-after the solve inside the timed step.
-Rank 0 prints ONE JSON line.
+N > 1: the batch shards embarrassingly -- every rank owns `--batch` QPs of the same seeded stream (weak scaling), no
+collective on the solve path (the QPs of a batch are independent).  `--allgather` adds the optional exchange step of
+BASELINE config 4 (all-gather of joint torques over RCCL/xGMI through the library's own wbcqp_allgather_tau) after the
+solve inside the timed step.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -28,8 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# compact-boundary bytes per Talos fp64 QP (inputs 34 200 B + outputs 952 B)
+# compact-boundary bytes per fp64 QP (Talos: inputs 34 200 B + outputs 952 B)
 ALGORITHMIC_BYTES = {"talos": 35152, "icub": 23872, "franka": 1152}
+N_TICKS = 128  # distinct consecutive ticks of the reference stream kept resident (the timed steps cycle through them)
+SWEEP = (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192)
 
 
 def parse():
@@ -39,25 +45,30 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--batch", type=int, default=1024, help="QPs per GPU per step")
     p.add_argument("--robot", default="talos", choices=["talos", "icub", "franka"])
-    p.add_argument("--squat", action="store_true", help="CoM reference follows etc/talos/squat.yaml (BASELINE config 4)")
+    p.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                   help="boundary type of every input / output array (the solve itself runs in f64, DESIGN.md section 3)")
+    p.add_argument("--replay", action="store_true", help="solve the same batch every step (the round-1 headline) instead of the tick stream")
+    p.add_argument("--squat", action="store_true", help="accepted for compatibility: the tick stream IS the squat reference stream")
     p.add_argument("--allgather", action="store_true",
                    help="N > 1: also all-gather the joint torques over RCCL inside every step (BASELINE config 4's optional\n"
                         "exchange; the path itself has none -- the QPs of a batch are independent)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-compare", action="store_true", help="skip the extra index-order and hardware-dispatch runs reported beside `value`")
+    p.add_argument("--no-compare", action="store_true", help="skip the extra runs reported beside `value`")
+    p.add_argument("--no-sweep", action="store_true", help="skip the batch 1..8192 table")
     p.add_argument("--index-order", action="store_true",
                    help="launch the QPs in index order instead of longest-first (WBCQP_FLAG_INDEX_ORDER)")
+    p.add_argument("--flags", type=int, default=0, help="extra wbcqp_desc.flags for the headline handle")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
     p.add_argument("--traffic", type=float, default=None,
                    help="HBM bytes per launch from rocprofv3 PMC passes (default: scaled from profiles/pmc_latest.json)")
-    p.add_argument("--sweep", default=None, help="also time batch 1..8192 and write the table to this JSON file")
+    p.add_argument("--sweep", default=None, help="also write the batch 1..8192 table to this JSON file")
     return p.parse_args()
-
 
 
 def before_path(h, st, dev, B, torch, cpu_baseline=True):
     """Before the path, outside `value`: the rows kernel (q, v, references -> QP record) on a
-    Talos-like tree, alone and chained with the solve and the state integration (one whole control tick on the device)."""
+    Talos-like tree, alone and chained with the solve and the state integration (one whole control tick on the device),
+    open loop on fixed states and CLOSED loop (q_next, v_next fed back on the device, the squat reference advancing)."""
     from inria_wbc_amd import capi
     from inria_wbc_amd import model as mdl
     m = mdl.talos_like()
@@ -108,25 +119,81 @@ def before_path(h, st, dev, B, torch, cpu_baseline=True):
     res["whole_tick"] = {"ticks_per_s": B / (ms * 1e-3), "ms_per_batch": ms, "iters_mean": float(it.mean()),
                          "status_optimal": int((out["status"] == 0).sum().item()),
                          "note": "rows kernel + solve kernel + integrate kernel on the same stream, states around the reference posture"}
+    # closed loop: the integrated state is the next tick's state (ping-pong buffers, nothing leaves the device)
+    try:
+        sa = {"q": state["q"].clone(), "v": state["v"].clone(), "ref": state["ref"]}
+        sb = {"q": torch.zeros_like(sa["q"]), "v": torch.zeros_like(sa["v"]), "ref": state["ref"]}
+
+        def closed(n_ticks):
+            a, b = sa, sb
+            for _ in range(n_ticks):
+                h.problem_data(1, B, a, rows, stream=sp)
+                h.solve_batch(1, B, rows, out, stream=sp)
+                h.integrate(B, st.nv, True, tm.dt, a["q"], a["v"], out["x"], st.n, out["status"], b["q"], b["v"], None, stream=sp)
+                a, b = b, a
+
+        closed(10)
+        torch.cuda.synchronize()
+        it0 = out["iters"].cpu().numpy().astype(np.float64)
+        closed(1)
+        torch.cuda.synchronize()
+        it1 = out["iters"].cpu().numpy().astype(np.float64)
+        e0.record()
+        closed(200)
+        e1.record()
+        torch.cuda.synchronize()
+        msc = e0.elapsed_time(e1) / 200
+        res["closed_loop"] = {"ticks_per_s": B / (msc * 1e-3), "ms_per_batch": msc, "ticks": 200,
+                              "status_optimal_last": int((out["status"] == 0).sum().item()),
+                              "iters_mean_last": float(out["iters"].float().mean().item()),
+                              "iters_tick_to_tick_corr": _corr(it0, it1), "iters_tick_to_tick_equal": float((it0 == it1).mean()),
+                              "note": "q_next, v_next fed back on the device for 200 ticks: every launch solves QPs no earlier launch has seen"}
+    except Exception as e:  # noqa: BLE001
+        res["closed_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if cpu_baseline:
         from oracle import rbd
         ns = min(B, 128)
         t1 = time.perf_counter()
         ora = rbd.task_rows(m, tm, st, s["q"][:ns], s["v"][:ns], s["ref"][:ns], n_threads=1)
         dt1 = time.perf_counter() - t1
+        h.problem_data(1, B, state, rows, stream=sp)
+        torch.cuda.synchronize()
         got = {k: rows[k][:ns].cpu().numpy() for k in capi.ROW_FIELDS}
         res["cpu_port"] = {"instances_per_s": ns / dt1, "cores": 1, "sample": "%d instances, oracle/rbd_oracle.c" % ns}
         res["parity"] = {k: float(np.abs(got[k] - ora[k]).max() / max(1.0, np.abs(ora[k]).max())) for k in capi.ROW_FIELDS}
     return res
 
+
+def _corr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.std() == 0.0 or b.std() == 0.0:
+        return 1.0 if np.array_equal(a, b) else 0.0
+    return float(np.corrcoef(a, b)[0, 1])
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d needs one process per GPU: launch it as\n  python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...\n"
+                         "(WORLD_SIZE is %d here)" % (args.gpus, args.gpus, args.gpus, world))
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -141,33 +208,69 @@ def main():
     if distributed:
         dist.barrier()
 
+    f32 = args.dtype == "f32"
+    tdt = torch.float32 if f32 else torch.float64
+    ndt = np.float32 if f32 else np.float64
+    cdt = capi.F32 if f32 else capi.F64
     st = structure.STRUCTURES[args.robot]()
     B = args.batch
-    seed_key = "talos_squat" if (args.squat and args.robot == "talos") else args.robot
-    # rank r owns QPs [r*B, (r+1)*B) of the stream
-    inputs = synth.generate(st, B, synth.SEED_BASE[seed_key], first=rank * B, squat=args.squat)
     dev = torch.device("cuda", local_rank)
-    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
-    d_out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev),
-                 tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
-                 status=torch.full((B,), -99, dtype=torch.int32, device=dev),
-                 iters=torch.zeros(B, dtype=torch.int32, device=dev))
-    tau_all = torch.zeros(world * B, max(st.na, 1), dtype=torch.float64, device=dev) if distributed else None
+    # rank r owns QPs [r*B, (r+1)*B) of the stream
+    inputs = synth.generate(st, B, synth.SEED_BASE[args.robot], first=rank * B)
+    if f32:
+        inputs = {k: v.astype(np.float32).astype(np.float64) for k, v in inputs.items()}  # the oracle sees what the device sees
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v.astype(ndt))).to(dev) for k, v in inputs.items() if v.size}
 
-    h = capi.Handle(device=local_rank, dtype=capi.F64, flags=capi.FLAG_INDEX_ORDER if args.index_order else 0)
+    # ---- the tick stream: CoM rows of b1 follow the squat reference, instance i at step t is on tick (rank B + i + t) ----
+    stream = (not args.replay) and ("com" in st.task_names)
+    com_rows = np.where(st.dense_row_task == st.task_names.index("com"))[0] if stream else None
+    b1_ticks = None
+    if stream:
+        kp = st.kp.get("com", 30.0)
+        table = np.stack([synth.squat_com_rhs(st, t, kp) for t in range(4000)])  # [4000, 3]
+        idx = (rank * B + np.arange(B)[None, :] + np.arange(N_TICKS)[:, None]) % 4000  # [tick, instance]
+        b1_all = np.repeat(inputs["b1"][None, :, :], N_TICKS, axis=0)
+        b1_all[:, :, com_rows] += table[idx][:, :, :com_rows.size]
+        if f32:
+            b1_all = b1_all.astype(np.float32).astype(np.float64)
+        b1_ticks = torch.from_numpy(np.ascontiguousarray(b1_all.astype(ndt))).to(dev)
+
+    def tick_inputs(t):
+        if not stream:
+            return d_in
+        d = dict(d_in)
+        d["b1"] = b1_ticks[t % N_TICKS]
+        return d
+
+    tick_dicts = [tick_inputs(t) for t in range(N_TICKS if stream else 1)]
+
+    def new_out(b=B):
+        return dict(x=torch.zeros(b, st.n, dtype=tdt, device=dev), tau=torch.zeros(b, max(st.na, 1), dtype=tdt, device=dev),
+                    status=torch.full((b,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(b, dtype=torch.int32, device=dev))
+
+    d_out = new_out()
+    base_flags = args.flags | (capi.FLAG_INDEX_ORDER if args.index_order else 0)
+    h = capi.Handle(device=local_rank, dtype=cdt, flags=base_flags)
     h.set_structure(0, st)
     layout = capi.layout_of(st)
-    do_gather = distributed and args.allgather
-    gather_state = {"ok": do_gather, "err": None}
+    sp = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
-        if gather_state["ok"]:
-            try:
-                dist.all_gather_into_tensor(tau_all, d_out["tau"])
-            except Exception as e:  # keep the scaling run alive; the exchange step is optional
-                gather_state["ok"] = False
-                gather_state["err"] = repr(e)
+    # optional exchange step: the library's own RCCL entry point on a communicator of this job's ranks
+    gather = {"ok": False, "err": None, "comm": None}
+    tau_all = None
+    if distributed and args.allgather:
+        try:
+            from inria_wbc_amd import rccl
+            gather["comm"] = rccl.comm_from_torch(dist, rank, world, dev)
+            tau_all = torch.zeros(world * B, max(st.na, 1), dtype=tdt, device=dev)
+            gather["ok"] = True
+        except Exception as e:  # keep the scaling run alive; the exchange step is optional
+            gather["err"] = repr(e)
+
+    def step(t, hh=h, out=d_out):
+        hh.solve_batch(0, B, tick_dicts[t % len(tick_dicts)], out, stream=sp)
+        if gather["ok"]:
+            hh.allgather_tau(gather["comm"], out["tau"].data_ptr(), tau_all.data_ptr(), B * max(st.na, 1), stream=sp)
 
     def fence():
         torch.cuda.synchronize()
@@ -175,35 +278,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # one HIP event pair over the timed region, on the stream the kernels are launched on: per-launch duration = region / K
-    # (it includes the two order kernels of every 4th step).  Not one pair per step: measured with rocprofv3, every event
-    # record left a 10 us bubble in front of the next solve kernel -- 3.5 % of a step spent on the measurement itself.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
-        if gather_state["ok"]:
-            dist.all_gather_into_tensor(tau_all, d_out["tau"])
-    ev1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(n_steps, warm, hh=h, out=d_out, t_first=0):
+        """(wall seconds, event seconds) of exactly n_steps steps after `warm` untimed ones"""
+        for t in range(warm):
+            step(t_first + t, hh, out)
+        fence()
+        # one HIP event pair over the timed region, on the stream the kernels are launched on (one pair per step left a
+        # 10 us bubble in front of every solve kernel -- rocprofv3 trace, round 1)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for t in range(n_steps):
+            step(t_first + warm + t, hh, out)
+        ev1.record()
+        fence()
+        el = time.perf_counter() - t0
+        return el, ev0.elapsed_time(ev1) * 1e-3
+
+    elapsed, ev_s = timed(args.steps, args.warmup)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_avg_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
+    kern_avg_s = ev_s / args.steps
 
+    # the last timed step's outputs, with the tick they belong to (parity sample below)
+    last_tick = (args.warmup + args.steps - 1) % len(tick_dicts)
     status = d_out["status"].cpu().numpy()
     iters = d_out["iters"].cpu().numpy()
-    x_gpu = d_out["x"].cpu().numpy()
-    tau_gpu = d_out["tau"].cpu().numpy()[:, :st.na]
+    x_gpu = d_out["x"].cpu().numpy().astype(np.float64)
+    tau_gpu = d_out["tau"].cpu().numpy()[:, :st.na].astype(np.float64)
 
     traffic = args.traffic
-    if traffic is None and args.robot == "talos":
+    if traffic is None and args.robot == "talos" and not f32:
         try:  # committed PMC measurement (separate --pmc passes), scaled to this launch's batch
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)
@@ -215,25 +322,34 @@ def main():
     if rank == 0:
         total_qps = world * B * args.steps
         value = total_qps / elapsed
-        abytes = ALGORITHMIC_BYTES.get(args.robot, st.algorithmic_bytes())
+        ab64 = ALGORITHMIC_BYTES.get(args.robot, st.algorithmic_bytes())
+        abytes = (ab64 - 8) // 2 + 8 if f32 else ab64
         achieved = abytes * B / kern_avg_s / 1e9
+        per_cu = layout["waves_per_cu"]
+        queued = (per_cu == 1 or (base_flags & capi.FLAG_QUEUE)) and not (base_flags & capi.FLAG_HW_DISPATCH)
+        compact = per_cu >= 2 or layout["lds_bytes"] <= 80 * 1024
+        tname = "float" if f32 else "double"
+        kernel = "wbcqp::%s<%s, %s>" % ("solve_queue_kernel" if queued else "solve_kernel", tname, "true" if compact and not (base_flags & capi.FLAG_FULL_LDS) else "false")
         result = {
             "metric": "QP solves/sec (Talos ~50-var WBC tick)" if args.robot == "talos" else "QP solves/sec (%s)" % args.robot,
             "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s_pos_tracker%s_b%d_fp64_one_workgroup_per_qp" % (args.robot, "_squat" if args.squat else "", B),
+            "config": {"workload": "%s_pos_tracker_b%d_%s_%s" % (args.robot, B, "fp32_boundary" if f32 else "fp64",
+                                                                 "squat_tick_stream" if stream else "replayed_batch"),
                        "batch_per_gpu": B, "n": st.n, "neq": st.neq, "nin": st.nin, "level1_rows": st.r1,
+                       "boundary_dtype": args.dtype,
                        "parallelism": "batch-shard x%d" % world,
+                       "stream": ("instance i at step t solves tick (i + t) of the squat CoM reference (etc/talos/squat.yaml, move_com.cpp:22-45); "
+                                  "%d consecutive ticks resident, cycled" % N_TICKS) if stream else "the same batch every step",
                        "schedule": "index-order" if args.index_order else
-                       ("queue of resident workgroups; order bin-packed from the iteration counts of an earlier step, renewed every 4th launch"
-                        if layout["waves_per_cu"] == 1 else
-                        "hardware dispatch (several workgroups per CU), longest-first from the iteration counts of an earlier step"),
-                       "allgather_tau": bool(gather_state["ok"]), "lds_bytes_per_qp": layout["lds_bytes"],
-                       "qps_resident_per_cu": layout["waves_per_cu"]},
+                       ("queue of resident workgroups; order from the iteration counts of an earlier launch, renewed every 4th launch" if queued else
+                        "hardware dispatch, longest-first from the iteration counts of an earlier launch, renewed every 4th launch"),
+                       "allgather_tau": bool(gather["ok"]), "lds_bytes_per_qp": layout["lds_bytes"],
+                       "qps_resident_per_cu": per_cu},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "wbcqp::solve_queue_kernel<double>", "kernel_ms": kern_avg_s * 1e3,
+                         "kernel": kernel, "kernel_ms": kern_avg_s * 1e3,
                          "algorithmic_bytes_per_qp": abytes},
             "active_set": {"iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
                            "iters_hist": np.bincount(np.minimum(iters, 15), minlength=16).tolist(),
@@ -243,16 +359,76 @@ def main():
         result["fp64"] = {"flops_per_qp": flops, "achieved_TFLOPs": flops * B / kern_avg_s / 1e12,
                           "note": "analytic useful flops (Structure.flops_estimate) at the batch's mean iteration count; the path is a "
                                   "chain of dependent operations, see DESIGN.md section 4"}
-        if gather_state["err"]:
-            result["config"]["allgather_error"] = gather_state["err"]
-        if world == 1 and args.robot == "talos":
+        if gather["err"]:
+            result["config"]["allgather_error"] = gather["err"]
+
+        if world == 1 and stream:
+            # how alike are consecutive ticks?  (the launch order is built on it)
+            o1, o2 = new_out(), new_out()
+            h.solve_batch(0, B, tick_dicts[5], o1, stream=sp)
+            h.solve_batch(0, B, tick_dicts[6], o2, stream=sp)
+            h.solve_batch(0, B, tick_dicts[9], d_out, stream=sp)
+            torch.cuda.synchronize()
+            i1, i2, i4 = (o["iters"].cpu().numpy() for o in (o1, o2, d_out))
+            result["tick_to_tick"] = {"iters_corr_1_tick": _corr(i1, i2), "iters_equal_1_tick": float((i1 == i2).mean()),
+                                      "iters_corr_4_ticks": _corr(i1, i4), "iters_equal_4_ticks": float((i1 == i4).mean()),
+                                      "note": "active-set iteration counts of the same instances one and four ticks apart (the launch order is at most four launches old)"}
+
+        if world == 1 and not args.no_compare:
+            # a region of >= 0.5 s of the same stream: the K-step figure above must agree with it
+            n_long = max(args.steps, int(0.6 / max(kern_avg_s, 1e-6)))
+            el, evl = timed(n_long, 2)
+            result["long_run"] = {"value": B * n_long / el, "unit": "QP/s", "steps": n_long, "seconds": el, "kernel_ms": evl / n_long * 1e3}
+
+            def variant(flags, note, replay=False, fresh=None):
+                h2 = capi.Handle(device=local_rank, dtype=cdt, flags=flags)
+                h2.set_structure(0, st)
+                n2 = max(args.steps, 100)
+                o2 = new_out()
+
+                def st2(t):
+                    if fresh is not None:
+                        h2.solve_batch(0, B, fresh[t % len(fresh)], o2, stream=sp)
+                    elif replay:
+                        h2.solve_batch(0, B, tick_dicts[0], o2, stream=sp)
+                    else:
+                        h2.solve_batch(0, B, tick_dicts[t % len(tick_dicts)], o2, stream=sp)
+
+                for t in range(8):
+                    st2(t)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for t in range(n2):
+                    st2(8 + t)
+                torch.cuda.synchronize()
+                r = {"value": B * n2 / (time.perf_counter() - t1), "unit": "QP/s", "note": note}
+                h2.close()
+                return r
+
+            Q, HW = capi.FLAG_QUEUE, capi.FLAG_HW_DISPATCH
+            result["replayed_batch"] = variant(base_flags, "the same batch every step: the order comes from the very QPs it schedules (round 1's headline; an upper bound)", replay=True)
+            result["index_order"] = variant(capi.FLAG_INDEX_ORDER, "same stream, QPs taken in index order (no schedule at all)")
+            result["hw_dispatch"] = variant(HW, "same stream, longest-first, one workgroup per QP dealt out by the hardware's dispatcher")
+            result["queue_packed"] = variant(Q, "same stream, resident workgroups take QPs from a queue, bin-packed order where the launch is small enough")
+            result["queue_longest_first"] = variant(Q | capi.FLAG_NO_PACKING, "same stream, queue, plain longest-first order")
+            result["refresh_every_launch"] = variant(base_flags | capi.flag_refresh(1), "same stream, order renewed after every launch (default: every 4th, WBCQP_FLAG_REFRESH)")
+            result["full_lds_layout"] = variant(capi.FLAG_FULL_LDS, "same stream on round 1's layout: every array of the QP in LDS (Talos: one QP per CU), queue + packed order")
+            try:  # unrelated batches: every launch is scheduled from the counts of QPs that have nothing to do with it
+                fresh = []
+                for j in range(4):
+                    fi = synth.generate(st, B, synth.SEED_BASE[args.robot] + 100_000 * (j + 1))
+                    fresh.append({k: torch.from_numpy(np.ascontiguousarray(v.astype(ndt))).to(dev) for k, v in fi.items() if v.size})
+                result["unrelated_batches"] = variant(base_flags, "four unrelated batches in rotation: the order of a launch comes from other QPs (a lower bound: worse than no order only if the library mis-orders)", fresh=fresh)
+            except Exception as e:  # noqa: BLE001
+                result["unrelated_batches"] = {"error": repr(e)}
+
+        if world == 1 and args.robot == "talos" and not f32:
             # after the path: state integration kernel on the solver's own output, outside `value`
             nvv, nq = st.nv, st.nv + 1
             gq = torch.zeros(B, nq, dtype=torch.float64, device=dev)
             gq[:, 6] = 1.0
             gdq = torch.zeros(B, nvv, dtype=torch.float64, device=dev)
             gqn, gvn, gqs = torch.zeros_like(gq), torch.zeros_like(gdq), torch.zeros_like(gdq)
-            sp = torch.cuda.current_stream().cuda_stream
             for _ in range(3):
                 h.integrate(B, nvv, True, 1e-3, gq, gdq, d_out["x"], st.n, d_out["status"], gqn, gvn, gqs, stream=sp)
             torch.cuda.synchronize()
@@ -266,91 +442,79 @@ def main():
             ibytes = B * (8 * (2 * nq + 4 * nvv) + 4)  # q, dq, dv in; q_next, v_next, q_solver out; status
             result["after_path"] = {"kernel": "wbcqp::integrate_kernel<double>", "us_per_launch": us, "bytes_per_launch": ibytes,
                                     "achieved_GBps": ibytes / (us * 1e-6) / 1e9, "bound": "hbm (launch-latency sized at this batch)"}
-        if world == 1 and args.robot == "talos":
             try:  # secondary section: never allowed to take the headline line down with it
                 result["before_path"] = before_path(h, st, dev, B, torch, not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001
                 result["before_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and not args.index_order and not args.no_compare:
-            # the same K steps (a) in plain index order, (b) longest-first but one workgroup per QP through the hardware's
-            # dispatcher instead of resident workgroups and a queue -- both reported beside `value`
-            for key, flags, note in (
-                    ("index_order", capi.FLAG_INDEX_ORDER, "same batch, QPs taken in index order (no schedule from the previous step)"),
-                    ("hw_dispatch", capi.FLAG_HW_DISPATCH, "same batch, longest-first, one workgroup per QP dealt out by the hardware "
-                                                           "(XCD i % 8, shader engine (i / 8) % 4, in order) instead of the queue"),
-                    ("queue_longest_first", capi.FLAG_NO_PACKING, "same batch, queue, plain longest-first order (no bin packing)"),
-                    ("refresh_every_launch", capi.flag_refresh(1), "same batch, queue, packed order renewed after every launch "
-                                                                    "(default: every 4th, WBCQP_FLAG_REFRESH)")):
-                h2 = capi.Handle(device=local_rank, dtype=capi.F64, flags=flags)
-                h2.set_structure(0, st)
-                for _ in range(args.warmup):
-                    h2.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+
+        if world == 1 and not args.no_sweep and not args.no_compare:
+            # batch 1 .. 8192 on the same stream (BASELINE metric: "at batch 1..8192"); instances beyond 1024 repeat the 1024
+            # generated ones on their own ticks
+            table = []
+            hs = capi.Handle(device=local_rank, dtype=cdt, flags=base_flags)
+            hs.set_structure(0, st)
+            for bsz in SWEEP:
+                reps_in = (bsz + B - 1) // B
+                di = {k: (v.repeat(reps_in, 1)[:bsz].contiguous()) for k, v in d_in.items()}
+                nt = 8 if stream else 1
+                dicts = []
+                for t in range(nt):
+                    d = dict(di)
+                    if stream:
+                        d["b1"] = b1_ticks[(17 * t) % N_TICKS].repeat(reps_in, 1)[:bsz].contiguous() if bsz > B else b1_ticks[t][:bsz].contiguous()
+                    dicts.append(d)
+                do = new_out(bsz)
+                for t in range(6):
+                    hs.solve_batch(0, bsz, dicts[t % nt], do, stream=sp)
                 torch.cuda.synchronize()
+                nrep = 40 if bsz <= 2048 else 20
                 t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    h2.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+                for t in range(nrep):
+                    hs.solve_batch(0, bsz, dicts[t % nt], do, stream=sp)
                 torch.cuda.synchronize()
-                result[key] = {"value": B * args.steps / (time.perf_counter() - t1), "unit": "QP/s", "note": note}
-                h2.close()
+                dt = (time.perf_counter() - t1) / nrep
+                table.append({"batch": bsz, "ms": round(dt * 1e3, 5), "qps": round(bsz / dt, 1),
+                              "frac_hbm": round(abytes * bsz / dt / 1e9 / HBM_PEAK_GBS, 5)})
+            hs.close()
+            result["sweep"] = table
+            if args.sweep:
+                os.makedirs(os.path.dirname(os.path.abspath(args.sweep)), exist_ok=True)
+                with open(args.sweep, "w") as fh:
+                    json.dump(table, fh, indent=1)
 
         if not args.no_cpu_baseline and world == 1:
-            # the oracle is the checker here and the reported CPU baseline -- never the thing shipped
+            # the oracle is the checker here and the reported CPU baseline -- never the thing shipped.  One call per figure:
+            # work items from one counter, per-thread workspace, the clock inside the C driver between the threads' common
+            # start line and the last one's end (loop shape of qp_timer_test.cpp:55-63)
             from oracle import oracle
             oracle.build()
             cores = os.cpu_count() or 1
             nsamp = min(B, 256)
-            sub = {k: v[:nsamp] for k, v in inputs.items()}
-            t1 = time.perf_counter()
-            ref = oracle.tick_batch(st, sub, nthreads=1)
-            single = nsamp / (time.perf_counter() - t1)
-            # all-core run, repeated until the sample is ~cpu_seconds of CPU wall time (bounded)
-            reps, done, tcpu = 0, 0, 0.0
-            budget = max(1.0, args.cpu_seconds - nsamp / single)
-            while tcpu < budget and reps < 64:
-                t1 = time.perf_counter()
-                oracle.tick_batch(st, inputs, nthreads=cores)
-                tcpu += time.perf_counter() - t1
-                done += B
-                reps += 1
-            multi = done / tcpu
+            cpu_in = {k: v.copy() for k, v in inputs.items()}
+            if stream:
+                cpu_in["b1"] = b1_ticks[last_tick].cpu().numpy().astype(np.float64)
+            sub = {k: v[:nsamp] for k, v in cpu_in.items()}
+            s1, ref = oracle.tick_batch_timed(st, sub, nthreads=1, reps=1)
+            single = nsamp / s1
+            budget = max(1.0, args.cpu_seconds - s1)
+            reps = int(max(1, min(4096, budget * single * cores * 0.7 / B)))
+            sm, _ = oracle.tick_batch_timed(st, cpu_in, nthreads=cores, reps=reps)
+            multi = B * reps / sm
             ok = ref["status"] == 0
             xs = np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
             result["cpu_baseline"] = {
                 "value": multi, "unit": "QP/s", "cores": cores, "kind": "port",
-                "sample": "%d x %d Talos QPs of the same batch, %d pthreads; single-thread %.0f QP/s on %d QPs" % (reps, B, cores, single, nsamp)
-                          if args.robot == "talos" else "%d x %d QPs, %d pthreads" % (reps, B, cores),
-                "single_thread": single,
+                "sample": "%d passes over the %d QPs of the last timed tick on %d pthreads (%.1f s); single thread %.0f QP/s on %d QPs" %
+                          (reps, B, cores, sm, single, nsamp),
+                "single_thread": single, "scaling_efficiency": multi / (single * cores), "cpu_model": cpu_model(),
             }
             result["parity"] = {
-                "sample": nsamp,
+                "sample": nsamp, "tick": int(last_tick),
                 "max_rel_dx": float((np.abs(x_gpu[:nsamp] - ref["x"]).max(axis=1) / xs)[ok].max()),
                 "max_abs_dtau": float(np.abs(tau_gpu[:nsamp] - ref["tau"])[ok].max()) if st.na else 0.0,
                 "status_equal": bool(np.array_equal(status[:nsamp], ref["status"])),
                 "iters_equal_frac": float((iters[:nsamp] == ref["iters"]).mean()),
             }
-
-        if args.sweep and world == 1:
-            table = []
-            for b in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
-                si = synth.generate(st, min(b, 1024), synth.SEED_BASE[seed_key])
-                reps_in = (b + 1023) // 1024
-                di = {k: torch.from_numpy(np.ascontiguousarray(np.tile(v, (reps_in, 1))[:b])).to(dev) for k, v in si.items() if v.size}
-                do = dict(x=torch.zeros(b, st.n, dtype=torch.float64, device=dev),
-                          tau=torch.zeros(b, max(st.na, 1), dtype=torch.float64, device=dev),
-                          status=torch.zeros(b, dtype=torch.int32, device=dev), iters=torch.zeros(b, dtype=torch.int32, device=dev))
-                for _ in range(4):
-                    h.solve_batch(0, b, di, do, stream=torch.cuda.current_stream().cuda_stream)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                nrep = 20
-                for _ in range(nrep):
-                    h.solve_batch(0, b, di, do, stream=torch.cuda.current_stream().cuda_stream)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / nrep
-                table.append({"batch": b, "ms": dt * 1e3, "qps": b / dt})
-            os.makedirs(os.path.dirname(os.path.abspath(args.sweep)), exist_ok=True)
-            with open(args.sweep, "w") as fh:
-                json.dump(table, fh, indent=1)
         print(json.dumps(result), flush=True)
 
     h.close()

@@ -18,9 +18,11 @@
  * Plain pointers and sizes only; no C++/torch types.  Nothing throws across this boundary: every
  * entry point returns a wbcqp_status and wbcqp_last_error() gives the text.  A handle is bound to one
  * HIP device and is not thread-safe; distinct handles may be used concurrently (the reference's
- * Controller is single-threaded and non-copyable, controller.hpp:50-51).  After wbcqp_create and
- * wbcqp_set_structure, the device-pointer solve entry points allocate nothing (upstream's solver
- * runs under EIGEN_MALLOC_NOT_ALLOWED).
+ * Controller is single-threaded and non-copyable, controller.hpp:50-51).  The device-pointer solve
+ * entry points allocate nothing in the steady state (upstream's solver runs under
+ * EIGEN_MALLOC_NOT_ALLOWED); the FIRST launch of a larger batch than any before it (launch-order buffer,
+ * 8 bytes per QP, with one stream synchronisation) and the first launch on a new stream (an 8-byte queue
+ * counter) do allocate.  A captured tick (wbcqp_tick_graph_create) owns its buffers and never does.
  */
 #ifndef WBCQP_H
 #define WBCQP_H
@@ -158,6 +160,11 @@ typedef struct {
 #define WBCQP_FLAG_NO_PACKING 4  /* keep the plain longest-first order for the queue.  Default (0): when a launch holds between
                                     one and eight QPs per resident workgroup, the order is bin-packed from the predicted costs
                                     (setup + iterations of the previous launch) so that the workgroups finish together */
+
+#define WBCQP_FLAG_FULL_LDS 16    /* keep every structure on the layout that holds M, Jc and A_c in LDS for the QP's whole life
+                                    (Talos: one QP per CU).  Default (0): structures within n <= 80, nEq <= 22, nv <= 52, two
+                                    contacts (every stack the reference ships) use the compact layout -- half the LDS, two
+                                    QPs resident per CU; same algorithm, results agree to rounding */
 
 #define WBCQP_FLAG_REFRESH_SHIFT 8
 #define WBCQP_FLAG_REFRESH(n) (((n) & 0xff) << WBCQP_FLAG_REFRESH_SHIFT) /* renew the launch order every n-th launch of a shape

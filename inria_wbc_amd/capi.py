@@ -256,6 +256,7 @@ def check_model(st: Structure, model, tm) -> int:
 FLAG_INDEX_ORDER = 1  # wbcqp_desc.flags: launch in index order (default: longest-first, see include/wbcqp.h)
 FLAG_NO_PACKING = 4   # wbcqp_desc.flags: plain longest-first order for the queue (default: bin-packed order for small launches)
 FLAG_QUEUE = 8        # wbcqp_desc.flags: the queue also when several workgroups share a CU (default there: hardware dispatch)
+FLAG_FULL_LDS = 16    # wbcqp_desc.flags: keep the one-QP-per-CU LDS layout (default: compact layout, two QPs per CU, where eligible)
 FLAG_HW_DISPATCH = 2  # wbcqp_desc.flags: one workgroup per QP through the hardware dispatcher (default: resident workgroups + queue)
 
 

@@ -111,16 +111,43 @@ namespace inria_wbc {
             }
 
             const std::string& base_path() const { return base_path_; }
+            // Controller::update (controller.cpp:161-205): open loop integrates the controller's own state; closed loop REQUIRES
+            // the sensor keys the reference requires and builds q = [floating_base_position, positions],
+            // dq = [floating_base_velocity, joint_velocities] per instance (one row per instance instead of one vector)
             virtual void update(const SensorData& sensor_data = {})
             {
-                // open loop when no sensor is given (controller.cpp:203-205); closed loop reads the same keys as the reference
-                auto qi = sensor_data.find("positions"), vi = sensor_data.find("joint_velocities");
-                if (closed_loop_ && qi != sensor_data.end() && vi != sensor_data.end()) {
-                    IWBC_ASSERT(qi->second.rows == batch_ && vi->second.rows == batch_, "closed loop: one sensor row per instance");
-                    _solve(qi->second, vi->second);
-                }
-                else
+                if (!closed_loop_) {
                     _solve();
+                    return;
+                }
+                auto qi = sensor_data.find("positions"), vi = sensor_data.find("joint_velocities");
+                IWBC_ASSERT(qi != sensor_data.end(), "we need the joint positions in closed loop mode!");
+                IWBC_ASSERT(vi != sensor_data.end(), "we need the joint velocities in closed loop mode!");
+                const MatrixXd &pos = qi->second, &vel = vi->second;
+                IWBC_ASSERT(pos.rows == batch_ && vel.rows == batch_, "closed loop: one sensor row per instance (", batch_, ")");
+                if (!floating_base_) {
+                    IWBC_ASSERT(vel.cols == v_tsid_.cols, "Joint velocities do not have the correct size:", vel.cols, " vs (expected)", v_tsid_.cols);
+                    IWBC_ASSERT(pos.cols == q_tsid_.cols, "Joint positions do not have the correct size:", pos.cols, " vs (expected)", q_tsid_.cols);
+                    _solve(pos, vel);
+                    return;
+                }
+                auto fqi = sensor_data.find("floating_base_position"), fvi = sensor_data.find("floating_base_velocity");
+                IWBC_ASSERT(fqi != sensor_data.end(), "we need the floating base position in closed loop mode!");
+                IWBC_ASSERT(fvi != sensor_data.end(), "we need the floating base velocity in closed loop mode!");
+                const MatrixXd &fb_pos = fqi->second, &fb_vel = fvi->second;
+                IWBC_ASSERT(fb_pos.rows == batch_ && fb_vel.rows == batch_, "closed loop: one floating-base row per instance (", batch_, ")");
+                IWBC_ASSERT(vel.cols + fb_vel.cols == v_tsid_.cols, "Joint velocities do not have the correct size:", vel.cols + fb_vel.cols,
+                            " vs (expected)", v_tsid_.cols);
+                IWBC_ASSERT(pos.cols + fb_pos.cols == q_tsid_.cols, "Joint positions do not have the correct size:", pos.cols + fb_pos.cols,
+                            " vs (expected)", q_tsid_.cols);
+                MatrixXd q(batch_, q_tsid_.cols), dq(batch_, v_tsid_.cols);
+                for (int i = 0; i < batch_; ++i) {
+                    std::copy(fb_pos.row(i), fb_pos.row(i) + fb_pos.cols, q.row(i));
+                    std::copy(pos.row(i), pos.row(i) + pos.cols, q.row(i) + fb_pos.cols);
+                    std::copy(fb_vel.row(i), fb_vel.row(i) + fb_vel.cols, dq.row(i));
+                    std::copy(vel.row(i), vel.row(i) + vel.cols, dq.row(i) + fb_vel.cols);
+                }
+                _solve(q, dq);
             }
 
             int batch_size() const { return batch_; }
@@ -131,13 +158,17 @@ namespace inria_wbc {
             virtual void set_behavior_type(const std::string& bt) { behavior_type_ = bt; }
             const std::string& behavior_type() const { return behavior_type_; }
 
-            // one row per instance (the reference returns one Eigen::VectorXd)
-            const MatrixXd& tau() const { return tau_; }
+            // one row per instance (the reference returns one Eigen::VectorXd), in the reference's "DART" format
+            // (controller.cpp:262-281): ndofs = nv entries; a floating base is [position(3), angle * axis(3)] in q and six
+            // leading zeros in tau.  There are no mimic joints in the stacks this facade loads, so filter_mimics is the identity.
+            const MatrixXd& tau() const { return tau_dart_; }
             const MatrixXd& ddq() const { return a_tsid_; }
             const MatrixXd& dq() const { return v_tsid_; }
-            const MatrixXd& q() const { return q_tsid_; }
-            const MatrixXd& q_solver() const { return q_tsid_; }
+            const MatrixXd& q() const { return q_solver_; }
+            const MatrixXd& q_solver() const { return q_solver_; }
+            // tsid's own forms: q with the base quaternion (nq = nv + 1 entries), tau of the actuated joints only (na entries)
             const MatrixXd& q_tsid() const { return q_tsid_; }
+            const MatrixXd& tau_tsid() const { return tau_; }
             const std::vector<std::string>& activated_contacts() const { return activated_contacts_; }
             // 12 force components per activated contact and instance (tsid getContactForces, controller.cpp:258-261)
             const std::unordered_map<std::string, MatrixXd>& activated_contacts_forces() const { return activated_contacts_forces_; }
@@ -183,6 +214,7 @@ namespace inria_wbc {
                 IWBC_ASSERT(q.cols == (floating_base_ ? nv + 1 : nv), "q must hold ", floating_base_ ? nv + 1 : nv, " entries per instance");
                 MatrixXd vnew(B, nv);
                 MatrixXd qnew(B, q.cols);
+                MatrixXd qsol(B, nv);
                 const bool whole_tick = source_->handles_references();
                 if (whole_tick) {
                     // rows, QP and integration in one trip to the device: only the state and the references go up, the solution
@@ -197,7 +229,7 @@ namespace inria_wbc {
                     io.out = out;
                     io.q_next = qnew.data.data();
                     io.v_next = vnew.data.data();
-                    io.q_solver = nullptr;
+                    io.q_solver = qsol.data.data();
                     io.dt = dt_;
                     if (wbcqp_tick_host(handle_, _slot(), B, &io) != WBCQP_OK) IWBC_ERROR("wbcqp_tick_host failed: ", wbcqp_last_error(handle_));
                 }
@@ -230,10 +262,15 @@ namespace inria_wbc {
                     for (int j = 0; j < nv; ++j) a_tsid_(i, j) = x_[(size_t)i * n + j];
                 if (!whole_tick &&
                     wbcqp_integrate_host(handle_, B, nv, floating_base_ ? 1 : 0, dt_, q.data.data(), dq.data.data(), x_.data(), n,
-                                         status_.data(), qnew.data.data(), vnew.data.data(), nullptr) != WBCQP_OK)
+                                         status_.data(), qnew.data.data(), vnew.data.data(), qsol.data.data()) != WBCQP_OK)
                     IWBC_ERROR(wbcqp_last_error(handle_));
                 v_tsid_ = vnew;
                 q_tsid_ = qnew;
+                q_solver_ = qsol;
+                // tau_ << 0, 0, 0, 0, 0, 0, tau_tsid_ for a floating base (controller.cpp:269); tau_tsid_ itself otherwise
+                tau_dart_ = MatrixXd(B, nv);
+                for (int i = 0; i < B; ++i)
+                    for (int j = 0; j < na; ++j) tau_dart_(i, nv - na + j) = tau_(i, j);
                 t_ += dt_;
                 activated_contacts_forces_.clear();
                 for (size_t c = 0; c < st.contacts().size(); ++c) {
@@ -251,7 +288,7 @@ namespace inria_wbc {
             std::string base_path_, behavior_type_, solver_to_use_;
             int batch_ = 0;
 
-            MatrixXd q_tsid_, v_tsid_, a_tsid_, tau_;
+            MatrixXd q_tsid_, v_tsid_, a_tsid_, tau_, tau_dart_, q_solver_;
             std::vector<double> x_, objective_;
             VectorXi status_, iters_;
             std::vector<std::string> activated_contacts_, all_contacts_;

@@ -5,7 +5,9 @@
 //   qp_timer_test <controller.yaml> <behavior.yaml> <batch.bin | -> [n_ticks=10] [tau_out.bin] [first_tick=0] [q_out.bin]
 // With `-` for the batch file the controller must carry its own model (CONTROLLER.model): the rows come from the robot
 // state on the device (ModelSource), the loop is closed through the integrated state, and the final q can be written too.
+#include <algorithm>
 #include <csignal>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 
@@ -33,7 +35,13 @@ int main(int argc, char** argv)
         const std::string ctrl_path = argv[1];
         yaml::Node c_config = IWBC_CHECK(yaml::LoadFile(ctrl_path));
         c_config["CONTROLLER"].set("base_path", ctrl_path.substr(0, ctrl_path.find_last_of('/')));
+        // IWBC_SENSOR_LOOP=1: closed loop (controller.cpp:161-205) on sensor data in the reference's shape, made from the
+        // controller's own integrated state: positions / joint_velocities hold the joints only, the base travels in
+        // floating_base_position / floating_base_velocity.  IWBC_SENSOR_LOOP=missing: closed loop with no sensor data at all.
+        const char* sensor_loop = std::getenv("IWBC_SENSOR_LOOP");
+        if (sensor_loop) c_config["CONTROLLER"].set("closed_loop", "true");
         auto controller_name = IWBC_CHECK(c_config["CONTROLLER"]["name"].as<std::string>());
+        if (const char* as = std::getenv("IWBC_CONTROLLER_NAME")) controller_name = as; // e.g. talos-pos-tracker on the same file
         auto controller = controllers::Factory::instance().create(controller_name, c_config);
         if (std::string(argv[3]) != "-") controller->set_problem_source(std::make_shared<controllers::FileSource>(argv[3]));
 
@@ -47,8 +55,26 @@ int main(int argc, char** argv)
         utils::Timer timer;
         int it = 0;
         while (!stop && it < n_ticks) {
+            controllers::SensorData sensors;
+            if (sensor_loop && std::string(sensor_loop) == "1") {
+                const auto &q = controller->q_tsid(), &v = controller->dq();
+                const int B = q.rows, nq = q.cols, nvv = v.cols, fb = (nq == nvv + 1) ? 7 : 0, fbv = fb ? 6 : 0;
+                controllers::MatrixXd pos(B, nq - fb), vel(B, nvv - fbv), fpos(B, fb), fvel(B, fbv);
+                for (int i = 0; i < B; ++i) {
+                    std::copy(q.row(i), q.row(i) + fb, fpos.row(i));
+                    std::copy(q.row(i) + fb, q.row(i) + nq, pos.row(i));
+                    std::copy(v.row(i), v.row(i) + fbv, fvel.row(i));
+                    std::copy(v.row(i) + fbv, v.row(i) + nvv, vel.row(i));
+                }
+                sensors["positions"] = pos;
+                sensors["joint_velocities"] = vel;
+                if (fb) {
+                    sensors["floating_base_position"] = fpos;
+                    sensors["floating_base_velocity"] = fvel;
+                }
+            }
             timer.begin("solver");
-            behavior->update();
+            behavior->update(sensors);
             timer.end("solver");
             timer.report(std::cout, it++, 1);
         }
@@ -60,12 +86,12 @@ int main(int argc, char** argv)
             }
         if (argc > 5) {
             std::ofstream f(argv[5], std::ios::binary);
-            const auto& tau = controller->tau();
+            const auto& tau = controller->tau_tsid(); // na entries per instance (tau() pads a floating base with six zeros)
             f.write(reinterpret_cast<const char*>(tau.data.data()), (std::streamsize)(tau.data.size() * sizeof(double)));
         }
         if (argc > 7) {
             std::ofstream f(argv[7], std::ios::binary);
-            const auto& q = controller->q();
+            const auto& q = controller->q_tsid(); // quaternion form, nq entries (q() is the reference's angle-axis form)
             f.write(reinterpret_cast<const char*>(q.data.data()), (std::streamsize)(q.data.size() * sizeof(double)));
         }
     }

@@ -71,6 +71,8 @@ int main(int argc, char** argv)
     }
     // ---- factories: unknown name lists the known ones; known names are registered ----
     UTEST_CHECK(controllers::Factory::instance().has("pos-tracker"));
+    // the reference's two humanoid controllers load under their own names (humanoid_pos_tracker.cpp:35, talos_pos_tracker.cpp:35)
+    UTEST_CHECK(controllers::Factory::instance().has("humanoid-pos-tracker") && controllers::Factory::instance().has("talos-pos-tracker"));
     UTEST_CHECK(behaviors::Factory::instance().has("humanoid::move_com"));
     UTEST_CHECK(behaviors::Factory::instance().has("generic::cartesian") && behaviors::Factory::instance().has("generic::cartesian_traj"));
     UTEST_CHECK(behaviors::Factory::instance().has("humanoid::walk-on-spot") && behaviors::Factory::instance().has("humanoid::move-feet") &&
@@ -85,6 +87,7 @@ int main(int argc, char** argv)
         UTEST_CHECK_EXCEPTION(controllers::Factory::instance().create("pos-tracker", c), "must be either");
         c["CONTROLLER"].set("solver", "eiquadprog");
         UTEST_CHECK_EXCEPTION(controllers::Factory::instance().create("pos-tracker", c), "not available");
+        UTEST_CHECK_EXCEPTION(controllers::Factory::instance().create("talos-pos-tracker", c), "not available");
     }
     // ---- min jerk ----
     {

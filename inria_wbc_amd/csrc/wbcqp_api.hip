@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -28,8 +29,10 @@ thread_local std::string g_create_error;
 struct Slot {
     bool set = false;
     DevStruct host{};           // sizes, LDS layout and device pointers of the tables: travels by value with every launch
+    DevStruct host_cp{};        // the same with the compact LDS layout (wbcqp_compact.hpp); host_cp.compact == 0: not eligible
     std::vector<void*> allocs;  // device arrays owned by this slot
-    wbcqp_layout layout{};
+    wbcqp_layout layout{};      // what wbcqp_layout_of reports: the compact layout where the structure is eligible
+    int lds_full = 0, lds_cp = 0;
     bool has_model = false;     // wbcqp_set_model: tree + task bindings for wbcqp_problem_data
     TermsDev terms{};
     std::vector<void*> model_allocs;
@@ -42,6 +45,20 @@ struct Staging {
 
 } // namespace
 
+// launch-order state: the order left by one launch for the next one of the same shape on the same stream.  The handle has
+// one; every captured tick (wbcqp_graph) has its own, so that a replay never touches a buffer another launch may resize or
+// overwrite (a graph bakes the buffer's address into its kernel nodes).
+struct OrderState {
+    int* order = nullptr;        // [2][cap]: longest-first, then the packed order (pack_order_kernel)
+    bool packed = false;         // the second half is valid for total / sig / stream
+    int age = 0;                 // launches that have used the order since it was computed
+    int cap = 0;
+    int total = 0;               // 0: no valid order
+    unsigned long long sig = 0;  // shape of the launch the order belongs to
+    hipStream_t stream = nullptr;
+    int* queue = nullptr;        // graphs only: their own queue counter
+};
+
 constexpr size_t kMaxQueues = 16;
 constexpr int kOrderRefresh = 4; // default period of the launch-order renewal (WBCQP_FLAG_REFRESH)
 
@@ -51,18 +68,13 @@ struct wbcqp_handle {
     std::string err;
     Slot slots[WBCQP_MAX_STRUCTURES];
     Staging stage_in, stage_out;
-    int max_lds = 0;
+    int max_lds[2] = {0, 0};   // per kernel variant (full, compact): largest dynamic LDS size set so far
     long long* dbg = nullptr; // diagnostic builds only (wbcqp_debug_set_stamp_buffer)
     // longest-first schedule (schedule_kernel): launch order for the next solve of the same shape on the same stream
     int flags = 0;
-    int* order = nullptr;        // [2][order_cap]: longest-first, then the packed order (pack_order_kernel)
-    bool order_packed = false;   // the second half is valid for order_total / order_sig / order_stream
-    int order_age = 0;           // launches that have used the order since it was computed
-    bool capturing = false;      // wbcqp_tick_graph_create: a captured tick always renews its order
-    int order_cap = 0;
-    int order_total = 0;              // 0: no valid order
-    unsigned long long order_sig = 0; // shape of the launch the order belongs to
-    hipStream_t order_stream = nullptr;
+    OrderState ord;
+    OrderState* graph_ord = nullptr; // wbcqp_tick_graph_create: the launches of this tick use the graph's own order state
+    bool capturing = false;          // ... and a captured tick always renews its order
     // solve_queue_kernel: one counter pair per stream this handle has launched on (two launches in flight on two streams
     // must not share one); more streams than kMaxQueues fall back to the hardware's dispatch
     struct Queue {
@@ -71,7 +83,8 @@ struct wbcqp_handle {
     };
     std::vector<Queue> queues;
     int n_cu = 0;
-    int queue_lds = -1, queue_occ = 0; // occupancy of solve_queue_kernel at queue_lds bytes of LDS
+    int lds_pad = 0; // diagnostic (env WBCQP_DEBUG_LDS_PAD): extra dynamic LDS per workgroup, to force a lower residency
+    int queue_lds[2] = {-1, -1}, queue_occ[2] = {0, 0}; // occupancy of solve_queue_kernel<., CP> at queue_lds bytes of LDS
 };
 
 namespace {
@@ -93,6 +106,7 @@ int fail(wbcqp_handle* h, int code, const std::string& msg)
     } while (0)
 
 int odd(int v) { return v | 1; }
+void set_lds(wbcqp_layout& L, int lds_bytes);
 
 // Validates a structure and derives sizes + LDS layout. Pure host code.
 int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout& L, std::string& why)
@@ -163,20 +177,56 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
     D.o_int = o;
     o += kIntCount / 2 + 2;
     D.lds_doubles = o;
+    D.compact = 0;
 
     std::memset(&L, 0, sizeof(L));
     L.n = n; L.neq = D.neq; L.nin = D.nin2 / 2; L.nin2 = D.nin2; L.r1 = D.r1;
     L.len_M = nv * (nv + 1) / 2; L.len_h = nv; L.len_A = D.n_dense * nv; L.len_b1 = D.r1;
     L.len_Ac = D.nc * 6 * nv; L.len_bc = D.nc * 6; L.len_blb = D.n_bound; L.len_bub = D.n_bound;
     L.len_tlb = D.act_bounds ? D.na : 0; L.len_tub = L.len_tlb; L.len_w = D.n_tasks;
-    L.lds_bytes = o * 8;
-    L.waves_per_cu = L.lds_bytes > 0 ? (160 * 1024) / L.lds_bytes : 0;
-    if (L.waves_per_cu > 32) L.waves_per_cu = 32;
+    set_lds(L, o * 8);
     const int64_t n_in = (int64_t)L.len_M + L.len_h + L.len_A + L.len_b1 + L.len_Ac + L.len_bc + L.len_blb + L.len_bub +
                          L.len_tlb + L.len_tub + L.len_w;
     L.algorithmic_bytes = 8 * (n_in + n + D.na) + 8;
     if (L.lds_bytes > 160 * 1024) { why = "QP does not fit the 160 KiB LDS of one CU"; return WBCQP_ERR_UNSUPPORTED; }
     return WBCQP_OK;
+}
+
+// The compact LDS layout of an eligible structure (wbcqp_compact.hpp): J region | R region | vectors | ints; everything
+// else is staged inside the first two while they are idle, or never enters LDS.  Returns false when not eligible.
+bool derive_compact(const DevStruct& F, DevStruct& D)
+{
+    D = F;
+    D.compact = 0;
+    const int n = F.n, nv = F.nv;
+    if (!(n <= 80 && F.neq <= 22 && nv <= 52 && F.nc <= 2 && F.nu <= 8 && F.na <= 64 && F.n_bound <= 64 && F.nin2 <= 256 &&
+          F.r1 <= 128 && F.n_tasks <= 64))
+        return false;
+    int o = 0;
+    auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; };
+    const int as_size = (F.n_dense * 66 + 8 + 1) & ~1;   // staged task rows: 64 columns + (w, b) pairs
+    int jsize = n * F.ldj;
+    if (as_size + 1024 > jsize) jsize = as_size + 1024;  // + the elimination's panels (2 x 2 x 256)
+    D.o_pan = as_size;
+    D.o_J = take(jsize);
+    int rs = n * (n + 3) / 2 + 2;
+    if (F.neq > 0 && 256 + (n + 4) * F.ldb + 8 > rs) rs = 256 + (n + 4) * F.ldb + 8; // N = CE', then B = J0'N
+    D.o_R = take(rs);
+    D.o_vec = take(cp::COUNT);
+    D.o_int = o;
+    o += cp::ICOUNT / 2;
+    D.o_M = D.o_Jc = D.o_Ac = D.o_eqw = D.o_eqt = 0;
+    D.fric_lds = 0;
+    D.lds_doubles = o;
+    D.compact = 1;
+    return true;
+}
+
+void set_lds(wbcqp_layout& L, int lds_bytes)
+{
+    L.lds_bytes = lds_bytes;
+    L.waves_per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 0;
+    if (L.waves_per_cu > 2) L.waves_per_cu = 2; // registers: the solve kernels allocate 256 VGPRs = two waves per SIMD = two workgroups per CU
 }
 
 template <typename T>
@@ -207,9 +257,9 @@ void release(Slot& s)
 }
 
 template <typename TI>
-void fill_group(GroupArgs<TI>& g, const Slot& s, int batch, const wbcqp_inputs* in, const wbcqp_outputs* out)
+void fill_group(GroupArgs<TI>& g, const Slot& s, bool compact, int batch, const wbcqp_inputs* in, const wbcqp_outputs* out)
 {
-    g.st = s.host;
+    g.st = compact ? s.host_cp : s.host;
     g.M = static_cast<const TI*>(in->M); g.h = static_cast<const TI*>(in->h); g.A = static_cast<const TI*>(in->A);
     g.b1 = static_cast<const TI*>(in->b1); g.Ac = static_cast<const TI*>(in->Ac); g.bc = static_cast<const TI*>(in->bc);
     g.blb = static_cast<const TI*>(in->blb); g.bub = static_cast<const TI*>(in->bub);
@@ -240,14 +290,17 @@ int check_io(wbcqp_handle* h, const Slot& s, int batch, const wbcqp_inputs* in, 
     return WBCQP_OK;
 }
 
-template <typename TI>
+template <typename TI, bool CP>
 int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipStream_t stream)
 {
     if (total == 0) return WBCQP_OK;
-    if (lds_bytes > h->max_lds) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<TI>),
+    constexpr int V = CP ? 1 : 0;
+    if (lds_bytes > h->max_lds[V]) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<TI, CP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        h->max_lds = lds_bytes;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel<TI, CP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        h->max_lds[V] = lds_bytes;
     }
     // schedule: the order left by the previous launch is used when it is of this very shape and was produced on this
     // stream (stream order then guarantees that it is complete); otherwise index order
@@ -262,69 +315,72 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         sa.iters[g] = tab.g[g].iters;
         sa.count[g] = tab.g[g].count;
     }
-    tab.order = (sched && h->order_total == total && h->order_sig == sig && h->order_stream == stream)
-                    ? h->order + (h->order_packed ? h->order_cap : 0) : nullptr;
+    OrderState& os = h->graph_ord ? *h->graph_ord : h->ord;
+    tab.order = (sched && os.total == total && os.sig == sig && os.stream == stream)
+                    ? os.order + (os.packed ? os.cap : 0) : nullptr;
     // The queue pays when a workgroup fills a CU: then the dispatcher's binding of a workgroup to one shader engine leaves
     // CUs idle.  Small QPs (several workgroups per CU: Franka, 3) give the dispatcher slack, and one hand-over (1 us) is a
     // tenth of such a QP -- measured 27 M QP/s through the queue against 36 M through the hardware.  WBCQP_FLAG_QUEUE forces it.
-    if (h->queue_lds != lds_bytes) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel<TI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds));
+    if (h->queue_lds[V] != lds_bytes) {
         int occ = 0;
-        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI>, kThreads, (size_t)lds_bytes));
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI, CP>, kThreads, (size_t)lds_bytes));
         if (occ < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel: no workgroup fits a CU");
-        h->queue_occ = occ;
-        h->queue_lds = lds_bytes;
+        h->queue_occ[V] = occ;
+        h->queue_lds[V] = lds_bytes;
     }
+    const int queue_occ = h->queue_occ[V];
     int* queue = nullptr;
-    if (!(h->flags & WBCQP_FLAG_HW_DISPATCH) && (h->queue_occ == 1 || (h->flags & WBCQP_FLAG_QUEUE))) {
-        for (auto& q : h->queues)
-            if (q.stream == stream) queue = q.ctr;
-        if (!queue && h->queues.size() < kMaxQueues) {
+    if (!(h->flags & WBCQP_FLAG_HW_DISPATCH) && (queue_occ == 1 || (h->flags & WBCQP_FLAG_QUEUE))) {
+        if (h->graph_ord) queue = h->graph_ord->queue;
+        else
+            for (auto& q : h->queues)
+                if (q.stream == stream) queue = q.ctr;
+        if (!queue && !h->graph_ord && h->queues.size() < kMaxQueues) {
             HIP_TRY(h, hipMalloc(&queue, 2 * sizeof(int)));
             HIP_TRY(h, hipMemset(queue, 0, 2 * sizeof(int)));
             h->queues.push_back({stream, queue});
         }
     }
     if (queue) {
-        const long long resident = (long long)h->queue_occ * h->n_cu;
-        hipLaunchKernelGGL(solve_queue_kernel<TI>, dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
+        const long long resident = (long long)queue_occ * h->n_cu;
+        hipLaunchKernelGGL((solve_queue_kernel<TI, CP>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
                            stream, tab, queue, total);
     }
     else
-        hipLaunchKernelGGL(solve_kernel<TI>, dim3(total), dim3(kThreads), lds_bytes, stream, tab);
+        hipLaunchKernelGGL((solve_kernel<TI, CP>), dim3(total), dim3(kThreads), lds_bytes, stream, tab);
     HIP_TRY(h, hipGetLastError());
     // the order is renewed every `period` launches: iteration counts drift slowly from tick to tick, the queue absorbs what
     // drift there is, and the two order kernels (4.5 + 15 us) are then a fraction of a launch instead of a twentieth
     const int asked = (h->flags >> WBCQP_FLAG_REFRESH_SHIFT) & 0xff;
     const int period = h->capturing ? 1 : (asked ? asked : kOrderRefresh);
-    if (sched && tab.order && h->order_age + 1 < period)
-        ++h->order_age;
+    if (sched && tab.order && os.age + 1 < period)
+        ++os.age;
     else if (sched) {
-        h->order_age = 0;
-        if (total > h->order_cap) { // first launch of a larger shape: the only allocation on this path
+        os.age = 0;
+        if (total > os.cap) { // first launch of a larger shape (a graph's buffer has its final size from the start)
+            if (h->graph_ord) return fail(h, WBCQP_ERR_INVALID, "captured tick: launch larger than the graph's order buffer");
             HIP_TRY(h, hipStreamSynchronize(stream));
-            if (h->order) (void)hipFree(h->order);
-            h->order = nullptr;
-            h->order_cap = 0;
-            h->order_total = 0;
-            HIP_TRY(h, hipMalloc(&h->order, 2 * sizeof(int) * (size_t)total));
-            h->order_cap = total;
+            if (os.order) (void)hipFree(os.order);
+            os.order = nullptr;
+            os.cap = 0;
+            os.total = 0;
+            HIP_TRY(h, hipMalloc(&os.order, 2 * sizeof(int) * (size_t)total));
+            os.cap = total;
         }
-        hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, stream, sa, h->order, total);
+        hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, stream, sa, os.order, total);
         HIP_TRY(h, hipGetLastError());
         // a few QPs per resident workgroup, one structure, taken from the queue: pack the order (pack_order_kernel)
-        const long long resident = queue ? (long long)h->queue_occ * h->n_cu : 0;
-        h->order_packed = queue && !(h->flags & WBCQP_FLAG_NO_PACKING) && tab.n == 1 && resident % kPackSubs == 0 &&
+        const long long resident = queue ? (long long)queue_occ * h->n_cu : 0;
+        os.packed = queue && !(h->flags & WBCQP_FLAG_NO_PACKING) && tab.n == 1 && resident % kPackSubs == 0 &&
                           total % kPackSubs == 0 && total > resident && total <= 8 * resident && total / kPackSubs <= kPackMaxItems;
-        if (h->order_packed) {
-            PackArgs pa{tab.g[0].iters, h->order, h->order + h->order_cap, total, (int)(resident / kPackSubs)};
+        if (os.packed) {
+            PackArgs pa{tab.g[0].iters, os.order, os.order + os.cap, total, (int)(resident / kPackSubs)};
             hipLaunchKernelGGL(pack_order_kernel, dim3(kPackSubs), dim3(256), 0, stream, pa);
             HIP_TRY(h, hipGetLastError());
         }
-        h->order_total = total;
-        h->order_sig = sig;
-        h->order_stream = stream;
+        os.total = total;
+        os.sig = sig;
+        os.stream = stream;
     }
     return WBCQP_OK;
 }
@@ -356,6 +412,8 @@ int wbcqp_layout_of(const wbcqp_structure* st, wbcqp_layout* out)
     std::string why;
     int rc = derive(st, D, HB, L, why);
     if (rc != WBCQP_OK) return fail(nullptr, rc, why);
+    DevStruct C;
+    if (derive_compact(D, C)) set_lds(L, C.lds_doubles * 8);
     if (out) *out = L;
     return WBCQP_OK;
 }
@@ -381,6 +439,7 @@ int wbcqp_create(const wbcqp_desc* desc, wbcqp_handle** out)
     h->dtype = desc->dtype;
     h->flags = desc->flags;
     h->n_cu = prop.multiProcessorCount;
+    if (const char* pad = std::getenv("WBCQP_DEBUG_LDS_PAD")) h->lds_pad = std::atoi(pad);
     *out = h;
     return WBCQP_OK;
 }
@@ -392,7 +451,7 @@ int wbcqp_destroy(wbcqp_handle* h)
     for (auto& s : h->slots) release(s);
     if (h->stage_in.dev) (void)hipFree(h->stage_in.dev);
     if (h->stage_out.dev) (void)hipFree(h->stage_out.dev);
-    if (h->order) (void)hipFree(h->order);
+    if (h->ord.order) (void)hipFree(h->ord.order);
     for (auto& q : h->queues) (void)hipFree(q.ctr);
     delete h;
     return WBCQP_OK;
@@ -467,8 +526,21 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
             for (int col = 0; col < D.nv; ++col) ap[(size_t)r * D.nv + col] = (unsigned)(r * 64 + (col & 15) * 4 + (col >> 4));
         UP(apack, ap.data(), D.n_dense * D.nv);
     }
+    {
+        std::vector<unsigned> cpk((size_t)nc * 6 * D.nv + 1, 0u);
+        for (int rr = 0; rr < nc * 6; ++rr)
+            for (int kk = 0; kk < D.nv; ++kk) cpk[(size_t)rr * D.nv + kk] = (unsigned)(kk * D.ldb + D.nu + rr);
+        UP(acpack, cpk.data(), nc * 6 * D.nv);
+    }
 #undef UP
     s.host = D;
+    s.lds_full = D.lds_doubles * 8;
+    s.lds_cp = 0;
+    s.host_cp = DevStruct{};
+    if (!(h->flags & WBCQP_FLAG_FULL_LDS) && derive_compact(D, s.host_cp)) {
+        s.lds_cp = s.host_cp.lds_doubles * 8;
+        set_lds(L, s.lds_cp);
+    }
     s.layout = L;
     s.set = true;
     return WBCQP_OK;
@@ -483,24 +555,33 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
     int total = 0, lds = 0, used = 0;
     GroupTable<double> t64{};
     GroupTable<float> t32{};
+    // the compact kernel runs a launch whose groups are all eligible; one group that is not puts the launch on the full layout
+    bool compact = true;
     for (int g = 0; g < n_groups; ++g) {
         const wbcqp_group& G = groups[g];
         if (G.slot < 0 || G.slot >= WBCQP_MAX_STRUCTURES || !h->slots[G.slot].set)
             return fail(h, WBCQP_ERR_INVALID, "group uses a slot with no structure");
+        if (G.batch > 0 && !h->slots[G.slot].host_cp.compact) compact = false;
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        const wbcqp_group& G = groups[g];
         const Slot& s = h->slots[G.slot];
         int rc = check_io(h, s, G.batch, &G.in, &G.out);
         if (rc != WBCQP_OK) return rc;
         if (G.batch == 0) continue;
-        if (h->dtype == WBCQP_F64) { fill_group(t64.g[used], s, G.batch, &G.in, &G.out); t64.g[used].dbg = h->dbg; }
-        else { fill_group(t32.g[used], s, G.batch, &G.in, &G.out); t32.g[used].dbg = h->dbg; }
+        if (h->dtype == WBCQP_F64) { fill_group(t64.g[used], s, compact, G.batch, &G.in, &G.out); t64.g[used].dbg = h->dbg; }
+        else { fill_group(t32.g[used], s, compact, G.batch, &G.in, &G.out); t32.g[used].dbg = h->dbg; }
         ++used;
         total += G.batch;
-        if (s.layout.lds_bytes > lds) lds = s.layout.lds_bytes;
+        const int need = compact ? s.lds_cp : s.lds_full;
+        if (need > lds) lds = need;
     }
     t64.n = used;
     t32.n = used;
-    if (h->dtype == WBCQP_F64) return launch(h, t64, total, lds, static_cast<hipStream_t>(stream));
-    return launch(h, t32, total, lds, static_cast<hipStream_t>(stream));
+    if (h->lds_pad > 0) lds = std::min(lds + h->lds_pad, 160 * 1024);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (h->dtype == WBCQP_F64) return compact ? launch<double, true>(h, t64, total, lds, hs) : launch<double, false>(h, t64, total, lds, hs);
+    return compact ? launch<float, true>(h, t32, total, lds, hs) : launch<float, false>(h, t32, total, lds, hs);
 }
 
 int wbcqp_solve_batch(wbcqp_handle* h, int slot, int batch, const wbcqp_inputs* in, const wbcqp_outputs* out, void* stream)
@@ -597,13 +678,13 @@ int wbcqp_launch_order(wbcqp_handle* h, int32_t* order, int32_t capacity, int32_
 {
     if (!h || !order || capacity < 0) return WBCQP_ERR_INVALID;
     if (packed) *packed = 0;
-    if (!h->order || h->order_total <= 0) return 0;
-    if (capacity < h->order_total) return fail(h, WBCQP_ERR_INVALID, "wbcqp_launch_order: capacity below the order's length");
+    if (!h->ord.order || h->ord.total <= 0) return 0;
+    if (capacity < h->ord.total) return fail(h, WBCQP_ERR_INVALID, "wbcqp_launch_order: capacity below the order's length");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(order, h->order + (h->order_packed ? h->order_cap : 0), sizeof(int) * (size_t)h->order_total, hipMemcpyDeviceToHost));
-    if (packed) *packed = h->order_packed ? 1 : 0;
-    return h->order_total;
+    HIP_TRY(h, hipMemcpy(order, h->ord.order + (h->ord.packed ? h->ord.cap : 0), sizeof(int) * (size_t)h->ord.total, hipMemcpyDeviceToHost));
+    if (packed) *packed = h->ord.packed ? 1 : 0;
+    return h->ord.total;
 }
 
 int wbcqp_debug_set_stamp_buffer(wbcqp_handle* h, void* dev_ptr)
@@ -1063,6 +1144,7 @@ struct wbcqp_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t capture = nullptr;
+    OrderState ord; // the captured kernels read and write THESE buffers on every replay: nothing else ever touches them
 };
 
 int wbcqp_tick_graph_destroy(wbcqp_handle* h, wbcqp_graph* g)
@@ -1072,6 +1154,8 @@ int wbcqp_tick_graph_destroy(wbcqp_handle* h, wbcqp_graph* g)
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     if (g->capture) (void)hipStreamDestroy(g->capture);
+    if (g->ord.order) (void)hipFree(g->ord.order);
+    if (g->ord.queue) (void)hipFree(g->ord.queue);
     delete g;
     return WBCQP_OK;
 }
@@ -1086,16 +1170,25 @@ int wbcqp_tick_graph_create(wbcqp_handle* h, int slot, int batch, const wbcqp_ti
     wbcqp_graph* g = new wbcqp_graph();
     hipError_t e = hipStreamCreateWithFlags(&g->capture, hipStreamNonBlocking);
     if (e != hipSuccess) { delete g; return fail(h, WBCQP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-    // an ordinary tick on the capture stream first: function attributes, the schedule buffer and its validity for this
-    // stream and shape are then settled, and the capture below contains kernel launches only
+    // the graph's own launch-order buffer and queue counter, at their final size: a replay reads and rewrites them and
+    // nothing else does (the handle's own buffer may be resized or overwritten by any other launch)
+    e = hipMalloc(&g->ord.order, 2 * sizeof(int) * (size_t)batch);
+    if (e == hipSuccess) e = hipMalloc(&g->ord.queue, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(g->ord.queue, 0, 2 * sizeof(int));
+    if (e != hipSuccess) { wbcqp_tick_graph_destroy(h, g); return fail(h, WBCQP_ERR_HIP, std::string("graph buffers: ") + hipGetErrorString(e)); }
+    g->ord.cap = batch;
+    // an ordinary tick on the capture stream first: function attributes are then settled, the graph's order buffer holds a
+    // valid order for this stream and shape, and the capture below contains kernel launches only
+    h->graph_ord = &g->ord;
     int rc = wbcqp_tick(h, slot, batch, io, g->capture);
     if (rc == WBCQP_OK && hipStreamSynchronize(g->capture) != hipSuccess) rc = fail(h, WBCQP_ERR_HIP, "warm-up tick failed");
-    if (rc != WBCQP_OK) { wbcqp_tick_graph_destroy(h, g); return rc; }
+    if (rc != WBCQP_OK) { h->graph_ord = nullptr; wbcqp_tick_graph_destroy(h, g); return rc; }
     e = hipStreamBeginCapture(g->capture, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { wbcqp_tick_graph_destroy(h, g); return fail(h, WBCQP_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { h->graph_ord = nullptr; wbcqp_tick_graph_destroy(h, g); return fail(h, WBCQP_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
     h->capturing = true;
     rc = wbcqp_tick(h, slot, batch, io, g->capture);
     h->capturing = false;
+    h->graph_ord = nullptr;
     e = hipStreamEndCapture(g->capture, &g->graph);
     if (rc != WBCQP_OK || e != hipSuccess || !g->graph) {
         wbcqp_tick_graph_destroy(h, g);

@@ -1,0 +1,985 @@
+// wbcqp_compact.hpp -- the same QP on one workgroup with HALF the LDS: two QPs resident per CU.
+//
+// solve_one (wbcqp_device.hpp) keeps everything a QP ever touches in LDS (Talos: 160 KiB = one QP per CU, one wave per SIMD,
+// 44 % of every wave's cycles waiting with nothing else to issue -- profiles/r01/v15_pmc_sq.csv).  This variant holds only
+// what is touched MORE THAN ONCE PER PHASE:
+//   * J (n x ldj) and the packed R: the two arrays the active-set loop lives on;
+//   * their regions double as staging before they exist: the dense task rows sit in the J region until H is assembled,
+//     the elimination's panels behind them; N = CE' and then B = J0'N sit in the tail of the R region (R has only its neq
+//     first columns until the inequality loop starts);
+//   * M, Jc = T'A_c, A_c and the force generators never enter LDS: the six base-dynamics rows of M and J_u = Jc(:, :6) go
+//     from the record's registers straight into N; the actuation rows [M_a | -J_a'] (44 x 74 for Talos, constant for the
+//     whole loop) are re-read from the L2-resident record once and then live in REGISTERS, four lanes per row, where
+//     act_rows() used to read them from LDS in every iteration;
+//   * vectors in 80-entry slots (n <= 80) with the dead ones aliased; iai / iaexcl as bytes.
+// Talos: 81.2 KB, iCub 60 KB.  Eligibility (host, derive_compact): n <= 80, neq <= 22, nv <= 52, nc <= 2, nu <= 8,
+// nin2 <= 256, r1 <= 128, n_tasks <= 64 -- every stack the reference ships.  Anything else runs solve_one.
+//
+// Same algorithm, same phases, same reference contract as solve_one (controller.cpp:244-251); the row of an actuation or
+// friction constraint is published by the lanes that own it (one more barrier in those iterations).
+#pragma once
+
+#include "wbcqp_prims.hpp"
+#include "wbcqp_factor.hpp"
+#include "wbcqp_equality.hpp"
+#include "wbcqp_activeset.hpp"
+
+namespace wbcqp {
+#ifdef __HIPCC__
+
+namespace cp {
+// vector region (doubles, compile-time offsets from one base: immediates, not pointers in SGPRs)
+constexpr int X = 0, NP = 80, D = 160, Z = 240, XOLD = 320, R = 400, U = 480 /* n + 2 <= 88 */, UOLD = 568, RDINV = 648,
+              PART = 728, TACT = 808 /* 64 */, S = 872 /* 256 */, BLB = 1128, BUB = 1192, TL = 1256, TU = 1320, RED = 1384 /* 32 */,
+              CE0 = 1416 /* 24 */, COUNT = 1440;
+// dead-time aliases: g and 1/sqrt(pivot) die with x0, the weights with the force blocks, b1 with the assembly;
+// the Givens coefficients of delete_constraint (2 n) live where d and z are dead
+constexpr int G = XOLD, DINV = UOLD, W = R, B1 = S, PRM = D;
+// int region (ints)
+constexpr int IA = 0 /* n + 2 <= 84 */, IAOLD = 84, IGSKIP = 164, IMETA = 244 /* 256 */, IACT = 500 /* 256 bytes */, IEXCL = 564,
+              ICOUNT = 628;
+constexpr int NVQ = 13; // ceil(52 / 4): M_a coefficients per lane of a row's quad
+constexpr int KQ = 6;   // 24 / 4:  J_a' coefficients per lane
+} // namespace cp
+
+// the actuation rows [M_a | -J_a'] in registers: lane q4 of row rr's quad keeps columns q4 + 4u
+struct ActRegs {
+    double am[cp::NVQ];
+    double aj[cp::KQ];
+};
+
+// tau' = M_a xn - J_a' fn with xn = x + t z formed on the fly; same lane layout as act_rows().  Every read is base +
+// immediate from ONE per-lane address (q4): coefficients past nv / k are zero and what they multiply is finite -- the x and
+// z slots are zero from n to their end (set once per QP) and nv + 23 < 80.
+__device__ __forceinline__ void act_rows_reg(Ctx& c, const ActRegs& a, double* out, double t)
+{
+    const int nv = c.nv, na = c.na;
+    const int rr = c.tid >> 2, q4 = c.tid & 3;
+    const double* zq = c.z + q4;
+    const double* xq = c.x + q4;
+    const double* zfq = c.z + nv + q4;
+    const double* xfq = c.x + nv + q4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    double zv[cp::NVQ], xv[cp::NVQ];
+#pragma unroll
+    for (int u = 0; u < cp::NVQ; ++u) {
+        zv[u] = zq[4 * u];
+        xv[u] = xq[4 * u];
+    }
+    double zf[cp::KQ], xf[cp::KQ];
+#pragma unroll
+    for (int u = 0; u < cp::KQ; ++u) {
+        zf[u] = zfq[4 * u];
+        xf[u] = xfq[4 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < cp::NVQ; ++u) {
+        const double xn = fma(t, zv[u], xv[u]);
+        if ((u & 3) == 0) a0 = fma(a.am[u], xn, a0);
+        else if ((u & 3) == 1) a1 = fma(a.am[u], xn, a1);
+        else if ((u & 3) == 2) a2 = fma(a.am[u], xn, a2);
+        else a3 = fma(a.am[u], xn, a3);
+    }
+#pragma unroll
+    for (int u = 0; u < cp::KQ; ++u) {
+        const double xn = fma(t, zf[u], xf[u]);
+        if ((u & 3) == 0) a0 = fma(-a.aj[u], xn, a0);
+        else if ((u & 3) == 1) a1 = fma(-a.aj[u], xn, a1);
+        else if ((u & 3) == 2) a2 = fma(-a.aj[u], xn, a2);
+        else a3 = fma(-a.aj[u], xn, a3);
+    }
+    double acc = (a0 + a1) + (a2 + a3);
+    acc += dpp_get<0xB1>(acc);
+    acc += dpp_get<0x4E>(acc);
+    if (q4 == 0 && rr < na) out[rr] = acc;
+}
+
+// what a thread keeps about the one row of s it owns (nin2 <= 256: row tid)
+struct OwnRow {
+    int meta;        // -1: none
+    double ci0;
+    double coef[12]; // friction rows only, sign folded in
+};
+
+template <typename TI>
+__device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const DevStruct& S, const int b, double* lds, const int tid)
+{
+    Ctx c;
+    c.S = &S;
+    c.tid = tid;
+    c.lane = tid & (kWave - 1);
+    c.wave = uni(tid >> 6);
+    c.rslot = 0;
+    c.nv = S.nv; c.na = S.na; c.nc = S.nc; c.k = S.k; c.n = S.n; c.nu = S.nu;
+    c.neq = S.neq; c.nin2 = S.nin2; c.ldj = S.ldj; c.ldm = 0; c.ldc = 0; c.ldb = S.ldb;
+    c.J = lds + S.o_J; c.R = lds + S.o_R;
+    c.M = nullptr; c.Jc = nullptr; c.Ac = nullptr; c.h = nullptr; c.q = nullptr; c.wrow = nullptr; c.stash = nullptr;
+    c.eqw = nullptr; c.eqt = nullptr; c.bc = nullptr; c.iai = nullptr; c.iaexcl = nullptr;
+    {
+        double* vec = lds + S.o_vec;
+        c.x = vec + cp::X; c.np = vec + cp::NP; c.d = vec + cp::D; c.z = vec + cp::Z; c.xold = vec + cp::XOLD;
+        c.r = vec + cp::R; c.u = vec + cp::U; c.uold = vec + cp::UOLD; c.rdinv = vec + cp::RDINV; c.part = vec + cp::PART;
+        c.s = vec + cp::S; c.blb = vec + cp::BLB; c.bub = vec + cp::BUB; c.tl = vec + cp::TL; c.tu = vec + cp::TU;
+        c.red = vec + cp::RED; c.g = vec + cp::G; c.dinv = vec + cp::DINV; c.w = vec + cp::W; c.b1 = vec + cp::B1;
+        c.prm = vec + cp::PRM;
+    }
+    double* const tact = lds + S.o_vec + cp::TACT;
+    double* const ce0v = lds + S.o_vec + cp::CE0; // ce0 of the equalities, then rhs, then y
+    int* ia = reinterpret_cast<int*>(lds + S.o_int);
+    c.A = ia + cp::IA; c.Aold = ia + cp::IAOLD; c.gskip = ia + cp::IGSKIP; c.meta = ia + cp::IMETA;
+    signed char* const act = reinterpret_cast<signed char*>(ia + cp::IACT);   // 1: row is in the active set (iai == -1)
+    signed char* const excl = reinterpret_cast<signed char*>(ia + cp::IEXCL); // 1: row may be picked (iaexcl)
+    const int n = c.n, nv = c.nv, na = c.na, nc = c.nc, k = c.k, nu = c.nu, neq = c.neq, nin2 = c.nin2;
+    const int ldj = c.ldj, ldb = c.ldb;
+    c.iq = 0;
+    c.R_norm = 1.0;
+
+    const int n_dense = S.n_dense, n_sel = S.n_sel, n_bound = S.n_bound, r1 = S.r1, n_tasks = S.n_tasks;
+    const size_t qp = (size_t)b;
+    double* const As = c.J;                  // dense task rows are staged in the J region (J appears after the elimination)
+    double* const RB = c.J + S.o_pan;        // the elimination's panels, behind the staged rows
+    double* const YB = RB + 512;
+    double* const Nm = c.R + 256;            // N = CE' (n x ldb), then B = J0'N: tail of the R region
+    const int lenM = nv * (nv + 1) / 2, lenA = n_dense * nv, lenAc = nc * 6 * nv;
+    const TI* const pM = ga.M + qp * lenM;
+    const TI* const pAc = ga.Ac + qp * (size_t)lenAc;
+
+    STAMP_DECL
+    // ---------------- phase 0: the record's loads all in flight, then land where they are used ----------------
+    {
+        constexpr int RA = 9, RC = 3; // rounds of 256 covered by registers; longer arrays finish in tail loops
+        const TI* pA = ga.A + qp * (size_t)lenA;
+        TI vA[RA], vC[RC];
+        unsigned vQ[RA], vCq[RC];
+        if (lenA > 0) {
+            ld_regs<TI, RA>(pA, lenA, tid, vA);
+            ld_regs<unsigned, RA>(S.apack, lenA, tid, vQ);
+        }
+        if (nc > 0) {
+            ld_regs<TI, RC>(pAc, lenAc, tid, vC);
+            ld_regs<unsigned, RC>(S.acpack, lenAc, tid, vCq);
+        }
+        // base dynamics rows of N: N(kk, e) = M(kk, e), e < nu -- eight lanes per row, two rounds (nv <= 52)
+        TI vMu[2] = {TI(0), TI(0)};
+        if (nu > 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = tid + u * kThreads, kk = t >> 3, e = t & 7;
+                const int hi = max(kk, e), lo = min(kk, e);
+                vMu[u] = pM[min(hi * (hi + 1) / 2 + lo, lenM - 1)];
+            }
+        }
+        // N(nv + m, e) = -Jc(m, e) = -sum_r T(r, m) A_c(r, e): eight lanes per force column
+        TI acv[6];
+        double tcv[6];
+        if (nc > 0 && nu > 0) {
+            const int m = min(tid >> 3, k - 1), e = min(tid & 7, nu - 1);
+            const int ct = (m >= 12) ? 1 : 0, mm = m - 12 * ct;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                acv[r] = pAc[(ct * 6 + r) * nv + e];
+                tcv[r] = S.force_gen[ct * 72 + r * 12 + mm];
+            }
+        }
+        // the short vectors: one (clamped) element per thread each
+        const TI vb1 = ga.b1[qp * r1 + min(tid, r1 - 1)];
+        const TI vw = ga.w[qp * n_tasks + min(tid, n_tasks - 1)];
+        TI vce = TI(0), vbl = TI(0), vbu = TI(0), vtl = TI(0), vtu = TI(0), vha = TI(0);
+        if (neq > 0) {
+            if (tid < nu) vce = ga.h[qp * nv + tid];
+            else if (nc > 0) vce = ga.bc[qp * (nc * 6) + min(tid - nu, nc * 6 - 1)];
+        }
+        if (n_bound > 0) {
+            vbl = ga.blb[qp * n_bound + min(tid, n_bound - 1)];
+            vbu = ga.bub[qp * n_bound + min(tid, n_bound - 1)];
+        }
+        if (S.act_bounds) {
+            vtl = ga.tlb[qp * na + min(tid, na - 1)];
+            vtu = ga.tub[qp * na + min(tid, na - 1)];
+            vha = ga.h[qp * nv + nu + min(tid, na - 1)];
+        }
+        const int meta0 = (nin2 > 0) ? S.rowmeta[min(tid, nin2 - 1)] : 0;
+        const int drt = (n_dense > 0) ? S.dense_row_task[min(tid, n_dense - 1)] : 0;
+        int selc = 0, selt = 0, frt = 0;
+        double ftc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (n_sel > 0) {
+            selc = S.sel_col[min(tid, n_sel - 1)];
+            selt = S.sel_task[min(tid, n_sel - 1)];
+        }
+        if (nc > 0) {
+            const int fm = min(tid, k - 1);
+            frt = S.forcereg_task[fm / 12];
+#pragma unroll
+            for (int qd = 0; qd < 6; ++qd) ftc[qd] = S.ft[(fm / 12) * 72 + (fm % 12) * 6 + qd];
+        }
+        // ---- land
+        if (lenA > 0) {
+#pragma unroll
+            for (int u = 0; u < RA; ++u) {
+                const int e = tid + u * kThreads;
+                if (e < lenA) As[vQ[u]] = (double)vA[u];
+            }
+        }
+        if (nc > 0) {
+#pragma unroll
+            for (int u = 0; u < RC; ++u) {
+                const int e = tid + u * kThreads;
+                if (e < lenAc) Nm[vCq[u]] = (double)vC[u];
+            }
+            // rows of the force variables: -J_u' in the base-dynamics columns, zero in the contact-motion columns
+            if (nu > 0 && tid < 8 * k && (tid & 7) < nu) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) sacc = fma(tcv[r], (double)acv[r], sacc);
+                Nm[(nv + (tid >> 3)) * ldb + (tid & 7)] = -sacc;
+            }
+            for (int t = tid; t < 16 * k; t += kThreads) {
+                const int e2 = nu + (t & 15);
+                if (e2 < neq) Nm[(nv + (t >> 4)) * ldb + e2] = 0.0;
+            }
+        }
+        if (nu > 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = tid + u * kThreads, kk = t >> 3, e = t & 7;
+                if (kk < nv && e < nu) Nm[kk * ldb + e] = (double)vMu[u];
+            }
+        }
+        if (tid < neq) ce0v[tid] = (tid < nu) ? (double)vce : -(double)vce; // ce0 = h_u | -bc
+        if (tid < r1) c.b1[tid] = (double)vb1;
+        if (tid < n_tasks) c.w[tid] = (double)vw;
+        if (tid < n_bound) {
+            c.blb[tid] = (double)vbl;
+            c.bub[tid] = (double)vbu;
+        }
+        if (S.act_bounds && tid < na) { // lb - h_a, ub - h_a (computeProblemData, actuation tasks)
+            c.tl[tid] = (double)vtl - (double)vha;
+            c.tu[tid] = (double)vtu - (double)vha;
+        }
+        if (tid < nin2) c.meta[tid] = meta0;
+        // tails of arrays longer than the register rounds (none for the reference's stacks)
+        for (int e = tid + RA * kThreads; e < lenA; e += kThreads) As[S.apack[e]] = (double)pA[e];
+        for (int e = tid + RC * kThreads; e < lenAc; e += kThreads) Nm[S.acpack[e]] = (double)pAc[e];
+        if (tid < nv) { // diagonal additions / right-hand sides of the selection rows
+            c.z[tid] = 0.0;
+            c.d[tid] = 0.0;
+        }
+        if (tid >= n && tid < 80) { // finite padding for act_rows_reg's unconditional reads; never written again
+            c.z[tid] = 0.0;
+            c.x[tid] = 0.0;
+        }
+        bsync();
+        if (tid < n_dense) { // (row weight, right-hand side) pairs behind the staged rows: one 16-byte read per row
+            As[n_dense * 64 + 2 * tid] = c.w[drt];
+            As[n_dense * 64 + 2 * tid + 1] = c.b1[tid];
+        }
+        // selection rows (posture): H(c,c) += w, g(c) -= w b  (distinct columns)
+        for (int sidx = tid; sidx < n_sel; sidx += kThreads) {
+            const int col = (sidx == tid) ? selc : S.sel_col[sidx];
+            const double wt = c.w[(sidx == tid) ? selt : S.sel_task[sidx]];
+            c.z[col] = wt;
+            c.d[col] = wt * c.b1[n_dense + sidx];
+        }
+        // force regularisation: g_f = -w F' b
+        if (tid < k) {
+            const double* bb = c.b1 + n_dense + n_sel + 6 * (tid / 12);
+            double sacc = 0.0;
+#pragma unroll
+            for (int qd = 0; qd < 6; ++qd) sacc = fma(ftc[qd], bb[qd], sacc);
+            c.g[nv + tid] = -c.w[frt] * sacc;
+        }
+    }
+    bsync();
+    STAMP(0)
+
+    // ---------------- phases 1-2b in registers: H assembly, Cholesky H = U'U, J = U^-1 (as solve_one) ----------------
+    double c1, c2;
+    {
+        const int ta = tid >> 4, te = tid & 15;
+        double h[4][4];
+        double trace = 0.0;
+        {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) h[u][w] = 0.0;
+            double gacc[4] = {0.0, 0.0, 0.0, 0.0};
+            const double* Ai = As + ta * 4;
+            const double* Aj = As + te * 4;
+            const double* WB = As + n_dense * 64;
+            auto ldrow = [&](int r, double2v (&ai)[2], double2v (&aj)[2], double2v& wb) __attribute__((always_inline)) {
+                ai[0] = ld2(Ai + r * 64);
+                ai[1] = ld2(Ai + r * 64 + 2);
+                aj[0] = ld2(Aj + r * 64);
+                aj[1] = ld2(Aj + r * 64 + 2);
+                wb = ld2(WB + 2 * r);
+            };
+            auto macrow = [&](const double2v (&ai)[2], const double2v (&aj)[2], const double2v& wb) __attribute__((always_inline)) {
+                const double a[4] = {ai[0].x, ai[0].y, ai[1].x, ai[1].y};
+                const double ajw[4] = {aj[0].x * wb.x, aj[0].y * wb.x, aj[1].x * wb.x, aj[1].y * wb.x};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int w = u; w < 4; ++w) h[u][w] = fma(a[u], ajw[w], h[u][w]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) gacc[w] = fma(ajw[w], wb.y, gacc[w]);
+            };
+            if (n_dense > 0) {
+                double2v ai0[2], aj0[2], ai1[2], aj1[2], wb0, wb1;
+                ldrow(0, ai0, aj0, wb0);
+                int r = 0;
+                for (; r + 2 <= n_dense; r += 2) {
+                    ldrow(r + 1, ai1, aj1, wb1);
+                    macrow(ai0, aj0, wb0);
+                    ldrow(min(r + 2, n_dense - 1), ai0, aj0, wb0);
+                    macrow(ai1, aj1, wb1);
+                }
+                if (r < n_dense) macrow(ai0, aj0, wb0);
+            }
+            if (ta == 0) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int col = te + 16 * w;
+                    if (col < nv) c.g[col] = -gacc[w] - c.d[col];
+                }
+            }
+            if (ta == te) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = ta + 16 * u;
+                    if (i < nv) {
+                        h[u][u] += c.z[i] + S.hessian_reg;
+                        trace += h[u][u];
+                    }
+                }
+            }
+        }
+        STAMP(1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = u; w < 4; ++w) {
+                const int r = ta + 16 * u, q = te + 16 * w;
+                if (r >= nv || q >= nv) h[u][w] = (r == q) ? 1.0 : 0.0;
+            }
+        double y[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) y[u][w] = 0.0;
+        const int la = c.lane >> 3, le = c.lane & 7;
+        double hF[2][2], yF[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        {
+            const int cs = (c.wave < nc) ? c.wave : 0;
+            const double* ftf = S.ftf + cs * 144;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) hF[u][w] = (nc > 0) ? ftf[min(la + 8 * u, 11) * 12 + min(le + 8 * w, 11)] : 0.0;
+        }
+        // the panels lie behind the staged rows: a fast thread may publish while a slow one still reads its last task row
+        publish_panel<4, 4, false, 0>(c, h, y, ta, te, 0, RB, YB);
+        eliminate_block<4, 4, false, 0>(c, h, y, ta, te, (nv + 3) & ~3, RB, YB, c.dinv, tid >= 128 && tid < 132, tid & 3);
+        STAMP(2)
+        bsync(); // staged rows and panels are dead: the region becomes J
+        for (int e = tid; e < n * ldj; e += kThreads) c.J[e] = 0.0;
+        // ---- force blocks: wave-local (8 x 8 lane grid, 2 x 2 positions per lane), one contact per wave (nc <= 2), panels
+        //      in the (idle) s slot
+        const int fb = nv + 12 * c.wave;
+        if (c.wave < nc) {
+            const double wt = c.w[S.forcereg_task[c.wave]];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int r = la + 8 * u, q = le + 8 * w;
+                    if (r < 12 && q < 12) {
+                        hF[u][w] = wt * hF[u][w] + ((r == q) ? S.hessian_reg : 0.0);
+                        if (r == q) trace += hF[u][w];
+                    }
+                    else hF[u][w] = (r == q) ? 1.0 : 0.0;
+                    yF[u][w] = 0.0;
+                }
+            double* RBf = c.s + c.wave * 128;
+            double* YBf = RBf + 64;
+            publish_panel<3, 2, true, 0>(c, hF, yF, la, le, 0, RBf, YBf);
+            eliminate_block<3, 2, true, 0>(c, hF, yF, la, le, 12, RBf, YBf, c.dinv + fb, c.lane < 4, c.lane & 3);
+        }
+        bsync(); // J is zero, every 1/sqrt(pivot) is published
+        // final: J(r,q) = Y(r,q) dinv[q], J(r,r) = dinv[r]
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = u; w < 4; ++w) {
+                const int r = ta + 16 * u, q = te + 16 * w;
+                if (q < nv && r < q) c.J[r * ldj + q] = y[u][w] * c.dinv[q];
+                else if (r == q && r < nv) c.J[r * ldj + r] = c.dinv[r];
+            }
+        if (c.wave < nc) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int w = u; w < 2; ++w) {
+                    const int r = la + 8 * u, q = le + 8 * w;
+                    if (q < 12 && r < q) c.J[(fb + r) * ldj + fb + q] = yF[u][w] * c.dinv[fb + q];
+                    else if (r == q && r < 12) c.J[(fb + r) * ldj + fb + r] = c.dinv[fb + r];
+                }
+        }
+        bsync();
+        c1 = block_sum(c, trace);
+        double tr2 = 0.0;
+        for (int i = tid; i < n; i += kThreads) tr2 += c.dinv[i];
+        c2 = block_sum(c, tr2);
+    }
+    STAMP(3)
+
+    // ---------------- x = -H^-1 g = -J (J' g); f = 0.5 g'x ----------------
+    double f_value;
+    {
+        const int idx = tid >> 1, hf = tid & 1;
+        const int ic = min(idx, n - 1);
+        {
+            const int kb0 = blk_begin(ic, nv), len = ic + 1 - kb0, hl = (len + 1) >> 1;
+            const int ka = kb0 + hf * hl, kb = hf ? ic + 1 : kb0 + hl;
+            double dv = dot8(c.J + ic, ldj, c.g, 1, ka, kb);
+            dv += dpp_get<0xB1>(dv);
+            if (hf == 0 && idx < n) c.d[idx] = dv;
+        }
+        for (int i = tid; i < n + 2; i += kThreads) {
+            c.u[i] = 0.0;
+            c.A[i] = 0;
+        }
+        c.iq = 0;
+        bsync();
+        double part = 0.0;
+        {
+            const int ce = blk_end(ic, nv), len = ce - ic, hl = (len + 1) >> 1;
+            const int ca = ic + hf * hl, cb = hf ? ce : ic + hl;
+            double zv = dot8(c.J + ic * ldj, 1, c.d, 1, ca, cb);
+            zv += dpp_get<0xB1>(zv);
+            if (hf == 0 && idx < n) {
+                c.z[idx] = zv;
+                c.x[idx] = -zv;
+                part = 0.5 * c.g[idx] * (-zv);
+            }
+        }
+        f_value = block_sum(c, part);
+    }
+    STAMP(4)
+
+    const double eps = 2.220446049250313e-16;
+    const double inf = __builtin_huge_val();
+    int status = -2; // running
+    int iter = 0;
+
+    // ---------------- phase 3: equality constraints, blocked (equality_phase_blocked with N already in place) ----------------
+    if (neq > 0) {
+        const int m = neq;
+        double* rhs = ce0v;
+        // ---- rhs_e = -(N(:,e)'x0 + ce0_e): 8 lanes per equality, ten terms each in flight
+        {
+            const int e = tid >> 3, kc = tid & 7;
+            const int es = min(e, m - 1);
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 10; i += 2) {
+                const int k0 = min(kc + 8 * i, n - 1), k1 = min(kc + 8 * i + 8, n - 1);
+                const double x0 = (kc + 8 * i < n) ? c.x[k0] : 0.0, x1 = (kc + 8 * i + 8 < n) ? c.x[k1] : 0.0;
+                a0 = fma(Nm[k0 * ldb + es], x0, a0);
+                a1 = fma(Nm[k1 * ldb + es], x1, a1);
+            }
+            const double acc = grp8_sum(a0 + a1);
+            if (e < m && kc == 0) rhs[e] = -(acc + rhs[e]);
+        }
+        STAMP(22)
+        // ---- B = J0' N over N itself: every product is in registers before the first element is replaced
+        {
+            const int ncg = (m + 3) >> 2;
+            const int cpi = tid / ncg, cg = tid - cpi * ncg;
+            const int c0 = 2 * cpi, c1i = min(c0 + 1, n - 1);
+            const bool actv = c0 < n;
+            int kmin = actv ? blk_begin(c0, nv) : n, kmax = actv ? c1i + 1 : 0;
+            kmin = wave_min_int(kmin);
+            kmax = wave_max_int(kmax);
+            double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            const int c0s = actv ? c0 : 0, c1s = actv ? c1i : 0;
+            tile2x4(c.J, c0s, c1s, ldj, Nm + 4 * cg, ldb, kmin, kmax, acc);
+            bsync();
+            if (actv) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (4 * cg + q < m) {
+                        Nm[c0 * ldb + 4 * cg + q] = acc[0][q];
+                        if (c0 + 1 < n) Nm[(c0 + 1) * ldb + 4 * cg + q] = acc[1][q];
+                    }
+            }
+        }
+        bsync();
+        STAMP(5)
+        bool ok = qr_resident(c, Nm, c.s, c.s + 160);
+        if (!ok) status = HQP_ERROR; // redundant equalities
+        else {
+            bsync();
+            STAMP(6)
+            if (c.wave == 0) {
+                if (m <= 12) solve_y<12>(c, rhs);
+                else if (m <= 20) solve_y<20>(c, rhs);
+                else solve_y<24>(c, rhs);
+            }
+            bsync();
+            STAMP(19)
+            double yy = 0.0;
+            if (tid < m) yy = rhs[tid] * rhs[tid];
+            if (tid >= 128 && tid - 128 < n) {
+                const int kk = tid - 128;
+                const double* Jr = c.J + kk * ldj;
+                double acc = 0.0;
+                for (int e = 0; e < m; ++e) acc = fma(Jr[e], rhs[e], acc);
+                c.x[kk] += acc;
+            }
+            yy = block_sum(c, yy);
+            f_value += 0.5 * yy;
+            c.iq = m;
+            bsync();
+        }
+        STAMP(8)
+    }
+
+    // ---------------- the actuation rows into registers (from the record: L2) ----------------
+    ActRegs ar;
+    if (na > 0) {
+        const int rr = min(tid >> 2, na - 1), q4 = tid & 3;
+        const int row = nu + rr;
+        TI mv[cp::NVQ];
+#pragma unroll
+        for (int u = 0; u < cp::NVQ; ++u) {
+            const int j = min(q4 + 4 * u, nv - 1);
+            const int hi = max(row, j), lo = min(row, j);
+            mv[u] = pM[hi * (hi + 1) / 2 + lo];
+        }
+        TI av[2][6];
+        double tv[cp::KQ][6];
+        if (nc > 0) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) av[ct][r] = pAc[(min(ct, nc - 1) * 6 + r) * nv + row];
+#pragma unroll
+            for (int u = 0; u < cp::KQ; ++u) {
+                const int mcol = min(q4 + 4 * u, k - 1);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) tv[u][r] = S.force_gen[(u / 3) * 72 * ((nc > 1) ? 1 : 0) + r * 12 + (mcol - 12 * (u / 3) * ((nc > 1) ? 1 : 0))];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < cp::NVQ; ++u) ar.am[u] = (q4 + 4 * u < nv) ? (double)mv[u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < cp::KQ; ++u) {
+            double sacc = 0.0;
+            if (nc > 0) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) sacc = fma(tv[u][r], (double)av[u / 3][r], sacc);
+            }
+            ar.aj[u] = (q4 + 4 * u < k) ? sacc : 0.0;
+        }
+    }
+    else {
+#pragma unroll
+        for (int u = 0; u < cp::NVQ; ++u) ar.am[u] = 0.0;
+#pragma unroll
+        for (int u = 0; u < cp::KQ; ++u) ar.aj[u] = 0.0;
+    }
+
+    // ---------------- phase 4: inequality loop (GI steps 1, 2, 2a-2c; the five-barrier iteration of solve_one) ----------------
+    bool tau_stale = true; // tau' = A_act x not current
+    const bool act_ineq = S.act_bounds && na > 0; // actuation rows are inequality rows (otherwise tau' is only decoded)
+    if (status == -2 && nin2 > 0) {
+        if (tid < nin2) act[tid] = 0;
+        OwnRow own;
+        {
+            own.meta = -1;
+            own.ci0 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 12; ++m) own.coef[m] = 0.0;
+            if (tid < nin2) {
+                const int mt = c.meta[tid];
+                const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15;
+                const bool neg = (mt >> 2) & 1;
+                own.meta = mt;
+                if (kind == INEQ_BOUNDS) own.ci0 = neg ? c.bub[rr] : -c.blb[rr];
+                else if (kind == INEQ_ACTUATION) own.ci0 = neg ? c.tu[rr] : -c.tl[rr];
+                else {
+                    own.ci0 = neg ? S.fric_ub[ct * 17 + rr] : -S.fric_lb[ct * 17 + rr];
+                    const double* B = S.fric_mat + (ct * 17 + rr) * 12;
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) own.coef[m] = neg ? -B[m] : B[m];
+                }
+            }
+        }
+        if (act_ineq) act_rows_reg(c, ar, tact, 0.0);
+        bsync();
+        const double psi_tol = (double)nin2 * eps * c1 * c2 * 100.0;
+        bool redo_l2 = false;
+        tau_stale = !act_ineq;
+        double sip = 0.0; // s(ip) of the constraint being added
+        while (status == -2) {
+            ValIdx best;
+            if (!redo_l2) {
+                // l1
+                ++iter;
+                if (iter >= S.max_iter) {
+                    status = HQP_MAX_ITER;
+                    break;
+                }
+                if (act_ineq && tau_stale) {
+                    act_rows_reg(c, ar, tact, 0.0);
+                    bsync();
+                    tau_stale = false;
+                }
+                for (int i = tid; i < c.iq; i += kThreads) {
+                    c.uold[i] = c.u[i];
+                    c.Aold[i] = c.A[i];
+                }
+                for (int i = tid; i < n; i += kThreads) c.xold[i] = c.x[i];
+                double psi = 0.0;
+                best = ValIdx{0.0, 0x7fffffff};
+                {
+                    const int mt = own.meta;
+                    if (mt >= 0) {
+                        const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
+                        const bool neg = (mt >> 2) & 1;
+                        double v;
+                        if (kind == INEQ_BOUNDS) v = neg ? -c.x[col] : c.x[col];
+                        else if (kind == INEQ_ACTUATION) v = neg ? -tact[rr] : tact[rr];
+                        else {
+                            const double* f = c.x + nv + 12 * ct;
+                            double a = 0.0;
+#pragma unroll
+                            for (int m = 0; m < 12; ++m) a = fma(own.coef[m], f[m], a);
+                            v = a;
+                        }
+                        v += own.ci0;
+                        c.s[tid] = v;
+                        excl[tid] = 1;
+                        psi = fmin(0.0, v);
+                        if (v < 0.0 && !act[tid]) best = ValIdx{v, tid};
+                    }
+                }
+                psi = wave_sum(psi);
+                best = wave_argmin(best);
+                double* slot = c.red + c.rslot * 16;
+                if (c.lane == 0) {
+                    slot[c.wave] = psi;
+                    slot[4 + c.wave] = best.v;
+                    slot[8 + c.wave] = __hiloint2double(0, best.i);
+                }
+                bsync(); // B1
+                psi = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+                best = ValIdx{slot[4], __double2loint(slot[8])};
+#pragma unroll
+                for (int w = 1; w < kWaves; ++w) best = vi_min(best, ValIdx{slot[4 + w], __double2loint(slot[8 + w])});
+                c.rslot ^= 1;
+                if (fabs(psi) <= psi_tol) {
+                    status = HQP_OPTIMAL;
+                    break;
+                }
+                STAMP(9)
+            }
+            else {
+                // l2 again after a rejected constraint: s is still valid, the rejected row is excluded
+                best = ValIdx{0.0, 0x7fffffff};
+                if (tid < nin2) {
+                    const double sv = c.s[tid];
+                    if (sv < 0.0 && !act[tid] && excl[tid]) best = ValIdx{sv, tid};
+                }
+                best = block_argmin(c, best);
+                redo_l2 = false;
+            }
+            if (best.v >= 0.0) {
+                status = HQP_OPTIMAL;
+                break;
+            }
+            const int ip = best.i;
+            sip = best.v;
+            // the row n of constraint ip: kind, support [k0, k1), sign; n itself is published by the lanes that own it
+            const int mt = c.meta[ip];
+            const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
+            const double sg = ((mt >> 2) & 1) ? -1.0 : 1.0;
+            int k0, k1;
+            if (kind == INEQ_BOUNDS) {
+                k0 = col;
+                k1 = col + 1;
+                if (tid == 0) c.np[col] = sg;
+            }
+            else if (kind == INEQ_ACTUATION) {
+                k0 = 0;
+                k1 = n;
+                if ((tid >> 2) == rr) {
+                    // unconditional stores from one address: the M part first (zeros past nv), then the force part on top of
+                    // it -- the four lanes are one wave, whose LDS operations execute in program order
+                    double* npq = c.np + (tid & 3);
+#pragma unroll
+                    for (int u = 0; u < cp::NVQ; ++u) npq[4 * u] = sg * ar.am[u];
+                    double* npf = npq + nv;
+#pragma unroll
+                    for (int u = 0; u < cp::KQ; ++u) npf[4 * u] = -sg * ar.aj[u];
+                }
+            }
+            else {
+                k0 = nv + 12 * ct;
+                k1 = k0 + 12;
+                if (tid == ip) {
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) c.np[k0 + m] = own.coef[m];
+                }
+            }
+            if (tid == kThreads - 1) {
+                c.u[c.iq] = 0.0;
+                c.A[c.iq] = ip;
+            }
+            if (kind != INEQ_BOUNDS) bsync(); // the published row
+            STAMP(10)
+
+            // l2a
+            while (true) {
+                const int iq = c.iq;
+                // ---- P2: d = J' n
+                if (kind == INEQ_BOUNDS) {
+                    if (tid < n) c.d[tid] = sg * c.J[col * ldj + tid];
+                }
+                else if (kind == INEQ_FORCE) {
+                    if (tid < n) {
+                        const double* F = c.np + k0;
+                        const double* Jb = c.J + k0 * ldj + tid;
+                        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 12; m += 2) {
+                            a0 = fma(F[m], Jb[m * ldj], a0);
+                            a1 = fma(F[m + 1], Jb[(m + 1) * ldj], a1);
+                        }
+                        c.d[tid] = a0 + a1;
+                    }
+                }
+                else { // actuation row: two lanes per column, halves of the support
+                    const int idx = tid >> 1, hf = tid & 1;
+                    const int ic = min(idx, n - 1);
+                    const int mid = (n + 1) >> 1;
+                    const int ka = hf ? mid : 0, kb = hf ? n : mid;
+                    double acc = dot8(c.np, 1, c.J + ic, ldj, ka, kb);
+                    acc += dpp_get<0xB1>(acc);
+                    if (hf == 0 && idx < n) c.d[idx] = acc;
+                }
+                bsync(); // B2
+                STAMP(11)
+                // ---- P3: z, r and the reductions of step 2b
+                double* slot = c.red + c.rslot * 16;
+                if (c.wave < 3) {
+                    const int lpr = (2 * n <= 3 * kWave) ? 2 : 1; // lanes per row
+                    const int idx = (lpr == 2) ? (tid >> 1) : tid, hf = (lpr == 2) ? (tid & 1) : 0;
+                    const int ir = min(idx, n - 1);
+                    const int span = n - iq, hlen = (lpr == 2) ? ((span + 1) >> 1) : span;
+                    const int ca = iq + hf * hlen, cb = min(n, ca + hlen);
+                    const double* Jr = c.J + ir * ldj;
+                    double zv = dot8(Jr, 1, c.d, 1, ca, cb);
+                    if (lpr == 2) zv += dpp_get<0xB1>(zv);
+                    double zz = 0.0, znp = 0.0, dn2 = 0.0;
+                    if (hf == 0 && idx < n) {
+                        c.z[idx] = zv;
+                        zz = zv * zv;
+                        if (idx >= iq) {
+                            const double dv = c.d[idx];
+                            dn2 = dv * dv;
+                        }
+                        if (idx >= k0 && idx < k1) znp = zv * c.np[idx];
+                    }
+                    zz = wave_sum(zz);
+                    znp = wave_sum(znp);
+                    dn2 = wave_sum(dn2);
+                    if (c.lane == 0) {
+                        slot[c.wave] = zz;
+                        slot[4 + c.wave] = znp;
+                        slot[8 + c.wave] = dn2;
+                    }
+                }
+                else {
+                    update_r_wave(c, neq);
+                    ValIdx bt{inf, 0x7fffffff};
+                    for (int kk = neq + c.lane; kk < iq; kk += kWave) {
+                        const double rk = c.r[kk];
+                        if (rk > 0.0) bt = vi_min(bt, ValIdx{c.u[kk] / rk, kk});
+                    }
+                    bt = wave_argmin(bt);
+                    if (c.lane == 0) {
+                        slot[12] = bt.v;
+                        slot[13] = __hiloint2double(0, bt.i);
+                    }
+                }
+                bsync(); // B3
+                STAMP(12)
+                // ---- P4: step lengths
+                const double zz = (slot[0] + slot[1]) + slot[2], znp = (slot[4] + slot[5]) + slot[6];
+                const double dn2 = (slot[8] + slot[9]) + slot[10];
+                const double t1 = slot[12];
+                const int lpos = __double2loint(slot[13]);
+                c.rslot ^= 1;
+                const int l = (t1 < inf) ? c.A[lpos] : 0;
+                const double uiq = c.u[iq];
+                const double t2 = (fabs(zz) > eps) ? (-sip / znp) : inf;
+                const double t = fmin(t1, t2);
+                if (t >= inf) {
+                    status = HQP_INFEASIBLE; // eiquadprog UNBOUNDED (dual) -> tsid INFEASIBLE
+                    break;
+                }
+                if (t2 >= inf) {
+                    // (ii) dual step only, drop l
+                    bsync(); // everyone has read u[iq], A[lpos] before they change
+                    for (int j = neq + tid; j < iq; j += kThreads) c.u[j] = fma(-t, c.r[j], c.u[j]);
+                    if (tid == kThreads - 1) {
+                        c.u[iq] = uiq + t;
+                        act[l] = 0;
+                    }
+                    bsync();
+                    STAMP(13)
+                    delete_constraint(c, l);
+                    STAMP(15)
+                    continue;
+                }
+                f_value += t * znp * (0.5 * t + uiq);
+                if (t == t2) {
+                    // (iii) full step: add ip to the active set with one reflector (see solve_one)
+                    const double diq = c.d[iq];
+                    double alpha = diq, v0 = 0.0, tau = 0.0;
+                    const bool reflect = (iq + 1 < n && dn2 > 0.0);
+                    if (reflect) {
+                        const double inx = rsqrt(dn2);
+                        const double nx = dn2 * inx;
+                        alpha = (diq >= 0.0) ? -nx : nx;
+                        v0 = diq - alpha;
+                        tau = fast_rcp(fma(nx, fabs(diq), dn2));
+                    }
+                    const bool accepted = fabs(alpha) > eps * c.R_norm;
+                    if (reflect && tid < n) c.part[tid] = tau * (c.z[tid] - alpha * c.J[tid * ldj + iq]);
+                    if (act_ineq) act_rows_reg(c, ar, tact, t); // tau' of the next iterate, x + t z formed on the fly
+                    bsync(); // B4
+                    STAMP(13)
+                    // ---- P5
+                    if (reflect) {
+                        const int kr = tid & 127, half = tid >> 7;
+                        if (kr < n) {
+                            const int span = n - iq;
+                            const int ca = iq + half * ((span + 1) >> 1), cb = half ? n : iq + ((span + 1) >> 1);
+                            double* Jk = c.J + kr * ldj;
+                            const double wk = c.part[kr];
+                            int cc = ca;
+                            if (cc == iq && cc < cb) {
+                                Jk[cc] = fma(-wk, v0, Jk[cc]);
+                                ++cc;
+                            }
+                            for (; cc + 8 <= cb; cc += 8) {
+                                double dd[8], jj[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    dd[u] = c.d[cc + u];
+                                    jj[u] = Jk[cc + u];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) Jk[cc + u] = fma(-wk, dd[u], jj[u]);
+                            }
+                            for (; cc < cb; ++cc) Jk[cc] = fma(-wk, c.d[cc], Jk[cc]);
+                        }
+                    }
+                    {
+                        double* Rc = c.R + roff(iq);
+                        for (int i = tid; i < iq; i += kThreads) Rc[i] = c.d[i];
+                        if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
+                        if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                        if (tid == kThreads - 1) {
+                            Rc[iq] = alpha;
+                            c.rdinv[iq] = 1.0 / alpha;
+                            c.u[iq] = uiq + t;
+                            if (accepted) act[ip] = 1;
+                        }
+                    }
+                    c.iq = iq + 1;
+                    bsync(); // B5
+                    STAMP(14)
+                    if (accepted) c.R_norm = fmax(c.R_norm, fabs(alpha));
+                    else {
+                        // numerically dependent: take the constraint out again, back to the saved iterate, pick another
+                        if (tid == 0) excl[ip] = 0;
+                        bsync();
+                        delete_constraint(c, ip);
+                        if (tid < nin2) act[tid] = 0;
+                        bsync();
+                        for (int i = tid; i < c.iq; i += kThreads) {
+                            const int av = c.Aold[i];
+                            c.A[i] = av;
+                            if (av >= 0) act[av] = 1;
+                            c.u[i] = c.uold[i];
+                        }
+                        for (int i = tid; i < n; i += kThreads) c.x[i] = c.xold[i];
+                        bsync();
+                        redo_l2 = true;
+                        tau_stale = true;
+                    }
+                    break; // -> l1 (or l2 again)
+                }
+                // (iii) partial step: primal + dual step, drop l, refresh s(ip)
+                bsync(); // everyone has read u[iq], A[lpos] before they change
+                if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
+                if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                if (tid == kThreads - 1) c.u[iq] = uiq + t;
+                if (tid == 0) act[l] = 0;
+                bsync();
+                STAMP(13)
+                tau_stale = true;
+                delete_constraint(c, l);
+                STAMP(15)
+                {
+                    double part = 0.0;
+                    for (int j = k0 + tid; j < k1; j += kThreads) part = fma(c.np[j], c.x[j], part);
+                    part = block_sum(c, part);
+                    if (tid == ip) c.s[ip] = part + own.ci0;
+                    bsync();
+                    sip = c.s[ip];
+                }
+            }
+        }
+    }
+    else if (status == -2) {
+        // no inequality rows at all: the equality-constrained minimiser is the solution (eiquadprog: one pass of l1)
+        iter = 1;
+        status = HQP_OPTIMAL;
+    }
+
+    STAMP(16)
+    // ---------------- phase 5: decode + write-out ----------------
+    // tau = h_a + M_a dv - J_a' f   (getActuatorForces)
+    bsync();
+    TI* xo = ga.x + qp * n;
+    for (int i = tid; i < n; i += kThreads) xo[i] = (TI)c.x[i];
+    if (na > 0) {
+        TI* to = ga.tau + qp * na;
+        const TI hav = ga.h[qp * nv + nu + min(tid, na - 1)];
+        // tau' of the final iterate: the optimality test of the last l1 ran on exactly this vector
+        if (status != HQP_OPTIMAL || tau_stale) {
+            act_rows_reg(c, ar, tact, 0.0);
+            bsync();
+        }
+        if (tid < na) to[tid] = (TI)((double)hav + tact[tid]);
+    }
+    if (tid == 0) {
+        ga.status[qp] = status;
+        ga.iters[qp] = iter;
+        if (ga.objective) ga.objective[qp] = (TI)f_value;
+        if (ga.n_active) ga.n_active[qp] = c.iq;
+    }
+#ifdef WBCQP_STAMPS
+    STAMP(17)
+    if (tid == 0 && ga.dbg)
+        for (int i = 0; i < kStamps; ++i) ga.dbg[qp * kStamps + i] = c.st_acc_[i];
+#endif
+}
+
+#endif // __HIPCC__
+} // namespace wbcqp

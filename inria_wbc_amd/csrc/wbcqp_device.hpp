@@ -25,6 +25,7 @@
 #include "wbcqp_equality.hpp"
 #include "wbcqp_activeset.hpp"
 #include "wbcqp_integrate.hpp"
+#include "wbcqp_compact.hpp"
 
 namespace wbcqp {
 #ifdef __HIPCC__
@@ -824,7 +825,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
 // ------------------------------------------------------------------------------------------------
 // the kernel: grid = total QPs, block = 256 threads = four wavefronts = one QP
 // ------------------------------------------------------------------------------------------------
-template <typename TI>
+template <typename TI, bool CP>
 __global__ __launch_bounds__(kThreads) void solve_kernel(const GroupTable<TI> tab)
 {
     extern __shared__ __align__(16) double lds[];
@@ -835,7 +836,8 @@ __global__ __launch_bounds__(kThreads) void solve_kernel(const GroupTable<TI> ta
     }
     const GroupArgs<TI>& ga = tab.g[gi];
     const DevStruct& S = ga.st;
-    solve_one<TI>(ga, S, b, lds, threadIdx.x);
+    if constexpr (CP) solve_one_compact<TI>(ga, S, b, lds, threadIdx.x);
+    else solve_one<TI>(ga, S, b, lds, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(kThreads) void solve_kernel(const GroupTable<TI> ta
 // all 256 CUs.  *queue: positions handed out beyond the first one of each workgroup; the last fetch of a launch zeroes it
 // for the next launch (stream order makes that visible; no memset on the path, and a captured launch replays as it is).
 // ------------------------------------------------------------------------------------------------
-template <typename TI>
+template <typename TI, bool CP>
 __global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<TI> tab, int* queue, const int total)
 {
     extern __shared__ __align__(16) double lds[];
@@ -877,7 +879,8 @@ __global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<
         // this loop and stays live across it (measured: 256 VGPRs + 146 AGPRs instead of 240 + 0; build.py refuses that)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        solve_one<TI>(ga, ga.st, b, lds, tid);
+        if constexpr (CP) solve_one_compact<TI>(ga, ga.st, b, lds, tid);
+        else solve_one<TI>(ga, ga.st, b, lds, tid);
         __syncthreads(); // the next QP reuses every byte of LDS, next_qp included
     }
 }

@@ -60,6 +60,10 @@ struct DevStruct {
     int o_int; // int area (fixed slots, see kInt*)
     int fric_lds; // 1: the friction tables (238 doubles per contact) fit the equality-phase scratch, which is free in the inequality loop
     int lds_doubles;
+    // compact layout (wbcqp_compact.hpp: half the LDS, two QPs per CU): 1 when the structure is eligible and not vetoed
+    int compact;
+    int o_pan;               // elimination panels, offset inside the J region (behind the staged task rows)
+    const unsigned* acpack;  // [nc 6 nv] contact-Jacobian element (rr, kk) -> offset kk ldb + nu + rr in N = CE'
 };
 
 template <typename TI>

@@ -180,6 +180,24 @@ def tick_batch(st, inputs: Dict[str, np.ndarray], nthreads: int = 1):
     return dict(x=x, tau=tau[:, :st.na], status=status, iters=iters)
 
 
+def tick_batch_timed(st, inputs: Dict[str, np.ndarray], nthreads: int = 1, reps: int = 1):
+    """`reps` passes over the batch on `nthreads` threads; returns (seconds inside the C driver, dict of pass 0's outputs).
+    The clock runs from the threads' common start line to the last thread's end (wbco_tick_batch_timed)."""
+    ost = OracleStructure(st)
+    batch = np.asarray(inputs["h"]).reshape(-1, st.nv).shape[0]
+    arrs = _prep_inputs(st, inputs, batch)
+    x = np.zeros((batch, st.n)); tau = np.zeros((batch, max(st.na, 1)))
+    status = np.zeros(batch, np.int32); iters = np.zeros(batch, np.int32)
+    bin_ = _BatchInputs(*[_dp(arrs[k]) for k in _FIELDS])
+    bout = _BatchOutputs(_dp(x), _dp(tau), _ip(status), _ip(iters))
+    f = lib().wbco_tick_batch_timed
+    f.restype = C.c_double
+    secs = f(C.byref(ost.c), int(batch), C.byref(bin_), C.byref(bout), int(nthreads), int(reps))
+    if secs < 0.0:
+        raise RuntimeError("wbco_tick_batch_timed failed (threads)")
+    return float(secs), dict(x=x, tau=tau[:, :st.na], status=status, iters=iters)
+
+
 def tick_single(st, inputs: Dict[str, np.ndarray], index: int = 0):
     """One QP with multipliers and active set."""
     ost = OracleStructure(st)

@@ -51,15 +51,25 @@ static inline double Msym(const double* Mp, int i, int j)
  * Level-0 order: base dynamics (formulation ctor), then constraints in task-stack order;
  * addRigidContact pushes the force inequality, then the motion equality (tasks.cpp:365).
  */
-void wbco_assemble(const wbco_structure* st, const wbco_inputs* in,
-                   double* H, double* g, double* CE, double* ce0, double* CI, double* ci0)
+/* doubles of scratch wbco_assemble_ws needs: Jc (k x nv), Arow (n), Ht (n x n), gt (n) */
+long wbco_assemble_ws_size(const wbco_structure* st)
+{
+    int n, neq, nin2, r1;
+    wbco_sizes(st, &n, &neq, &nin2, &r1);
+    const int k = 12 * st->nc;
+    return (long)(k > 0 ? k : 1) * st->nv + n + (long)n * n + n;
+}
+
+static void wbco_assemble_ws(const wbco_structure* st, const wbco_inputs* in,
+                             double* H, double* g, double* CE, double* ce0, double* CI, double* ci0, double* scratch)
 {
     const int nv = st->nv, na = st->na, nc = st->nc, k = 12 * nc, nu = nv - na;
     int n, neq, nin2, r1;
     wbco_sizes(st, &n, &neq, &nin2, &r1);
 
     /* Jc = T' * A_c  (12 x nv per contact): m_Jc.middleRows(idx,12) = T.transpose()*mc.matrix() */
-    double* Jc = (double*)calloc((size_t)(k > 0 ? k : 1) * nv, sizeof(double));
+    double* Jc = scratch;
+    memset(Jc, 0, sizeof(double) * (size_t)(k > 0 ? k : 1) * nv);
     for (int c = 0; c < nc; ++c) {
         const double* T = st->force_gen + (size_t)c * 72;
         const double* Ac = in->Ac + (size_t)c * 6 * nv;
@@ -140,9 +150,9 @@ void wbco_assemble(const wbco_structure* st, const wbco_inputs* in,
     /* ---- level 1 -> H, g (dense, the way Eigen does: H += w * A' * A per task) ---- */
     memset(H, 0, sizeof(double) * (size_t)n * n);
     memset(g, 0, sizeof(double) * (size_t)n);
-    double* Arow = (double*)calloc((size_t)n, sizeof(double));
-    double* Ht = (double*)calloc((size_t)n * n, sizeof(double)); /* per-task A'A */
-    double* gt = (double*)calloc((size_t)n, sizeof(double));
+    double* Arow = Jc + (size_t)(k > 0 ? k : 1) * nv;
+    double* Ht = Arow + n; /* per-task A'A */
+    double* gt = Ht + (size_t)n * n;
     /* dense motion rows, grouped by task (consecutive rows of one task share dense_row_task) */
     int r = 0;
     while (r < st->n_dense) {
@@ -186,11 +196,14 @@ void wbco_assemble(const wbco_structure* st, const wbco_inputs* in,
         }
     }
     for (int i = 0; i < n; ++i) H[IDX(i, i, n)] += st->hessian_reg;
+}
 
-    free(Arow);
-    free(Ht);
-    free(gt);
-    free(Jc);
+void wbco_assemble(const wbco_structure* st, const wbco_inputs* in,
+                   double* H, double* g, double* CE, double* ce0, double* CI, double* ci0)
+{
+    double* scratch = (double*)malloc(sizeof(double) * (size_t)wbco_assemble_ws_size(st));
+    wbco_assemble_ws(st, in, H, g, CE, ce0, CI, ci0, scratch);
+    free(scratch);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -593,7 +606,7 @@ long wbco_tick_ws_size(const wbco_structure* st)
 {
     int n, neq, nin2, r1;
     wbco_sizes(st, &n, &neq, &nin2, &r1);
-    return (long)n * n + n + (long)neq * n + neq + (long)nin2 * n + nin2 + wbco_ws_size(n, neq, nin2) + 16;
+    return (long)n * n + n + (long)neq * n + neq + (long)nin2 * n + nin2 + wbco_ws_size(n, neq, nin2) + wbco_assemble_ws_size(st) + 16;
 }
 
 /* One control tick of the path: Controller::_solve lines 244-251 (controller.cpp). */
@@ -609,8 +622,9 @@ int wbco_tick(const wbco_structure* st, const wbco_inputs* in, wbco_outputs* out
     double* CI = ce0 + neq;
     double* ci0 = CI + (size_t)nin2 * n;
     double* qws = ci0 + nin2;
+    double* aws = qws + wbco_ws_size(n, neq, nin2);
 
-    wbco_assemble(st, in, H, g, CE, ce0, CI, ci0);
+    wbco_assemble_ws(st, in, H, g, CE, ce0, CI, ci0, aws);
     int iq = 0, iter = 0;
     double fval = 0.0;
     int est = wbco_eiquadprog_fast(n, neq, nin2, H, g, CE, ce0, CI, ci0, out->x, out->lambda, out->active,
@@ -649,13 +663,31 @@ int wbco_tick(const wbco_structure* st, const wbco_inputs* in, wbco_outputs* out
     return status;
 }
 
-/* ---- batched driver (pthreads; one QP per work item) ---- */
+/* ---- batched driver (pthreads): work items = reps x batch QPs handed out from one atomic counter in chunks, so that the
+ * threads finish together whatever the iteration counts; per-thread workspace allocated once; nothing is allocated per QP.
+ * Pass 0 writes the caller's outputs; later passes (reps > 1: the CPU baseline's timed sample) solve the same QPs again into
+ * per-thread scratch.  The clock starts when every thread stands at the start line and stops when the last one is done:
+ * thread creation is not part of what is timed. ---- */
+#include <stdatomic.h>
+#include <time.h>
 typedef struct {
     const wbco_structure* st;
     const wbco_batch_inputs* in;
     const wbco_batch_outputs* out;
-    int begin, end;
+    int batch;
+    long total;
+    atomic_long* next;
+    pthread_barrier_t* start;
 } batch_job;
+
+enum { WBCO_CHUNK = 4 };
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static void* batch_worker(void* arg)
 {
@@ -665,56 +697,87 @@ static void* batch_worker(void* arg)
     wbco_sizes(st, &n, &neq, &nin2, &r1);
     const int nv = st->nv, na = st->na, nc = st->nc;
     const size_t mlen = (size_t)nv * (nv + 1) / 2;
-    double* ws = (double*)malloc(sizeof(double) * (size_t)wbco_tick_ws_size(st));
-    for (int i = job->begin; i < job->end; ++i) {
-        wbco_inputs in;
-        in.M = job->in->M + (size_t)i * mlen;
-        in.h = job->in->h + (size_t)i * nv;
-        in.A = job->in->A + (size_t)i * st->n_dense * nv;
-        in.b1 = job->in->b1 + (size_t)i * r1;
-        in.Ac = job->in->Ac + (size_t)i * nc * 6 * nv;
-        in.bc = job->in->bc + (size_t)i * nc * 6;
-        in.blb = job->in->blb + (size_t)i * st->n_bound;
-        in.bub = job->in->bub + (size_t)i * st->n_bound;
-        in.tlb = job->in->tlb + (size_t)i * na;
-        in.tub = job->in->tub + (size_t)i * na;
-        in.w = job->in->w + (size_t)i * st->n_tasks;
-        wbco_outputs out;
-        out.x = job->out->x + (size_t)i * n;
-        out.tau = job->out->tau + (size_t)i * na;
-        out.lambda = NULL;
-        out.active = NULL;
-        wbco_tick(st, &in, &out, ws);
-        job->out->status[i] = out.status;
-        job->out->iters[i] = out.iters;
+    double* ws = (double*)malloc(sizeof(double) * ((size_t)wbco_tick_ws_size(st) + n + (na > 0 ? na : 1)));
+    double* sx = ws + wbco_tick_ws_size(st);
+    double* stau = sx + n;
+    if (job->start) pthread_barrier_wait(job->start);
+    for (;;) {
+        const long t0 = atomic_fetch_add(job->next, (long)WBCO_CHUNK);
+        if (t0 >= job->total) break;
+        const long t1 = t0 + WBCO_CHUNK < job->total ? t0 + WBCO_CHUNK : job->total;
+        for (long t = t0; t < t1; ++t) {
+            const int i = (int)(t % job->batch);
+            const int first = t < job->batch;
+            wbco_inputs in;
+            in.M = job->in->M + (size_t)i * mlen;
+            in.h = job->in->h + (size_t)i * nv;
+            in.A = job->in->A + (size_t)i * st->n_dense * nv;
+            in.b1 = job->in->b1 + (size_t)i * r1;
+            in.Ac = job->in->Ac + (size_t)i * nc * 6 * nv;
+            in.bc = job->in->bc + (size_t)i * nc * 6;
+            in.blb = job->in->blb + (size_t)i * st->n_bound;
+            in.bub = job->in->bub + (size_t)i * st->n_bound;
+            in.tlb = job->in->tlb + (size_t)i * na;
+            in.tub = job->in->tub + (size_t)i * na;
+            in.w = job->in->w + (size_t)i * st->n_tasks;
+            wbco_outputs out;
+            out.x = first ? job->out->x + (size_t)i * n : sx;
+            out.tau = first ? job->out->tau + (size_t)i * na : stau;
+            out.lambda = NULL;
+            out.active = NULL;
+            wbco_tick(st, &in, &out, ws);
+            if (first) {
+                job->out->status[i] = out.status;
+                job->out->iters[i] = out.iters;
+            }
+        }
     }
     free(ws);
     return NULL;
 }
 
+/* reps passes over the batch on nthreads threads; returns the seconds between the start line and the last thread's end
+ * (negative on error).  reps <= 1: one pass. */
+double wbco_tick_batch_timed(const wbco_structure* st, int batch, const wbco_batch_inputs* in,
+                             const wbco_batch_outputs* out, int nthreads, int reps)
+{
+    if (batch <= 0) return 0.0;
+    if (reps < 1) reps = 1;
+    if (nthreads < 1) nthreads = 1;
+    const long total = (long)batch * reps;
+    if ((long)nthreads * WBCO_CHUNK > total) nthreads = (int)((total + WBCO_CHUNK - 1) / WBCO_CHUNK);
+    atomic_long next;
+    atomic_init(&next, 0);
+    batch_job job = {st, in, out, batch, total, &next, NULL};
+    if (nthreads == 1) {
+        const double t0 = now_s();
+        batch_worker(&job);
+        return now_s() - t0;
+    }
+    pthread_barrier_t start;
+    if (pthread_barrier_init(&start, NULL, (unsigned)nthreads + 1) != 0) return -1.0;
+    job.start = &start;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
+    int made = 0;
+    for (; made < nthreads; ++made)
+        if (pthread_create(&th[made], NULL, batch_worker, &job) != 0) break;
+    if (made < nthreads) { /* cannot reach the start line: release what exists through the counter and give up */
+        atomic_store(&next, total);
+        for (int t = made; t < nthreads; ++t) pthread_create(&th[t], NULL, batch_worker, &job);
+    }
+    pthread_barrier_wait(&start);
+    const double t0 = now_s();
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    const double dt = now_s() - t0;
+    pthread_barrier_destroy(&start);
+    free(th);
+    return made < nthreads ? -1.0 : dt;
+}
+
 int wbco_tick_batch(const wbco_structure* st, int batch, const wbco_batch_inputs* in,
                     const wbco_batch_outputs* out, int nthreads)
 {
-    if (nthreads < 1) nthreads = 1;
-    if (nthreads > batch) nthreads = batch > 0 ? batch : 1;
-    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
-    batch_job* jobs = (batch_job*)malloc(sizeof(batch_job) * nthreads);
-    for (int t = 0; t < nthreads; ++t) {
-        jobs[t].st = st;
-        jobs[t].in = in;
-        jobs[t].out = out;
-        jobs[t].begin = (int)((long)batch * t / nthreads);
-        jobs[t].end = (int)((long)batch * (t + 1) / nthreads);
-        if (nthreads == 1)
-            batch_worker(&jobs[t]);
-        else
-            pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
-    }
-    if (nthreads > 1)
-        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
-    free(th);
-    free(jobs);
-    return 0;
+    return wbco_tick_batch_timed(st, batch, in, out, nthreads, 1) < 0.0 ? -1 : 0;
 }
 
 

@@ -131,6 +131,12 @@ typedef struct {
     double *x, *tau;
     int *status, *iters;
 } wbco_batch_outputs;
+/* reps passes over the batch on nthreads threads (work handed out from one counter, per-thread workspace, no allocation
+ * per QP); returns the seconds from the moment every thread stands at the start line to the last thread's end (< 0: error).
+ * Pass 0 writes `out`.  The timing loop of the CPU baseline (shape of qp_timer_test.cpp:55-63, many ticks per timer). */
+double wbco_tick_batch_timed(const wbco_structure* st, int batch, const wbco_batch_inputs* in,
+                             const wbco_batch_outputs* out, int nthreads, int reps);
+long wbco_assemble_ws_size(const wbco_structure* st);
 int wbco_tick_batch(const wbco_structure* st, int batch, const wbco_batch_inputs* in,
                     const wbco_batch_outputs* out, int nthreads);
 

@@ -48,3 +48,61 @@ def test_shard_and_allgather_equals_single_rank(tmp_path, oracle_mod):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "tau_%d.npy" % r))
         assert np.array_equal(got, ref), r
+
+
+def _worker_squat(rank, world, port, B, out_dir):
+    """BASELINE config 4 in small: Talos squat stream, contiguous shards (inria_wbc_amd.shard), all-gather of tau."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inria_wbc_amd import shard, structure, synth
+    from oracle import oracle
+    st = structure.talos_structure()
+    begin, end = shard.contiguous_shards(world * B, world)[rank]
+    mine = synth.generate(st, end - begin, synth.SEED_BASE["talos_squat"], first=begin, squat=True)
+    out = oracle.tick_batch(st, mine)
+    tau = torch.from_numpy(out["tau"].copy())
+    gathered = torch.zeros(world * B, st.na, dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered, tau)
+    np.save(os.path.join(out_dir, "squat_tau_%d.npy" % rank), gathered.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_squat_stream_shards_and_gathers(tmp_path, oracle_mod):
+    from inria_wbc_amd import structure, synth
+    world, B = 2, 4
+    mp.spawn(_worker_squat, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    st = structure.talos_structure()
+    full = synth.generate(st, world * B, synth.SEED_BASE["talos_squat"], squat=True)
+    ref = oracle_mod.tick_batch(st, full)["tau"]
+    for r in range(world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "squat_tau_%d.npy" % r)), ref), r
+
+
+def test_ragged_shards_balance_cost_and_cover_every_qp():
+    """a ragged batch is cut by cumulative n^3 cost, not by count."""
+    from inria_wbc_amd import shard
+    groups = [(9, 3000), (12, 1000), (62, 700), (74, 2000), (62, 492)]  # Franka, Tiago, iCub, Talos, Talos single support
+    for world in (1, 2, 3, 4, 8):
+        shards = shard.ragged_shards(groups, world)
+        assert len(shards) == world
+        seen = {gi: [] for gi in range(len(groups))}
+        for pieces in shards:
+            last = (-1, 0)
+            for gi, b, e in pieces:
+                assert 0 <= b < e <= groups[gi][1]
+                assert (gi, b) >= last  # contiguous in the concatenated batch index
+                last = (gi, e)
+                seen[gi].append((b, e))
+        for gi, (_, cnt) in enumerate(groups):
+            iv = sorted(seen[gi])
+            assert iv[0][0] == 0 and iv[-1][1] == cnt and all(iv[i][1] == iv[i + 1][0] for i in range(len(iv) - 1))
+        cost = shard.shard_costs(groups, shards)
+        mean = sum(cost) / world
+        assert max(abs(c - mean) for c in cost) <= 74.0 ** 3  # within one QP of the largest structure
+    # by count the same batch would be far off: the first half holds the small robots
+    by_count = shard.shard_costs(groups, [[(0, 0, 3000), (1, 0, 596)], [(1, 596, 1000), (2, 0, 700), (3, 0, 2000), (4, 0, 492)]])
+    assert by_count[1] > 50 * by_count[0]
+    assert shard.contiguous_shards(8192, 8)[3] == (3072, 4096)

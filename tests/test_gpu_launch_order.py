@@ -33,28 +33,30 @@ def _run(st, inputs, flags, launches, want_order=False):
 
 @pytest.mark.parametrize("batch", [1, 17, 256, 300, 512, 1024, 1040, 2048, 2100])
 def test_every_dispatch_gives_the_same_bits(batch):
-    """queue + packed order (default), queue + longest-first, queue + index order, hardware dispatch: bitwise the same."""
+    """default, queue + packed order, queue + longest-first, queue + index order, hardware dispatch: bitwise the same."""
     from inria_wbc_amd import capi, structure, synth
     st = structure.talos_structure()
     inputs = synth.generate(st, batch, synth.SEED_BASE["talos"] + 31 * batch)
     plain = _run(st, inputs, capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH, 1)[0]
     assert (plain["status"] != -99).all()
-    for flags in (0, capi.FLAG_NO_PACKING, capi.FLAG_INDEX_ORDER, capi.FLAG_HW_DISPATCH):
+    Q = capi.FLAG_QUEUE
+    for flags in (0, Q, Q | capi.FLAG_NO_PACKING, Q | capi.FLAG_INDEX_ORDER, capi.FLAG_HW_DISPATCH):
         for o in _run(st, inputs, flags, 3):
             for k in ("x", "tau", "status", "iters"):
                 assert np.array_equal(o[k], plain[k], equal_nan=True), (flags, k)
 
 
-@pytest.mark.parametrize("batch,noise", [(1024, 1.0), (1024, 2.0), (512, 1.0), (2048, 1.0), (1536, 0.3), (272, 1.0)])
+@pytest.mark.parametrize("batch,noise", [(1024, 1.0), (1024, 2.0), (512, 1.0), (2048, 1.0), (4096, 1.0), (1536, 0.3), (544, 1.0)])
 def test_packed_order_matches_the_host_model(batch, noise):
     from inria_wbc_amd import capi, launch_order, structure, synth
     import torch
     st = structure.talos_structure()
     inputs = synth.generate(st, batch, synth.SEED_BASE["talos"] + 5, task_noise=noise)
-    outs, orders = _run(st, inputs, 0, 2, want_order=True)
+    outs, orders = _run(st, inputs, capi.FLAG_QUEUE, 2, want_order=True)
     iters = outs[0]["iters"]
     order, packed = orders[0]
-    resident = torch.cuda.get_device_properties(0).multi_processor_count  # one Talos QP per CU
+    # resident workgroups: QPs per CU (compact layout: two Talos QPs) x CUs
+    resident = capi.layout_of(st)["waves_per_cu"] * torch.cuda.get_device_properties(0).multi_processor_count
     assert packed == launch_order.packs(batch, resident)
     assert sorted(order.tolist()) == list(range(batch))
     cls = np.clip(iters, 0, launch_order.MAX_CLASS)
@@ -79,3 +81,21 @@ def test_small_structures_share_a_cu():
         for o in _run(st, inputs, flags, 3):
             for k in ("x", "tau", "status", "iters"):
                 assert np.array_equal(o[k], plain[k], equal_nan=True), (flags, k)
+
+
+@pytest.mark.parametrize("robot,batch", [("talos", 700), ("icub", 900), ("talos_single_support", 300), ("tiago", 1000)])
+def test_compact_and_full_lds_layouts_agree(robot, batch):
+    """The compact LDS layout (two QPs per CU, wbcqp_compact.hpp) and the full one (WBCQP_FLAG_FULL_LDS) are the same
+    algorithm with different summation orders in a few places: same status and iteration counts, x / tau to rounding."""
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.STRUCTURES[robot]()
+    inputs = synth.generate(st, batch, synth.SEED_BASE.get(robot, 77) + 11)
+    a = _run(st, inputs, capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH, 1)[0]
+    b = _run(st, inputs, capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH | capi.FLAG_FULL_LDS, 1)[0]
+    assert np.array_equal(a["status"], b["status"])
+    assert (a["iters"] == b["iters"]).mean() >= 0.99
+    ok = a["status"] == 0
+    scale = np.maximum(1.0, np.abs(b["x"]).max(axis=1, keepdims=True))
+    assert (np.abs(a["x"] - b["x"]) / scale)[ok].max() < 1e-9
+    if st.na:
+        assert np.abs(a["tau"] - b["tau"])[ok].max() < 1e-6 * max(1.0, np.abs(b["tau"][ok]).max())

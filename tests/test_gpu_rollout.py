@@ -128,6 +128,55 @@ def test_tick_and_graph_replay_are_the_three_calls(B):
     assert (results[0][2] == 0).all()
 
 
+def test_graph_replay_survives_other_launches_on_the_same_handle():
+    """A captured tick owns its launch-order buffer and queue counter: launches of other shapes on the same handle (which
+    resize and overwrite the handle's own order buffer) between replays change nothing -- bitwise equal to an index-order run."""
+    import torch
+    from inria_wbc_amd import synth
+    m = mdl.talos_like()
+    st = structure.talos_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    B = 64
+    results = []
+    for mode in ("plain", "graph"):
+        h = capi.Handle(0, capi.F64, flags=capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH if mode == "plain" else capi.FLAG_QUEUE)
+        h.set_structure(0, st)
+        h.set_model(0, m, tm)
+        state, rows, out, qn, vn = _tick_buffers(m, st, tm, B, 88_500, dev, torch)
+        q_init, v_init = state["q"].clone(), state["v"].clone()
+        g = h.tick_graph(0, B, state, rows, out, qn, vn, tm.dt) if mode == "graph" else None
+        state["q"].copy_(q_init); state["v"].copy_(v_init)
+        others = []
+        for ob in (256, 32, 1500):
+            oi = synth.generate(st, min(ob, 256), synth.SEED_BASE["talos"] + ob)
+            reps = (ob + 255) // 256
+            d_in = {k: torch.from_numpy(np.ascontiguousarray(np.tile(v, (reps, 1))[:ob])).to(dev) for k, v in oi.items() if v.size}
+            d_out = dict(x=torch.zeros(ob, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(ob, st.na, dtype=torch.float64, device=dev),
+                         status=torch.zeros(ob, dtype=torch.int32, device=dev), iters=torch.zeros(ob, dtype=torch.int32, device=dev))
+            others.append((ob, d_in, d_out))
+        for k in range(9):
+            if mode == "graph":
+                ob, d_in, d_out = others[k % 3]
+                for _ in range(2):  # the second launch of a shape uses (and the first one resizes) the handle's order buffer
+                    h.solve_batch(0, ob, d_in, d_out, stream=stream)
+                h.tick_graph_launch(g, stream=stream)
+            else:
+                h.tick(0, B, state, rows, out, qn, vn, tm.dt, stream=stream)
+            state["q"].copy_(qn)
+            state["v"].copy_(vn)
+        torch.cuda.synchronize()
+        results.append((state["q"].cpu().numpy().copy(), out["tau"].cpu().numpy().copy(), out["status"].cpu().numpy().copy(),
+                        out["iters"].cpu().numpy().copy()))
+        if g is not None:
+            h.tick_graph_destroy(g)
+        h.close()
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b)
+    assert (results[0][2] == 0).all()
+
+
 def test_tick_host_equals_the_device_tick():
     """wbcqp_tick_host stages the state up and the solution down around the same three launches."""
     import torch

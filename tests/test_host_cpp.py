@@ -119,6 +119,43 @@ def test_qp_timer_test_closed_loop_on_the_model(host_build, oracle_mod, tmp_path
 
 
 @pytest.mark.gpu
+def test_closed_loop_takes_reference_shaped_sensor_data(host_build, tmp_path):
+    """Controller::update in closed loop (controller.cpp:161-205): the sensor keys the reference requires are required here,
+    a floating base arrives split into floating_base_position / _velocity + joints, and feeding the controller's own
+    integrated state back through them gives bitwise the open-loop run.  Also: the same file loads as "talos-pos-tracker"
+    (talos_pos_tracker.cpp:35), and a configuration that switches the stabiliser on is refused with a message that says why."""
+    cfg = os.path.join(ROOT, "configs/talos/pos_tracker_model.yaml")
+    beh = os.path.join(ROOT, "configs/talos/squat.yaml")
+    outs = {}
+    for mode, env in (("open", {}), ("sensors", {"IWBC_SENSOR_LOOP": "1"}), ("talos", {"IWBC_CONTROLLER_NAME": "talos-pos-tracker"})):
+        tau_path, q_path = str(tmp_path / ("tau_%s.bin" % mode)), str(tmp_path / ("q_%s.bin" % mode))
+        r = subprocess.run([host_build["qp_timer_test"], cfg, beh, "-", "25", tau_path, "0", q_path], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[mode] = (np.fromfile(tau_path, dtype=np.float64), np.fromfile(q_path, dtype=np.float64))
+    for mode in ("sensors", "talos"):
+        assert np.array_equal(outs["open"][0], outs[mode][0]) and np.array_equal(outs["open"][1], outs[mode][1]), mode
+    r = subprocess.run([host_build["qp_timer_test"], cfg, beh, "-", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, IWBC_SENSOR_LOOP="missing"))
+    assert r.returncode != 0 and "we need the joint positions in closed loop mode" in (r.stdout + r.stderr)
+    text = open(cfg).read()
+    assert "CONTROLLER:" in text
+    stab = str(tmp_path / "stab.yaml")
+    with open(stab, "w") as fh:
+        fh.write(text.rstrip("\n") + "\n  stabilizer:\n    activated: true\n")
+    for name in ("base_path",):
+        pass
+    # the harness derives base_path from the file's directory: keep the relative files reachable
+    for f in os.listdir(os.path.dirname(cfg)):
+        src = os.path.join(os.path.dirname(cfg), f)
+        if os.path.isfile(src) and not os.path.exists(str(tmp_path / f)):
+            os.symlink(src, str(tmp_path / f))
+    r = subprocess.run([host_build["qp_timer_test"], stab, beh, "-", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, IWBC_CONTROLLER_NAME="humanoid-pos-tracker"))
+    assert r.returncode != 0 and "stabilizer" in (r.stdout + r.stderr) and "not part of this build" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
 def test_qp_timer_test_franka_cartesian_line(host_build, oracle_mod, tmp_path):
     """BASELINE config 1 on the model: PosTracker + generic::cartesian (etc/franka/cartesian_line.yaml: ee 0.4 m along -x in
     2 s, min-jerk) on the Franka-like arm, closed loop for 600 ticks, against the oracle loop fed the same SE(3) stream, and
