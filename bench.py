@@ -172,6 +172,37 @@ def _corr(a, b):
     return float(np.corrcoef(a, b)[0, 1])
 
 
+def usable_cores():
+    """(threads to use, how that number was found): the CPUs this process may run on, capped by the container's CPU quota
+    (cgroup cpu.max) -- os.cpu_count() alone reports the machine, not what the container is given."""
+    n = os.cpu_count() or 1
+    note = "os.cpu_count() = %d" % n
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, note = aff, note + ", affinity mask %d" % aff
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota = txt[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                    period = float(fh2.read().split()[0])
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    n, note = q, note + ", cgroup CPU quota %d" % q
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, note
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -326,7 +357,7 @@ def main():
         abytes = (ab64 - 8) // 2 + 8 if f32 else ab64
         achieved = abytes * B / kern_avg_s / 1e9
         per_cu = layout["waves_per_cu"]
-        queued = (per_cu == 1 or (base_flags & capi.FLAG_QUEUE)) and not (base_flags & capi.FLAG_HW_DISPATCH)
+        queued = (layout["lds_bytes"] >= 48 * 1024 or (base_flags & capi.FLAG_QUEUE)) and not (base_flags & capi.FLAG_HW_DISPATCH)
         compact = per_cu >= 2 or layout["lds_bytes"] <= 80 * 1024
         tname = "float" if f32 else "double"
         kernel = "wbcqp::%s<%s, %s>" % ("solve_queue_kernel" if queued else "solve_kernel", tname, "true" if compact and not (base_flags & capi.FLAG_FULL_LDS) else "false")
@@ -343,7 +374,7 @@ def main():
                        "stream": ("instance i at step t solves tick (i + t) of the squat CoM reference (etc/talos/squat.yaml, move_com.cpp:22-45); "
                                   "%d consecutive ticks resident, cycled" % N_TICKS) if stream else "the same batch every step",
                        "schedule": "index-order" if args.index_order else
-                       ("queue of resident workgroups; order from the iteration counts of an earlier launch, renewed every 4th launch" if queued else
+                       ("queue of resident workgroups (2 per CU), longest-first from the iteration counts of an earlier launch, renewed every 4th launch" if queued else
                         "hardware dispatch, longest-first from the iteration counts of an earlier launch, renewed every 4th launch"),
                        "allgather_tau": bool(gather["ok"]), "lds_bytes_per_qp": layout["lds_bytes"],
                        "qps_resident_per_cu": per_cu},
@@ -409,8 +440,7 @@ def main():
             result["replayed_batch"] = variant(base_flags, "the same batch every step: the order comes from the very QPs it schedules (round 1's headline; an upper bound)", replay=True)
             result["index_order"] = variant(capi.FLAG_INDEX_ORDER, "same stream, QPs taken in index order (no schedule at all)")
             result["hw_dispatch"] = variant(HW, "same stream, longest-first, one workgroup per QP dealt out by the hardware's dispatcher")
-            result["queue_packed"] = variant(Q, "same stream, resident workgroups take QPs from a queue, bin-packed order where the launch is small enough")
-            result["queue_longest_first"] = variant(Q | capi.FLAG_NO_PACKING, "same stream, queue, plain longest-first order")
+            result["queue_packed"] = variant(Q, "same stream, queue, bin-packed order where the launch is small enough (default at one workgroup per CU only)")
             result["refresh_every_launch"] = variant(base_flags | capi.flag_refresh(1), "same stream, order renewed after every launch (default: every 4th, WBCQP_FLAG_REFRESH)")
             result["full_lds_layout"] = variant(capi.FLAG_FULL_LDS, "same stream on round 1's layout: every array of the QP in LDS (Talos: one QP per CU), queue + packed order")
             try:  # unrelated batches: every launch is scheduled from the counts of QPs that have nothing to do with it
@@ -488,7 +518,7 @@ def main():
             # start line and the last one's end (loop shape of qp_timer_test.cpp:55-63)
             from oracle import oracle
             oracle.build()
-            cores = os.cpu_count() or 1
+            cores, cores_note = usable_cores()
             nsamp = min(B, 256)
             cpu_in = {k: v.copy() for k, v in inputs.items()}
             if stream:
@@ -496,8 +526,10 @@ def main():
             sub = {k: v[:nsamp] for k, v in cpu_in.items()}
             s1, ref = oracle.tick_batch_timed(st, sub, nthreads=1, reps=1)
             single = nsamp / s1
-            budget = max(1.0, args.cpu_seconds - s1)
-            reps = int(max(1, min(4096, budget * single * cores * 0.7 / B)))
+            # one pass on all usable cores sizes the timed sample (the container may grant fewer CPUs than it shows)
+            sp1, _ = oracle.tick_batch_timed(st, cpu_in, nthreads=cores, reps=1)
+            budget = max(1.0, args.cpu_seconds - s1 - sp1)
+            reps = int(max(1, min(4096, budget / max(sp1, 1e-6))))
             sm, _ = oracle.tick_batch_timed(st, cpu_in, nthreads=cores, reps=reps)
             multi = B * reps / sm
             ok = ref["status"] == 0
@@ -507,6 +539,7 @@ def main():
                 "sample": "%d passes over the %d QPs of the last timed tick on %d pthreads (%.1f s); single thread %.0f QP/s on %d QPs" %
                           (reps, B, cores, sm, single, nsamp),
                 "single_thread": single, "scaling_efficiency": multi / (single * cores), "cpu_model": cpu_model(),
+                "cores_note": cores_note,
             }
             result["parity"] = {
                 "sample": nsamp, "tick": int(last_tick),

@@ -60,6 +60,7 @@ struct OrderState {
 };
 
 constexpr size_t kMaxQueues = 16;
+constexpr int kQueueMinLds = 48 * 1024; // workgroups at least this large take their QPs from the queue by default
 constexpr int kOrderRefresh = 4; // default period of the launch-order renewal (WBCQP_FLAG_REFRESH)
 
 struct wbcqp_handle {
@@ -128,11 +129,12 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
     HB.n_blocks = st->n_ineq_blocks;
     int off = 0;
     bool has_act = false;
+    int act_off = -1, n_act_blocks = 0;
     for (int b = 0; b < HB.n_blocks; ++b) {
         const int kind = st->ineq_kind[b];
         int rows;
         if (kind == WBCQP_INEQ_BOUNDS) rows = D.n_bound;
-        else if (kind == WBCQP_INEQ_ACTUATION) { rows = D.na; has_act = true; }
+        else if (kind == WBCQP_INEQ_ACTUATION) { rows = D.na; has_act = true; act_off = off; ++n_act_blocks; }
         else if (kind == WBCQP_INEQ_FORCE) {
             rows = 17;
             if (st->ineq_arg[b] < 0 || st->ineq_arg[b] >= D.nc) { why = "force block names a missing contact"; return WBCQP_ERR_INVALID; }
@@ -143,6 +145,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
     }
     if (has_act != (D.act_bounds != 0)) { why = "act_bounds flag and inequality blocks disagree"; return WBCQP_ERR_INVALID; }
     D.nin2 = off;
+    D.act_off = (n_act_blocks == 1) ? act_off : -1;
     if (D.nin2 > 4 * kSlot) { why = "more than 512 one-sided inequality rows"; return WBCQP_ERR_UNSUPPORTED; }
     if (D.r1 > 2 * kSlot) { why = "more than 256 level-1 rows"; return WBCQP_ERR_UNSUPPORTED; }
     if (D.neq > D.n) { why = "more equalities than variables"; return WBCQP_ERR_INVALID; }
@@ -200,7 +203,7 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
     D.compact = 0;
     const int n = F.n, nv = F.nv;
     if (!(n <= 80 && F.neq <= 22 && nv <= 52 && F.nc <= 2 && F.nu <= 8 && F.na <= 64 && F.n_bound <= 64 && F.nin2 <= 256 &&
-          F.r1 <= 128 && F.n_tasks <= 64))
+          F.r1 <= 128 && F.n_tasks <= 64 && (!F.act_bounds || F.act_off >= 0)))
         return false;
     int o = 0;
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; };
@@ -318,9 +321,11 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     OrderState& os = h->graph_ord ? *h->graph_ord : h->ord;
     tab.order = (sched && os.total == total && os.sig == sig && os.stream == stream)
                     ? os.order + (os.packed ? os.cap : 0) : nullptr;
-    // The queue pays when a workgroup fills a CU: then the dispatcher's binding of a workgroup to one shader engine leaves
-    // CUs idle.  Small QPs (several workgroups per CU: Franka, 3) give the dispatcher slack, and one hand-over (1 us) is a
-    // tenth of such a QP -- measured 27 M QP/s through the queue against 36 M through the hardware.  WBCQP_FLAG_QUEUE forces it.
+    // The queue pays when a QP is long enough for a hand-over (1 us: atomic + order entry) to vanish and few enough workgroups
+    // fit a CU for the dispatcher's binding of a workgroup to one shader engine to leave CUs idle: the humanoid stacks (one
+    // or two workgroups per CU; measured on the compact layout, tools/dispatch_sweep.py: 1-2 % over the dispatcher at every
+    // batch size).  Small QPs (Franka: 26 KB of LDS) give the dispatcher slack -- measured 27 M QP/s through the queue
+    // against 36 M through the hardware.  WBCQP_FLAG_QUEUE forces the queue, WBCQP_FLAG_HW_DISPATCH the dispatcher.
     if (h->queue_lds[V] != lds_bytes) {
         int occ = 0;
         HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI, CP>, kThreads, (size_t)lds_bytes));
@@ -330,7 +335,7 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     }
     const int queue_occ = h->queue_occ[V];
     int* queue = nullptr;
-    if (!(h->flags & WBCQP_FLAG_HW_DISPATCH) && (queue_occ == 1 || (h->flags & WBCQP_FLAG_QUEUE))) {
+    if (!(h->flags & WBCQP_FLAG_HW_DISPATCH) && (lds_bytes >= kQueueMinLds || (h->flags & WBCQP_FLAG_QUEUE))) {
         if (h->graph_ord) queue = h->graph_ord->queue;
         else
             for (auto& q : h->queues)
@@ -371,7 +376,8 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         HIP_TRY(h, hipGetLastError());
         // a few QPs per resident workgroup, one structure, taken from the queue: pack the order (pack_order_kernel)
         const long long resident = queue ? (long long)queue_occ * h->n_cu : 0;
-        os.packed = queue && !(h->flags & WBCQP_FLAG_NO_PACKING) && tab.n == 1 && resident % kPackSubs == 0 &&
+        // (with two workgroups per CU the packed order measured no better than plain longest-first: WBCQP_FLAG_QUEUE asks for it)
+        os.packed = queue && !(h->flags & WBCQP_FLAG_NO_PACKING) && (queue_occ == 1 || (h->flags & WBCQP_FLAG_QUEUE)) && tab.n == 1 && resident % kPackSubs == 0 &&
                           total % kPackSubs == 0 && total > resident && total <= 8 * resident && total / kPackSubs <= kPackMaxItems;
         if (os.packed) {
             PackArgs pa{tab.g[0].iters, os.order, os.order + os.cap, total, (int)(resident / kPackSubs)};

@@ -48,17 +48,17 @@ struct ActRegs {
     double aj[cp::KQ];
 };
 
-// tau' = M_a xn - J_a' fn with xn = x + t z formed on the fly; same lane layout as act_rows().  Every read is base +
-// immediate from ONE per-lane address (q4): coefficients past nv / k are zero and what they multiply is finite -- the x and
-// z slots are zero from n to their end (set once per QP) and nv + 23 < 80.
-__device__ __forceinline__ void act_rows_reg(Ctx& c, const ActRegs& a, double* out, double t)
+// One actuation row of tau' = M_a xn - J_a' fn with xn = xp + t zp formed on the fly (t = 0: xn = xp exactly): four lanes per
+// row (act_rows()' layout), every lane of the quad returns the row's total.  Every read is base + immediate from ONE
+// per-lane address: coefficients past nv / k are zero and what they multiply is finite -- the x and z slots are zero from
+// n to their end (set once per QP) and nv + 23 < 80.
+__device__ __forceinline__ double act_dot(const Ctx& c, const ActRegs& a, const double* xp, const double* zp, double t)
 {
-    const int nv = c.nv, na = c.na;
-    const int rr = c.tid >> 2, q4 = c.tid & 3;
-    const double* zq = c.z + q4;
-    const double* xq = c.x + q4;
-    const double* zfq = c.z + nv + q4;
-    const double* xfq = c.x + nv + q4;
+    const int nv = c.nv, q4 = c.tid & 3;
+    const double* zq = zp + q4;
+    const double* xq = xp + q4;
+    const double* zfq = zq + nv;
+    const double* xfq = xq + nv;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     double zv[cp::NVQ], xv[cp::NVQ];
 #pragma unroll
@@ -91,7 +91,41 @@ __device__ __forceinline__ void act_rows_reg(Ctx& c, const ActRegs& a, double* o
     double acc = (a0 + a1) + (a2 + a3);
     acc += dpp_get<0xB1>(acc);
     acc += dpp_get<0x4E>(acc);
-    if (q4 == 0 && rr < na) out[rr] = acc;
+    return acc;
+}
+
+// update_r_wave with d read as dsg * dsrc[.] (a bound's d is a row of J that has not been copied to d yet)
+__device__ __forceinline__ void update_r_wave_src(Ctx& c, int rlo, const double* dsrc, double dsg)
+{
+    const int lane = c.lane, iq = c.iq;
+    if (iq <= rlo) return;
+    double v0 = (lane < iq) ? dsg * dsrc[lane] : 0.0;
+    double v1 = (lane + kWave < iq) ? dsg * dsrc[lane + kWave] : 0.0;
+    auto step = [&](int j, double rd, double ra, double rb) {
+        const double dj = (j < kWave) ? bcast_lane(v0, j) : bcast_lane(v1, j - kWave);
+        const double rj = dj * rd;
+        if (lane == (j & (kWave - 1))) c.r[j] = rj;
+        if (lane < j) v0 = fma(-rj, ra, v0);
+        if (lane + kWave < j) v1 = fma(-rj, rb, v1);
+    };
+    int j = iq - 1;
+    for (; j >= rlo + 3; j -= 4) {
+        double rd[4], ra[4], rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = j - u;
+            const double* Rc = c.R + roff(jj);
+            rd[u] = c.rdinv[jj];
+            ra[u] = Rc[min(lane, jj)];
+            rb[u] = Rc[min(lane + kWave, jj)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) step(j - u, rd[u], ra[u], rb[u]);
+    }
+    for (; j >= rlo; --j) {
+        const double* Rc = c.R + roff(j);
+        step(j, c.rdinv[j], Rc[min(lane, j)], Rc[min(lane + kWave, j)]);
+    }
 }
 
 // what a thread keeps about the one row of s it owns (nin2 <= 256: row tid)
@@ -264,7 +298,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             c.z[tid] = 0.0;
             c.d[tid] = 0.0;
         }
-        if (tid >= n && tid < 80) { // finite padding for act_rows_reg's unconditional reads; never written again
+        if (tid >= n && tid < 80) { // finite padding for act_dot's unconditional reads; never written again
             c.z[tid] = 0.0;
             c.x[tid] = 0.0;
         }
@@ -590,11 +624,26 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         for (int u = 0; u < cp::KQ; ++u) ar.aj[u] = 0.0;
     }
 
-    // ---------------- phase 4: inequality loop (GI steps 1, 2, 2a-2c; the five-barrier iteration of solve_one) ----------------
-    bool tau_stale = true; // tau' = A_act x not current
+    // ---------------- phase 4: inequality loop (GI steps 1, 2, 2a-2c) ----------------
+    // The common iteration (full step, constraint accepted) takes THREE barriers (two when the row is a bound):
+    //   A  d = J'n from the published row (bounds: d is a row of J, formed inside B)                                  | bar
+    //   B  waves 0-2: z = J2 d2 (+ z'z, z'n, |d2|^2, column iq of J stashed); wave 3: r = R^-1 d, t1                   | bar
+    //   C  everything that follows from (t, alpha) at once: J -= w v' with w formed per thread, new column of R, u,
+    //      x_next into the OTHER x buffer, tau' and s of the next iterate from x + t z on the fly by the lanes that own the
+    //      rows, psi / most violated row reduced -- the barrier that ends C is the one the next iteration's pick waits for  | bar
+    // solve_one spends five barriers and three more LDS round trips on the same work (P4 | P5 | P1).  Partial steps, dual
+    // steps and rejected (dependent) constraints leave this path: they keep the plain barrier-per-phase code of solve_one,
+    // x is then updated in place with a snapshot in the other buffer, and the next pick re-evaluates s from scratch.
+    // Row ownership: thread i owns row i of s when it is a bound or friction row; the actuation rows +-[M_a | -J_a'] of
+    // joint rr belong to lanes 0 (+) and 1 (-) of quad rr, which hold tau' in a register anyway.
+    bool tact_valid = false;                      // tact[] = A_act x of the current iterate
     const bool act_ineq = S.act_bounds && na > 0; // actuation rows are inequality rows (otherwise tau' is only decoded)
     if (status == -2 && nin2 > 0) {
-        if (tid < nin2) act[tid] = 0;
+        if (tid < nin2) {
+            act[tid] = 0;
+            excl[tid] = 1;
+        }
+        if (tid >= n && tid < 80) c.xold[tid] = 0.0; // the second x buffer gets the same finite padding as the first
         OwnRow own;
         {
             own.meta = -1;
@@ -605,10 +654,12 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 const int mt = c.meta[tid];
                 const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15;
                 const bool neg = (mt >> 2) & 1;
-                own.meta = mt;
-                if (kind == INEQ_BOUNDS) own.ci0 = neg ? c.bub[rr] : -c.blb[rr];
-                else if (kind == INEQ_ACTUATION) own.ci0 = neg ? c.tu[rr] : -c.tl[rr];
-                else {
+                if (kind == INEQ_BOUNDS) {
+                    own.meta = mt;
+                    own.ci0 = neg ? c.bub[rr] : -c.blb[rr];
+                }
+                else if (kind == INEQ_FORCE) {
+                    own.meta = mt;
                     own.ci0 = neg ? S.fric_ub[ct * 17 + rr] : -S.fric_lb[ct * 17 + rr];
                     const double* B = S.fric_mat + (ct * 17 + rr) * 12;
 #pragma unroll
@@ -616,69 +667,100 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
             }
         }
-        if (act_ineq) act_rows_reg(c, ar, tact, 0.0);
+        const int arr = tid >> 2, aq = tid & 3;
+        const bool act_owner = act_ineq && arr < na && aq < 2;
+        const int arow = act_owner ? S.act_off + (aq ? na : 0) + arr : -1;
+        const double aci0 = act_owner ? (aq ? c.tu[arr] : -c.tl[arr]) : 0.0;
+        const double asg = aq ? -1.0 : 1.0;
+        double s_own = 0.0, s_act = 0.0; // s of the owned rows at the iterate of the last evaluation
+
+        // s = CI (xp + t zp) + ci0 for the rows this thread owns; returns its share of psi and its most violated eligible
+        // row (row ipx counts as active: its flag is being set while this runs).  tau' of that iterate lands in tact[].
+        auto eval_rows = [&](const double* xp, const double* zp, double t, int ipx, double& psi, ValIdx& best) __attribute__((always_inline)) {
+            psi = 0.0;
+            best = ValIdx{0.0, 0x7fffffff};
+            if (act_ineq) {
+                const double acc = act_dot(c, ar, xp, zp, t);
+                if (aq == 0 && arr < na) tact[arr] = acc;
+                if (act_owner) {
+                    const double v = fma(asg, acc, aci0);
+                    s_act = v;
+                    psi = fmin(0.0, v);
+                    if (v < 0.0 && !act[arow] && arow != ipx) best = ValIdx{v, arow};
+                }
+            }
+            const int mt = own.meta;
+            if (mt >= 0) {
+                const int kind = mt & 3, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
+                const bool neg = (mt >> 2) & 1;
+                double v;
+                if (kind == INEQ_BOUNDS) {
+                    const double xv = fma(t, zp[col], xp[col]);
+                    v = neg ? -xv : xv;
+                }
+                else {
+                    const double* f = xp + nv + 12 * ct;
+                    const double* zf = zp + nv + 12 * ct;
+                    double a = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) a = fma(own.coef[m], fma(t, zf[m], f[m]), a);
+                    v = a;
+                }
+                v += own.ci0;
+                s_own = v;
+                psi += fmin(0.0, v);
+                if (v < 0.0 && !act[tid] && tid != ipx) best = vi_min(best, ValIdx{v, tid});
+            }
+        };
+        auto publish_best = [&](double psi, ValIdx best) __attribute__((always_inline)) {
+            psi = wave_sum(psi);
+            best = wave_argmin(best);
+            double* slot = c.red + c.rslot * 16;
+            if (c.lane == 0) {
+                slot[c.wave] = psi;
+                slot[4 + c.wave] = best.v;
+                slot[8 + c.wave] = __hiloint2double(0, best.i);
+            }
+        };
         bsync();
         const double psi_tol = (double)nin2 * eps * c1 * c2 * 100.0;
         bool redo_l2 = false;
-        tau_stale = !act_ineq;
-        double sip = 0.0; // s(ip) of the constraint being added
+        bool s_ready = false;    // the slot holds psi / the most violated row of the current iterate
+        bool excl_dirty = false; // some excl[] entry is 0
+        bool slow = false;       // this pick has left the common path: x is updated in place, its snapshot is in c.xold
+        double sip = 0.0;        // s(ip) of the constraint being added
         while (status == -2) {
             ValIdx best;
             if (!redo_l2) {
                 // l1
+                if (!s_ready) {
+                    if (excl_dirty) {
+                        if (tid < nin2) excl[tid] = 1;
+                        excl_dirty = false;
+                    }
+                    for (int i = tid; i < c.iq; i += kThreads) {
+                        c.uold[i] = c.u[i];
+                        c.Aold[i] = c.A[i];
+                    }
+                    double psi;
+                    eval_rows(c.x, c.z, 0.0, -1, psi, best);
+                    tact_valid = act_ineq;
+                    publish_best(psi, best);
+                    bsync(); // B1
+                }
+                slow = false;
                 ++iter;
                 if (iter >= S.max_iter) {
                     status = HQP_MAX_ITER;
                     break;
                 }
-                if (act_ineq && tau_stale) {
-                    act_rows_reg(c, ar, tact, 0.0);
-                    bsync();
-                    tau_stale = false;
-                }
-                for (int i = tid; i < c.iq; i += kThreads) {
-                    c.uold[i] = c.u[i];
-                    c.Aold[i] = c.A[i];
-                }
-                for (int i = tid; i < n; i += kThreads) c.xold[i] = c.x[i];
-                double psi = 0.0;
-                best = ValIdx{0.0, 0x7fffffff};
-                {
-                    const int mt = own.meta;
-                    if (mt >= 0) {
-                        const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
-                        const bool neg = (mt >> 2) & 1;
-                        double v;
-                        if (kind == INEQ_BOUNDS) v = neg ? -c.x[col] : c.x[col];
-                        else if (kind == INEQ_ACTUATION) v = neg ? -tact[rr] : tact[rr];
-                        else {
-                            const double* f = c.x + nv + 12 * ct;
-                            double a = 0.0;
-#pragma unroll
-                            for (int m = 0; m < 12; ++m) a = fma(own.coef[m], f[m], a);
-                            v = a;
-                        }
-                        v += own.ci0;
-                        c.s[tid] = v;
-                        excl[tid] = 1;
-                        psi = fmin(0.0, v);
-                        if (v < 0.0 && !act[tid]) best = ValIdx{v, tid};
-                    }
-                }
-                psi = wave_sum(psi);
-                best = wave_argmin(best);
-                double* slot = c.red + c.rslot * 16;
-                if (c.lane == 0) {
-                    slot[c.wave] = psi;
-                    slot[4 + c.wave] = best.v;
-                    slot[8 + c.wave] = __hiloint2double(0, best.i);
-                }
-                bsync(); // B1
-                psi = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+                const double* slot = c.red + c.rslot * 16;
+                const double psi = (slot[0] + slot[1]) + (slot[2] + slot[3]);
                 best = ValIdx{slot[4], __double2loint(slot[8])};
 #pragma unroll
                 for (int w = 1; w < kWaves; ++w) best = vi_min(best, ValIdx{slot[4 + w], __double2loint(slot[8 + w])});
                 c.rslot ^= 1;
+                s_ready = false;
                 if (fabs(psi) <= psi_tol) {
                     status = HQP_OPTIMAL;
                     break;
@@ -686,12 +768,10 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 STAMP(9)
             }
             else {
-                // l2 again after a rejected constraint: s is still valid, the rejected row is excluded
+                // l2 again after a rejected constraint: the owners still hold s of the (restored) iterate, the rejected row is excluded
                 best = ValIdx{0.0, 0x7fffffff};
-                if (tid < nin2) {
-                    const double sv = c.s[tid];
-                    if (sv < 0.0 && !act[tid] && excl[tid]) best = ValIdx{sv, tid};
-                }
+                if (act_owner && s_act < 0.0 && !act[arow] && excl[arow]) best = ValIdx{s_act, arow};
+                if (own.meta >= 0 && s_own < 0.0 && !act[tid] && excl[tid]) best = vi_min(best, ValIdx{s_own, tid});
                 best = block_argmin(c, best);
                 redo_l2 = false;
             }
@@ -704,7 +784,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             // the row n of constraint ip: kind, support [k0, k1), sign; n itself is published by the lanes that own it
             const int mt = c.meta[ip];
             const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
-            const double sg = ((mt >> 2) & 1) ? -1.0 : 1.0;
+            const bool negrow = (mt >> 2) & 1;
+            const double sg = negrow ? -1.0 : 1.0;
+            const int owner_tid = (kind == INEQ_ACTUATION) ? 4 * rr + (negrow ? 1 : 0) : ip; // who holds ci0(ip)
             int k0, k1;
             if (kind == INEQ_BOUNDS) {
                 k0 = col;
@@ -743,11 +825,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             // l2a
             while (true) {
                 const int iq = c.iq;
-                // ---- P2: d = J' n
-                if (kind == INEQ_BOUNDS) {
-                    if (tid < n) c.d[tid] = sg * c.J[col * ldj + tid];
-                }
-                else if (kind == INEQ_FORCE) {
+                // ---- A: d = J' n.  A bound's d is +-row `col` of J: phase B reads it there and leaves the copy in d
+                if (kind == INEQ_FORCE) {
                     if (tid < n) {
                         const double* F = c.np + k0;
                         const double* Jb = c.J + k0 * ldj + tid;
@@ -759,8 +838,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         }
                         c.d[tid] = a0 + a1;
                     }
+                    bsync();
                 }
-                else { // actuation row: two lanes per column, halves of the support
+                else if (kind == INEQ_ACTUATION) { // two lanes per column, halves of the support
                     const int idx = tid >> 1, hf = tid & 1;
                     const int ic = min(idx, n - 1);
                     const int mid = (n + 1) >> 1;
@@ -768,29 +848,31 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     double acc = dot8(c.np, 1, c.J + ic, ldj, ka, kb);
                     acc += dpp_get<0xB1>(acc);
                     if (hf == 0 && idx < n) c.d[idx] = acc;
+                    bsync();
                 }
-                bsync(); // B2
                 STAMP(11)
-                // ---- P3: z, r and the reductions of step 2b
+                // ---- B: z, r and the reductions of step 2b
+                const double* dsrc = (kind == INEQ_BOUNDS) ? c.J + col * ldj : c.d;
+                const double dsg = (kind == INEQ_BOUNDS) ? sg : 1.0;
                 double* slot = c.red + c.rslot * 16;
                 if (c.wave < 3) {
-                    const int lpr = (2 * n <= 3 * kWave) ? 2 : 1; // lanes per row
-                    const int idx = (lpr == 2) ? (tid >> 1) : tid, hf = (lpr == 2) ? (tid & 1) : 0;
+                    const int idx = tid >> 1, hf = tid & 1; // lane pair per row (n <= 80)
                     const int ir = min(idx, n - 1);
-                    const int span = n - iq, hlen = (lpr == 2) ? ((span + 1) >> 1) : span;
+                    const int span = n - iq, hlen = (span + 1) >> 1;
                     const int ca = iq + hf * hlen, cb = min(n, ca + hlen);
                     const double* Jr = c.J + ir * ldj;
-                    double zv = dot8(Jr, 1, c.d, 1, ca, cb);
-                    if (lpr == 2) zv += dpp_get<0xB1>(zv);
+                    double zv = dsg * dot8(Jr, 1, dsrc, 1, ca, cb);
+                    zv += dpp_get<0xB1>(zv);
                     double zz = 0.0, znp = 0.0, dn2 = 0.0;
                     if (hf == 0 && idx < n) {
                         c.z[idx] = zv;
                         zz = zv * zv;
-                        if (idx >= iq) {
-                            const double dv = c.d[idx];
-                            dn2 = dv * dv;
-                        }
-                        if (idx >= k0 && idx < k1) znp = zv * c.np[idx];
+                        const double dv = dsg * dsrc[idx];
+                        if (kind == INEQ_BOUNDS) c.d[idx] = dv;
+                        if (idx >= iq) dn2 = dv * dv;
+                        // (a bound's n is +-e_col: its np entry is being written by thread 0 with no barrier in between)
+                        if (idx >= k0 && idx < k1) znp = zv * ((kind == INEQ_BOUNDS) ? sg : c.np[idx]);
+                        c.part[idx] = Jr[min(iq, n - 1)]; // column iq of J, for the w of phase C
                     }
                     zz = wave_sum(zz);
                     znp = wave_sum(znp);
@@ -802,7 +884,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     }
                 }
                 else {
-                    update_r_wave(c, neq);
+                    update_r_wave_src(c, neq, dsrc, dsg);
+                    // step 2b, partial step length t1 (dual feasibility): this wave just wrote r, LDS keeps its order
                     ValIdx bt{inf, 0x7fffffff};
                     for (int kk = neq + c.lane; kk < iq; kk += kWave) {
                         const double rk = c.r[kk];
@@ -816,7 +899,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
                 bsync(); // B3
                 STAMP(12)
-                // ---- P4: step lengths
+                // ---- step lengths
                 const double zz = (slot[0] + slot[1]) + slot[2], znp = (slot[4] + slot[5]) + slot[6];
                 const double dn2 = (slot[8] + slot[9]) + slot[10];
                 const double t1 = slot[12];
@@ -832,6 +915,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
                 if (t2 >= inf) {
                     // (ii) dual step only, drop l
+                    if (!slow && tid < n) c.xold[tid] = c.x[tid]; // leaving the common path: snapshot of x for a later rejection
+                    slow = true;
                     bsync(); // everyone has read u[iq], A[lpos] before they change
                     for (int j = neq + tid; j < iq; j += kThreads) c.u[j] = fma(-t, c.r[j], c.u[j]);
                     if (tid == kThreads - 1) {
@@ -846,7 +931,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
                 f_value += t * znp * (0.5 * t + uiq);
                 if (t == t2) {
-                    // (iii) full step: add ip to the active set with one reflector (see solve_one)
+                    // (iii) full step: add ip to the active set with one reflector H = I - tau v v' (v = d[iq:] - alpha e_0)
                     const double diq = c.d[iq];
                     double alpha = diq, v0 = 0.0, tau = 0.0;
                     const bool reflect = (iq + 1 < n && dn2 > 0.0);
@@ -858,18 +943,20 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         tau = fast_rcp(fma(nx, fabs(diq), dn2));
                     }
                     const bool accepted = fabs(alpha) > eps * c.R_norm;
-                    if (reflect && tid < n) c.part[tid] = tau * (c.z[tid] - alpha * c.J[tid * ldj + iq]);
-                    if (act_ineq) act_rows_reg(c, ar, tact, t); // tau' of the next iterate, x + t z formed on the fly
-                    bsync(); // B4
-                    STAMP(13)
-                    // ---- P5
+                    const bool fused = accepted && !slow;
+                    // w_k = tau (z_k - alpha J(k,iq)); J(:, iq) was stashed in phase B, so nobody waits for anybody here
                     if (reflect) {
+                        if (!fused) {
+                            if (tid < n) c.part[tid] = tau * (c.z[tid] - alpha * c.part[tid]);
+                            if (!slow && tid < n) c.xold[tid] = c.x[tid];
+                            bsync(); // B4 (the slow path keeps x in place)
+                        }
                         const int kr = tid & 127, half = tid >> 7;
                         if (kr < n) {
                             const int span = n - iq;
                             const int ca = iq + half * ((span + 1) >> 1), cb = half ? n : iq + ((span + 1) >> 1);
                             double* Jk = c.J + kr * ldj;
-                            const double wk = c.part[kr];
+                            const double wk = fused ? tau * (c.z[kr] - alpha * c.part[kr]) : c.part[kr];
                             int cc = ca;
                             if (cc == iq && cc < cb) {
                                 Jk[cc] = fma(-wk, v0, Jk[cc]);
@@ -888,18 +975,54 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                             for (; cc < cb; ++cc) Jk[cc] = fma(-wk, c.d[cc], Jk[cc]);
                         }
                     }
-                    {
-                        double* Rc = c.R + roff(iq);
-                        for (int i = tid; i < iq; i += kThreads) Rc[i] = c.d[i];
-                        if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
-                        if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                    else if (!fused) {
+                        if (!slow && tid < n) c.xold[tid] = c.x[tid];
+                        bsync();
+                    }
+                    double* Rc = c.R + roff(iq);
+                    for (int i = tid; i < iq; i += kThreads) Rc[i] = c.d[i];
+                    if (fused) {
+                        // ---- C: the rest of the step and the next iterate's s in one phase
+                        if (tid < n) c.xold[tid] = fma(t, c.z[tid], c.x[tid]); // x_next: the buffers swap below
+                        if (tid >= 128 + neq && tid - 128 < iq) {
+                            const double un = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                            c.u[tid - 128] = un;
+                            c.uold[tid - 128] = un;
+                        }
                         if (tid == kThreads - 1) {
                             Rc[iq] = alpha;
                             c.rdinv[iq] = 1.0 / alpha;
                             c.u[iq] = uiq + t;
-                            if (accepted) act[ip] = 1;
+                            c.uold[iq] = uiq + t;
+                            c.Aold[iq] = ip;
+                            act[ip] = 1;
                         }
+                        double psi;
+                        ValIdx nb;
+                        eval_rows(c.x, c.z, t, ip, psi, nb);
+                        tact_valid = act_ineq;
+                        publish_best(psi, nb);
+                        c.iq = iq + 1;
+                        c.R_norm = fmax(c.R_norm, fabs(alpha));
+                        bsync(); // C = B1 of the next iteration
+                        double* xt = c.x;
+                        c.x = c.xold;
+                        c.xold = xt;
+                        s_ready = true;
+                        STAMP(14)
+                        break; // -> l1
                     }
+                    // the plain path: x in place (its snapshot is in c.xold), the next pick evaluates s from scratch
+                    tact_valid = false;
+                    if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
+                    if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                    if (tid == kThreads - 1) {
+                        Rc[iq] = alpha;
+                        c.rdinv[iq] = 1.0 / alpha;
+                        c.u[iq] = uiq + t;
+                        if (accepted) act[ip] = 1;
+                    }
+                    slow = true;
                     c.iq = iq + 1;
                     bsync(); // B5
                     STAMP(14)
@@ -907,6 +1030,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     else {
                         // numerically dependent: take the constraint out again, back to the saved iterate, pick another
                         if (tid == 0) excl[ip] = 0;
+                        excl_dirty = true;
                         bsync();
                         delete_constraint(c, ip);
                         if (tid < nin2) act[tid] = 0;
@@ -920,11 +1044,13 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         for (int i = tid; i < n; i += kThreads) c.x[i] = c.xold[i];
                         bsync();
                         redo_l2 = true;
-                        tau_stale = true;
                     }
                     break; // -> l1 (or l2 again)
                 }
                 // (iii) partial step: primal + dual step, drop l, refresh s(ip)
+                if (!slow && tid < n) c.xold[tid] = c.x[tid];
+                slow = true;
+                tact_valid = false;
                 bsync(); // everyone has read u[iq], A[lpos] before they change
                 if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
                 if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
@@ -932,16 +1058,15 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 if (tid == 0) act[l] = 0;
                 bsync();
                 STAMP(13)
-                tau_stale = true;
                 delete_constraint(c, l);
                 STAMP(15)
                 {
                     double part = 0.0;
                     for (int j = k0 + tid; j < k1; j += kThreads) part = fma(c.np[j], c.x[j], part);
                     part = block_sum(c, part);
-                    if (tid == ip) c.s[ip] = part + own.ci0;
+                    if (tid == owner_tid) c.red[31] = part + ((kind == INEQ_ACTUATION) ? aci0 : own.ci0);
                     bsync();
-                    sip = c.s[ip];
+                    sip = c.red[31];
                 }
             }
         }
@@ -961,9 +1086,10 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     if (na > 0) {
         TI* to = ga.tau + qp * na;
         const TI hav = ga.h[qp * nv + nu + min(tid, na - 1)];
-        // tau' of the final iterate: the optimality test of the last l1 ran on exactly this vector
-        if (status != HQP_OPTIMAL || tau_stale) {
-            act_rows_reg(c, ar, tact, 0.0);
+        // tau' of the final iterate: the optimality test of the last pick ran on exactly this vector
+        if (status != HQP_OPTIMAL || !tact_valid) {
+            const double acc = act_dot(c, ar, c.x, c.z, 0.0);
+            if ((tid & 3) == 0 && (tid >> 2) < na) tact[tid >> 2] = acc;
             bsync();
         }
         if (tid < na) to[tid] = (TI)((double)hav + tact[tid]);

@@ -62,6 +62,7 @@ struct DevStruct {
     int lds_doubles;
     // compact layout (wbcqp_compact.hpp: half the LDS, two QPs per CU): 1 when the structure is eligible and not vetoed
     int compact;
+    int act_off;             // first one-sided row of the actuation block (+A rows; the -A rows follow na later), -1: none
     int o_pan;               // elimination panels, offset inside the J region (behind the staged task rows)
     const unsigned* acpack;  // [nc 6 nv] contact-Jacobian element (rr, kk) -> offset kk ldb + nu + rr in N = CE'
 };

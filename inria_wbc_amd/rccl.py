@@ -16,7 +16,7 @@ _lib = None
 
 
 class UniqueId(C.Structure):
-    _fields_ = [("internal", C.c_char * 128)]  # NCCL_UNIQUE_ID_BYTES
+    _fields_ = [("internal", C.c_ubyte * 128)]  # NCCL_UNIQUE_ID_BYTES (c_ubyte: a c_char array field would be cut at the first NUL)
 
 
 def lib():
@@ -56,14 +56,27 @@ def _check(rc: int, what: str):
         raise RuntimeError("%s failed: %s" % (what, (lib().ncclGetErrorString(rc) or b"?").decode()))
 
 
+def _bootstrap_env():
+    """One node, one process per GPU: the bootstrap (unique-id exchange) runs over the loopback interface unless the caller
+    chose one -- GPU boxes without an outward-facing interface otherwise fail in ncclCommInitRank with "remote process exited
+    or there was a network error".  The data path is xGMI / P2P either way."""
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
 def unique_id() -> bytes:
+    _bootstrap_env()
     uid = UniqueId()
     _check(lib().ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-    return bytes(uid.internal)
+    raw = bytes(uid.internal)
+    assert len(raw) == 128
+    return raw
 
 
 def comm_init_rank(uid: bytes, nranks: int, rank: int) -> int:
     """ncclCommInitRank on the current HIP device; returns the ncclComm_t as an integer"""
+    _bootstrap_env()
+    assert len(uid) == 128, "a unique id is 128 bytes"
     u = UniqueId()
     C.memmove(C.byref(u), uid, 128)
     comm = C.c_void_p()

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $ROOT
 python3 -c "from inria_wbc_amd import build; build.build(); build.build_stamps()" > $OUT/build.log 2>&1
-python3 bench.py --sweep $OUT/sweep.json > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --steps 20 --warmup 5 --sweep $OUT/sweep.json > $OUT/bench.json 2> $OUT/bench.err
 python3 tools/phase_profile.py --out $OUT/phase.json > $OUT/phase.txt 2>&1
 python3 tools/phase_profile.py --model > $OUT/phase_model.txt 2>&1
 python3 tools/terms_profile.py > $OUT/terms_phase.txt 2>&1
@@ -17,11 +17,13 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-compare > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/sq -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/sq.log 2>&1
 cd $OUT
+find ./sq -name "*counter_collection.csv" -exec cp {} $OUT/pmc_sq.csv \;
 find . -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find ./fetch -name "*counter_collection.csv" -exec cp {} $OUT/pmc_fetch_size.csv \;
 find ./write -name "*counter_collection.csv" -exec cp {} $OUT/pmc_write_size.csv \;
-rm -rf trace fetch write
+rm -rf trace fetch write sq
 ls -la $OUT
 tail -1 $OUT/bench.json | cut -c1-300
 head -3 $OUT/kernel_stats.csv
