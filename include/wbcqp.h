@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WBCQP_VERSION 121 /* 0.1.2: + wbcqp_integrate (0.1.1), wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions (0.1.2); 121: queue + packed launch order, wbcqp_launch_order */
+#define WBCQP_VERSION 130 /* 0.1.2: + wbcqp_integrate (0.1.1), wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions (0.1.2); 121: queue + packed launch order, wbcqp_launch_order */
 #define WBCQP_MAX_STRUCTURES 16
 #define WBCQP_MAX_INEQ_BLOCKS 16
 #define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: every per-QP vector fits one 128-entry LDS slot, n + 2 <= 128 */
@@ -211,6 +211,39 @@ int wbcqp_solve_batch_host(wbcqp_handle* handle, int slot, int batch,
                            const wbcqp_inputs* in, const wbcqp_outputs* out);
 /* Mixed-robot batch: one launch over several homogeneous groups (per-QP n differs between groups). */
 int wbcqp_solve_ragged(wbcqp_handle* handle, int n_groups, const wbcqp_group* groups, void* stream);
+
+/* ---- The narrow seam: one dense QP the way tsid's solver hands it to eiquadprog --------------------------
+ * What stands behind `solver_->resize(nVar, nEq, nIn)` (pos_tracker.cpp:102) and `const HQPOutput& solver_->solve(const
+ * HQPData&)` (controller.cpp:247) once SolverHQuadProgFast has stacked the HQPData:
+ *      min 1/2 x'Hx + g'x   s.t.  CE x + ce0 = 0,  CI x + ci0 >= 0
+ * H [n][n] (symmetric, the lower triangle is read), g [n], CE [neq][n], ce0 [neq], CI [nin][n], ci0 [nin], all row-major,
+ * nin = the rows eiquadprog sees (tsid stacks every two-sided row twice: [A; -A], ci0 = [-lb; ub]).  No structure is
+ * assumed and none is needed: this is the compatibility path for a caller that owns its HQPData (INTEGRATION.md section
+ * 3 shows the tsid SolverHQPBase subclass); wbcqp_solve_batch on a task stack is the fast path.  n <= 96 (J, R and the vectors of one QP must fit one CU's 160 KiB of LDS), nin <= 512.
+ * Status values are tsid's (wbcqp_hqp_status: eiquadprog UNBOUNDED -> INFEASIBLE, REDUNDANT_EQUALITIES -> ERROR). */
+typedef struct {
+    const void *H, *g, *CE, *ce0, *CI, *ci0; /* [batch][...] of the handle's dtype; CE / ce0 may be NULL when neq == 0, CI / ci0 when nin == 0 */
+} wbcqp_dense_inputs;
+
+/* DEVICE pointers, asynchronous on `stream`; out->tau is not written (a dense QP has no actuation model), out->x is [batch][n]. */
+int wbcqp_solve_dense(wbcqp_handle* handle, int batch, int n, int neq, int nin, int max_iter,
+                      const wbcqp_dense_inputs* in, const wbcqp_outputs* out, void* stream);
+
+/* HQPOutput of the reference: owned by the solver, valid until the next call on the same handle (the reference returns a
+ * reference to solver-owned storage, controller.cpp:247). */
+typedef struct {
+    int32_t batch, n;
+    const double* x;         /* [batch][n] */
+    const int32_t* status;   /* [batch] wbcqp_hqp_status */
+    const int32_t* iters;    /* [batch] */
+    const double* objective; /* [batch] SolverHQPBase::getObjectiveValue (pos_tracker.hpp:44) */
+    const int32_t* n_active; /* [batch] */
+} wbcqp_dense_output;
+
+/* HOST pointers to double arrays (whatever the handle's dtype: the reference's Eigen matrices are double), blocks until
+ * done; *result points into storage owned by the handle. */
+int wbcqp_solve_dense_host(wbcqp_handle* handle, int batch, int n, int neq, int nin, int max_iter,
+                           const wbcqp_dense_inputs* in, const wbcqp_dense_output** result);
 
 /* Optional exchange step: all-gather joint torques of a batch sharded over ranks.
  * `comm` is an ncclComm_t created by the caller (RCCL). send: [count] elements, recv: [nranks*count]. */

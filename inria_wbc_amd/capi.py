@@ -71,6 +71,15 @@ class CDesc(C.Structure):
     _fields_ = [("device", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_int32)]
 
 
+class CDenseInputs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("H", "g", "CE", "ce0", "CI", "ci0")]
+
+
+class CDenseOutput(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("n", C.c_int32), ("x", C.POINTER(C.c_double)), ("status", C.POINTER(C.c_int32)),
+                ("iters", C.POINTER(C.c_int32)), ("objective", C.POINTER(C.c_double)), ("n_active", C.POINTER(C.c_int32))]
+
+
 class CGroup(C.Structure):
     _fields_ = [("slot", C.c_int32), ("batch", C.c_int32), ("inp", CInputs), ("out", COutputs)]
 
@@ -464,6 +473,30 @@ class Handle:
         self._check(self.lib.wbcqp_solve_batch_host(self._h, slot, batch, C.byref(cin), C.byref(cout)))
         out["tau"] = out["tau"][:, :st.na]
         return out
+
+    def solve_dense_host(self, H, g, CE, ce0, CI, ci0, max_iter: int = 0):
+        """The narrow seam (wbcqp_solve_dense_host): dense QPs in eiquadprog's convention, [B, ...] double arrays.  The
+        returned arrays are COPIES of the handle-owned HQPOutput (which is valid until the next call)."""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        H, g = f(H), f(g)
+        if H.ndim == 2:
+            H, g = H[None], g[None]
+        B, n = g.shape
+        CE = f(CE).reshape(B, -1, n) if CE is not None and np.size(CE) else np.zeros((B, 0, n))
+        CI = f(CI).reshape(B, -1, n) if CI is not None and np.size(CI) else np.zeros((B, 0, n))
+        neq, nin = CE.shape[1], CI.shape[1]
+        ce0 = f(ce0).reshape(B, neq) if neq else np.zeros((B, 0))
+        ci0 = f(ci0).reshape(B, nin) if nin else np.zeros((B, 0))
+        ptr = lambda a: a.ctypes.data if a.size else None
+        din = CDenseInputs(ptr(H), ptr(g), ptr(CE), ptr(ce0), ptr(CI), ptr(ci0))
+        res = C.POINTER(CDenseOutput)()
+        self.lib.wbcqp_solve_dense_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(CDenseInputs),
+                                                    C.POINTER(C.POINTER(CDenseOutput))]
+        self._check(self.lib.wbcqp_solve_dense_host(self._h, B, n, neq, nin, int(max_iter), C.byref(din), C.byref(res)))
+        o = res.contents
+        return dict(x=np.ctypeslib.as_array(o.x, shape=(B, n)).copy(), status=np.ctypeslib.as_array(o.status, shape=(B,)).copy(),
+                    iters=np.ctypeslib.as_array(o.iters, shape=(B,)).copy(), objective=np.ctypeslib.as_array(o.objective, shape=(B,)).copy(),
+                    n_active=np.ctypeslib.as_array(o.n_active, shape=(B,)).copy())
 
     def allgather_tau(self, comm: int, send_ptr: int, recv_ptr: int, count: int, stream: int = 0):
         self._check(self.lib.wbcqp_allgather_tau(self._h, C.c_void_p(comm), C.c_void_p(send_ptr), C.c_void_p(recv_ptr),

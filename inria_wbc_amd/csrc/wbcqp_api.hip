@@ -6,6 +6,7 @@
 // gfx950 device wbcqp_create fails with WBCQP_ERR_NO_DEVICE.
 #include "wbcqp_device.hpp"
 #include "wbcqp_terms.hpp"
+#include "wbcqp_dense.hpp"
 
 #include "../../include/wbcqp.h"
 
@@ -84,6 +85,11 @@ struct wbcqp_handle {
     };
     std::vector<Queue> queues;
     int n_cu = 0;
+    int dense_max_lds = 0;
+    // wbcqp_solve_dense_host: the reference's HQPOutput, owned by the solver and valid until the next call
+    std::vector<double> dense_x, dense_obj;
+    std::vector<int32_t> dense_status, dense_iters, dense_nact;
+    wbcqp_dense_output dense_out{};
     int lds_pad = 0; // diagnostic (env WBCQP_DEBUG_LDS_PAD): extra dynamic LDS per workgroup, to force a lower residency
     int queue_lds[2] = {-1, -1}, queue_occ[2] = {0, 0}; // occupancy of solve_queue_kernel<., CP> at queue_lds bytes of LDS
 };
@@ -651,6 +657,112 @@ int wbcqp_solve_batch_host(wbcqp_handle* h, int slot, int batch, const wbcqp_inp
     if (out->objective) HIP_TRY(h, hipMemcpyAsync(out->objective, dso.objective, (size_t)batch * es, hipMemcpyDeviceToHost, nullptr));
     if (out->n_active) HIP_TRY(h, hipMemcpyAsync(out->n_active, dso.n_active, (size_t)batch * 4, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipStreamSynchronize(nullptr));
+    return WBCQP_OK;
+}
+
+int wbcqp_solve_dense(wbcqp_handle* h, int batch, int n, int neq, int nin, int max_iter, const wbcqp_dense_inputs* in,
+                      const wbcqp_outputs* out, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (batch < 0 || n <= 0 || neq < 0 || nin < 0) return fail(h, WBCQP_ERR_INVALID, "bad batch / n / neq / nin");
+    if (batch == 0) return WBCQP_OK;
+    if (!in || !out) return fail(h, WBCQP_ERR_INVALID, "inputs/outputs struct is NULL");
+    if (!in->H || !in->g || (neq > 0 && (!in->CE || !in->ce0)) || (nin > 0 && (!in->CI || !in->ci0)))
+        return fail(h, WBCQP_ERR_INVALID, "dense QP: H, g and the constraint arrays of non-empty blocks are required");
+    if (!out->x || !out->status || !out->iters) return fail(h, WBCQP_ERR_INVALID, "output arrays x, status, iters are required");
+    if (n > kDenseMaxVars || nin > kDenseMaxIneq || neq > n) return fail(h, WBCQP_ERR_UNSUPPORTED, "dense QP: n <= 126, nin <= 512, neq <= n");
+    DenseArgs a{};
+    a.n = n; a.neq = neq; a.nin = nin; a.ldj = odd(n);
+    int o = 0;
+    auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; };
+    a.o_J = take(n * a.ldj);
+    a.o_R = take(n * (n + 3) / 2 + 2);
+    a.o_vec = take(V_COUNT * kSlot);
+    a.o_int = o;
+    o += kIntCount / 2 + 2;
+    const int lds_bytes = o * 8;
+    if (lds_bytes > 160 * 1024) return fail(h, WBCQP_ERR_UNSUPPORTED, "dense QP does not fit the 160 KiB LDS of one CU (n <= 96)");
+    a.max_iter = max_iter > 0 ? max_iter : 1000;
+    a.count = batch;
+    a.H = in->H; a.g = in->g; a.CE = in->CE; a.ce0 = in->ce0; a.CI = in->CI; a.ci0 = in->ci0;
+    a.x = out->x; a.objective = out->objective; a.status = out->status; a.iters = out->iters; a.n_active = out->n_active;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (lds_bytes > h->dense_max_lds) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_dense_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_dense_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        h->dense_max_lds = lds_bytes;
+    }
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (h->dtype == WBCQP_F64) hipLaunchKernelGGL(solve_dense_kernel<double>, dim3(batch), dim3(kThreads), lds_bytes, hs, a);
+    else hipLaunchKernelGGL(solve_dense_kernel<float>, dim3(batch), dim3(kThreads), lds_bytes, hs, a);
+    HIP_TRY(h, hipGetLastError());
+    return WBCQP_OK;
+}
+
+int wbcqp_solve_dense_host(wbcqp_handle* h, int batch, int n, int neq, int nin, int max_iter, const wbcqp_dense_inputs* in,
+                           const wbcqp_dense_output** result)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (!in || !result) return fail(h, WBCQP_ERR_INVALID, "inputs / result is NULL");
+    if (batch <= 0 || n <= 0 || neq < 0 || nin < 0) return fail(h, WBCQP_ERR_INVALID, "bad batch / n / neq / nin");
+    *result = nullptr;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool f32 = h->dtype != WBCQP_F64;
+    const size_t es = f32 ? 4 : 8;
+    const size_t B = (size_t)batch;
+    const size_t lens[6] = {(size_t)n * n, (size_t)n, (size_t)neq * n, (size_t)neq, (size_t)nin * n, (size_t)nin};
+    const void* src[6] = {in->H, in->g, in->CE, in->ce0, in->CI, in->ci0};
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t offs[6], in_bytes = 0;
+    for (int f = 0; f < 6; ++f) { offs[f] = in_bytes; in_bytes += al(lens[f] * B * es); }
+    int rc = ensure(h, h->stage_in, in_bytes + 256);
+    if (rc != WBCQP_OK) return rc;
+    const size_t o_x = 0, o_obj = al((size_t)n * B * es), o_st = o_obj + al(B * es), o_it = o_st + al(B * 4), o_na = o_it + al(B * 4);
+    rc = ensure(h, h->stage_out, o_na + al(B * 4) + 256);
+    if (rc != WBCQP_OK) return rc;
+    char* din = static_cast<char*>(h->stage_in.dev);
+    char* dout = static_cast<char*>(h->stage_out.dev);
+    std::vector<float> tmp;
+    for (int f = 0; f < 6; ++f) {
+        if (lens[f] == 0) continue;
+        if (!src[f]) return fail(h, WBCQP_ERR_INVALID, "dense QP: a required input array is NULL");
+        if (f32) { // the caller's arrays are double (Eigen); an F32 handle carries float at the device boundary
+            tmp.resize(lens[f] * B);
+            const double* sd = static_cast<const double*>(src[f]);
+            for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (float)sd[i];
+            HIP_TRY(h, hipMemcpy(din + offs[f], tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+        }
+        else HIP_TRY(h, hipMemcpyAsync(din + offs[f], src[f], lens[f] * B * 8, hipMemcpyHostToDevice, nullptr));
+    }
+    wbcqp_dense_inputs di = {din + offs[0], din + offs[1], neq ? din + offs[2] : nullptr, neq ? din + offs[3] : nullptr,
+                             nin ? din + offs[4] : nullptr, nin ? din + offs[5] : nullptr};
+    wbcqp_outputs dso{};
+    dso.x = dout + o_x; dso.objective = dout + o_obj;
+    dso.status = reinterpret_cast<int32_t*>(dout + o_st); dso.iters = reinterpret_cast<int32_t*>(dout + o_it);
+    dso.n_active = reinterpret_cast<int32_t*>(dout + o_na);
+    rc = wbcqp_solve_dense(h, batch, n, neq, nin, max_iter, &di, &dso, nullptr);
+    if (rc != WBCQP_OK) return rc;
+    h->dense_x.assign((size_t)n * B, 0.0);
+    h->dense_obj.assign(B, 0.0);
+    h->dense_status.assign(B, WBCQP_HQP_UNKNOWN);
+    h->dense_iters.assign(B, 0);
+    h->dense_nact.assign(B, 0);
+    if (f32) {
+        std::vector<float> xf((size_t)n * B), of(B);
+        HIP_TRY(h, hipMemcpy(xf.data(), dso.x, xf.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(of.data(), dso.objective, B * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < xf.size(); ++i) h->dense_x[i] = xf[i];
+        for (size_t i = 0; i < B; ++i) h->dense_obj[i] = of[i];
+    }
+    else {
+        HIP_TRY(h, hipMemcpy(h->dense_x.data(), dso.x, (size_t)n * B * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(h->dense_obj.data(), dso.objective, B * 8, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(h, hipMemcpy(h->dense_status.data(), dso.status, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(h->dense_iters.data(), dso.iters, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(h->dense_nact.data(), dso.n_active, B * 4, hipMemcpyDeviceToHost));
+    h->dense_out = {batch, n, h->dense_x.data(), h->dense_status.data(), h->dense_iters.data(), h->dense_obj.data(), h->dense_nact.data()};
+    *result = &h->dense_out;
     return WBCQP_OK;
 }
 

@@ -1,0 +1,337 @@
+// wbcqp_dense.hpp -- the NARROW seam of the drop-in boundary: a dense QP the way tsid's
+// SolverHQuadProgFast hands it to eiquadprog (controller.cpp:247 -> solver_->solve(HQPData); pos_tracker.cpp:102
+// solver_->resize(nVar, nEq, nIn)):
+//        min 1/2 x'Hx + g'x   s.t.  CE x + ce0 = 0,  CI x + ci0 >= 0          (eiquadprog's convention)
+// with H, CE, CI dense and of ANY structure -- no task stack behind it.  One workgroup per QP, J / R / the vectors in LDS,
+// H only while it is factorised, CE and CI read row by row from HBM / L2.  This is the compatibility path for a caller that
+// owns its own HQPData (a tsid SolverHQPBase subclass); the batched structured path
+// (wbcqp_solve_batch) is the fast one and the one bench.py times.  Same Goldfarb-Idnani steps, status map and stopping rule as
+// solve_one; equalities are added one by one (eiquadprog's own order), add_constraint in its one-reflector form.
+#pragma once
+
+#include "wbcqp_prims.hpp"
+#include "wbcqp_activeset.hpp"
+
+namespace wbcqp {
+#ifdef __HIPCC__
+
+struct DenseArgs {
+    int n, neq, nin;            // nin = rows of CI as eiquadprog sees them (tsid: 2 x nIn two-sided rows)
+    int ldj;                    // odd
+    int o_J, o_R, o_vec, o_int; // LDS layout (doubles)
+    int max_iter;
+    int count;
+    const void *H, *g, *CE, *ce0, *CI, *ci0; // [count][...] row-major, the handle's dtype
+    void *x, *objective;
+    int *status, *iters, *n_active;
+};
+
+constexpr int kDenseMaxVars = 126, kDenseMaxIneq = 512;
+
+template <typename TI>
+__global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a)
+{
+    extern __shared__ __align__(16) double lds[];
+    const int tid = threadIdx.x;
+    const size_t qp = blockIdx.x;
+    const int n = a.n, neq = a.neq, nin = a.nin, ldj = a.ldj;
+    Ctx c;
+    c.S = nullptr;
+    c.tid = tid;
+    c.lane = tid & (kWave - 1);
+    c.wave = uni(tid >> 6);
+    c.rslot = 0;
+    c.nv = n; c.na = 0; c.nc = 0; c.k = 0; c.n = n; c.nu = 0; c.neq = neq; c.nin2 = nin; c.ldj = ldj; c.ldm = 0; c.ldc = 0; c.ldb = 0;
+    c.J = lds + a.o_J; c.R = lds + a.o_R;
+    c.M = c.Jc = c.Ac = nullptr;
+    {
+        double* vec = lds + a.o_vec;
+        c.h = vec + V_H * kSlot; c.x = vec + V_X * kSlot; c.np = vec + V_NP * kSlot; c.d = vec + V_D * kSlot;
+        c.z = vec + V_Z * kSlot; c.xold = vec + V_XOLD * kSlot; c.r = vec + V_R * kSlot; c.u = vec + V_U * kSlot;
+        c.uold = vec + V_UOLD * kSlot; c.q = vec + V_Q * kSlot; c.g = vec + V_G * kSlot; c.w = vec + V_W * kSlot;
+        c.wrow = vec + V_WROW * kSlot; c.blb = vec + V_BLB * kSlot; c.bub = vec + V_BUB * kSlot; c.tl = vec + V_TL * kSlot;
+        c.tu = vec + V_TU * kSlot; c.bc = vec + V_BC * kSlot; c.rdinv = vec + V_RDINV * kSlot; c.dinv = vec + V_DINV * kSlot;
+        c.red = vec + V_RED * kSlot; c.prm = vec + V_PRM * kSlot; c.b1 = vec + V_B1 * kSlot; c.s = vec + V_S * kSlot;
+        c.stash = vec + V_STASH * kSlot; c.part = vec + V_PART * kSlot;
+    }
+    c.eqw = c.eqt = nullptr;
+    int* ia = reinterpret_cast<int*>(lds + a.o_int);
+    c.A = ia + kIntA; c.Aold = ia + kIntAold; c.gskip = ia + kIntGskip; c.iai = ia + kIntIai; c.iaexcl = ia + kIntIaexcl;
+    c.meta = ia + kIntMeta;
+    c.iq = 0;
+    c.R_norm = 1.0;
+    const TI* H = static_cast<const TI*>(a.H) + qp * (size_t)n * n;
+    const TI* g = static_cast<const TI*>(a.g) + qp * (size_t)n;
+    const TI* CE = static_cast<const TI*>(a.CE) + qp * (size_t)neq * n;
+    const TI* ce0 = static_cast<const TI*>(a.ce0) + qp * (size_t)neq;
+    const TI* CI = static_cast<const TI*>(a.CI) + qp * (size_t)nin * n;
+    const TI* ci0 = static_cast<const TI*>(a.ci0) + qp * (size_t)nin;
+    const double eps = 2.220446049250313e-16;
+    const double inf = __builtin_huge_val();
+
+    // ---- H (lower triangle is read) into the J region, g; c1 = tr H
+    double tr = 0.0;
+    for (int e = tid; e < n * n; e += kThreads) {
+        const int i = e / n, j = e - i * n;
+        const double v = (double)H[e];
+        if (j <= i) c.J[i * ldj + j] = v;
+        if (i == j) tr += v;
+    }
+    for (int i = tid; i < n; i += kThreads) c.g[i] = (double)g[i];
+    const double c1 = block_sum(c, tr);
+    // ---- Cholesky H = L L' in place (right-looking, one column per step; Eigen LLT).  A non-positive pivot gives NaN,
+    //      which propagates like Eigen's LLT on a matrix that is not SPD
+    for (int j = 0; j < n; ++j) {
+        const double ljj = sqrt(c.J[j * ldj + j]);
+        bsync();
+        for (int i = j + tid; i < n; i += kThreads) c.J[i * ldj + j] = (i == j) ? ljj : c.J[i * ldj + j] / ljj;
+        bsync();
+        // trailing update: A(i, k) -= L(i, j) L(k, j), j < k <= i
+        const int m = n - j - 1;
+        for (int e = tid; e < m * m; e += kThreads) {
+            const int i = j + 1 + e / m, k = j + 1 + e % m;
+            if (k <= i) c.J[i * ldj + k] = fma(-c.J[i * ldj + j], c.J[k * ldj + j], c.J[i * ldj + k]);
+        }
+        bsync();
+    }
+    // ---- x = -H^-1 g through L: L y = g (forward), L' x = y (backward); one wave, lanes hold y / x entries
+    if (c.wave == 0) {
+        double y0 = (c.lane < n) ? c.g[c.lane] : 0.0, y1 = (c.lane + kWave < n) ? c.g[c.lane + kWave] : 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double yj = ((j < kWave) ? bcast_lane(y0, j) : bcast_lane(y1, j - kWave)) / c.J[j * ldj + j];
+            if (c.lane == j) y0 = yj;
+            if (c.lane + kWave == j) y1 = yj;
+            if (c.lane > j && c.lane < n) y0 = fma(-yj, c.J[c.lane * ldj + j], y0);
+            if (c.lane + kWave > j && c.lane + kWave < n) y1 = fma(-yj, c.J[(c.lane + kWave) * ldj + j], y1);
+        }
+        for (int j = n - 1; j >= 0; --j) {
+            const double xj = ((j < kWave) ? bcast_lane(y0, j) : bcast_lane(y1, j - kWave)) / c.J[j * ldj + j];
+            if (c.lane == j) y0 = xj;
+            if (c.lane + kWave == j) y1 = xj;
+            if (c.lane < j) y0 = fma(-xj, c.J[j * ldj + c.lane], y0);
+            if (c.lane + kWave < j) y1 = fma(-xj, c.J[j * ldj + c.lane + kWave], y1);
+        }
+        if (c.lane < n) c.x[c.lane] = -y0;
+        if (c.lane + kWave < n) c.x[c.lane + kWave] = -y1;
+    }
+    bsync();
+    double part = 0.0;
+    if (tid < n) part = 0.5 * c.g[tid] * c.x[tid];
+    double f_value = block_sum(c, part);
+    // ---- J = L^-T (upper triangular): column q of J solves L' J(:, q) = e_q; thread per column, rows q .. 0.
+    //      L is read from the lower triangle, J lands in a second array (the R region is too small: use part of it plus ...)
+    //      -> done in place column by column is impossible (J overwrites L): stage L^-T through the vector area is too small
+    //      too, so the inverse is formed into the UPPER triangle while L stays in the lower one; the diagonal of L moves to dinv.
+    if (tid < n) c.dinv[tid] = 1.0 / c.J[tid * ldj + tid];
+    bsync();
+    if (tid < n) {
+        // U = L' is upper triangular; X = U^-1 is upper triangular with X(q,q) = 1 / L(q,q) and, for i < q,
+        // X(i,q) = -(sum_{p=i+1..q} U(i,p) X(p,q)) / U(i,i) = -(sum_p L(p,i) X(p,q)) dinv[i].  Column q belongs to thread q: it
+        // reads L from the lower triangle (never written here) and writes only its own column above the diagonal.
+        const int q = tid;
+        for (int i = q - 1; i >= 0; --i) {
+            double acc = c.J[q * ldj + i] * c.dinv[q]; // p = q: L(q,i) X(q,q)
+            for (int p = i + 1; p < q; ++p) acc = fma(c.J[p * ldj + i], c.J[p * ldj + q], acc);
+            c.J[i * ldj + q] = -acc * c.dinv[i];
+        }
+    }
+    bsync();
+    // lower triangle := 0, diagonal := 1 / L(q,q): J = L^-T complete
+    double tr2 = 0.0;
+    for (int e = tid; e < n * n; e += kThreads) {
+        const int i = e / n, j = e - i * n;
+        if (j < i) c.J[i * ldj + j] = 0.0;
+        else if (i == j) {
+            c.J[i * ldj + i] = c.dinv[i];
+            tr2 += c.dinv[i];
+        }
+    }
+    const double c2 = block_sum(c, tr2);
+    for (int i = tid; i < n + 2; i += kThreads) {
+        c.u[i] = 0.0;
+        c.A[i] = 0;
+    }
+    bsync();
+
+    int status = -2, iter = 0;
+    // ---- equalities, one by one (eiquadprog's order)
+    for (int i = 0; i < neq && status == -2; ++i) {
+        if (tid < n) c.np[tid] = (double)CE[(size_t)i * n + tid];
+        const double ce = (double)ce0[i];
+        bsync();
+        compute_d(c, 0, n);
+        update_z_r(c, 0);
+        double zz = 0.0, znp = 0.0, npx = 0.0, dn2 = 0.0;
+        if (tid < n) {
+            const double zv = c.z[tid], nv_ = c.np[tid];
+            zz = zv * zv;
+            if (tid >= c.iq) dn2 = c.d[tid] * c.d[tid];
+            znp = zv * nv_;
+            npx = nv_ * c.x[tid];
+        }
+        block_sum4(c, zz, znp, npx, dn2);
+        double t2 = 0.0;
+        if (fabs(zz) > eps) t2 = (-npx - ce) / znp;
+        const int iq = c.iq;
+        if (tid < n) c.x[tid] = fma(t2, c.z[tid], c.x[tid]);
+        if (tid >= 128 && tid - 128 < iq) c.u[tid - 128] = fma(-t2, c.r[tid - 128], c.u[tid - 128]);
+        if (tid == kThreads - 1) {
+            c.u[iq] = t2;
+            c.A[i] = -i - 1;
+        }
+        f_value += 0.5 * (t2 * t2) * znp;
+        if (!add_constraint_hh(c, dn2)) status = HQP_ERROR; // redundant equalities
+    }
+    // ---- inequalities
+    if (status == -2) {
+        for (int i = tid; i < nin; i += kThreads) c.iai[i] = i;
+        bsync();
+        const double psi_tol = (double)nin * eps * c1 * c2 * 100.0;
+        bool redo_l2 = false;
+        while (status == -2) {
+            ValIdx best{0.0, 0x7fffffff};
+            if (!redo_l2) {
+                ++iter;
+                if (iter >= a.max_iter) {
+                    status = HQP_MAX_ITER;
+                    break;
+                }
+                for (int i = tid; i < c.iq; i += kThreads) {
+                    c.uold[i] = c.u[i];
+                    c.Aold[i] = c.A[i];
+                }
+                for (int i = tid; i < n; i += kThreads) c.xold[i] = c.x[i];
+                double psi = 0.0;
+                for (int i = tid; i < nin; i += kThreads) {
+                    const TI* row = CI + (size_t)i * n;
+                    double s0 = 0.0, s1 = 0.0;
+                    int j = 0;
+                    for (; j + 2 <= n; j += 2) {
+                        s0 = fma((double)row[j], c.x[j], s0);
+                        s1 = fma((double)row[j + 1], c.x[j + 1], s1);
+                    }
+                    if (j < n) s0 = fma((double)row[j], c.x[j], s0);
+                    const double v = (s0 + s1) + (double)ci0[i];
+                    c.s[i] = v;
+                    c.iaexcl[i] = 1;
+                    psi += fmin(0.0, v);
+                    if (v < 0.0 && c.iai[i] != -1) best = vi_min(best, ValIdx{v, i});
+                }
+                psi = block_sum(c, psi);
+                best = block_argmin(c, best);
+                if (fabs(psi) <= psi_tol) {
+                    status = HQP_OPTIMAL;
+                    break;
+                }
+            }
+            else {
+                for (int i = tid; i < nin; i += kThreads) {
+                    const double sv = c.s[i];
+                    if (sv < 0.0 && c.iai[i] != -1 && c.iaexcl[i]) best = vi_min(best, ValIdx{sv, i});
+                }
+                best = block_argmin(c, best);
+                redo_l2 = false;
+            }
+            if (best.v >= 0.0) {
+                status = HQP_OPTIMAL;
+                break;
+            }
+            const int ip = best.i;
+            if (tid < n) c.np[tid] = (double)CI[(size_t)ip * n + tid];
+            if (tid == kThreads - 1) {
+                c.u[c.iq] = 0.0;
+                c.A[c.iq] = ip;
+            }
+            bsync();
+            while (true) {
+                const int iq = c.iq;
+                compute_d(c, 0, n);
+                update_z_r(c, neq);
+                double zz = 0.0, znp = 0.0, dn2 = 0.0, dummy = 0.0;
+                if (tid < n) {
+                    const double zv = c.z[tid];
+                    zz = zv * zv;
+                    znp = zv * c.np[tid];
+                    if (tid >= iq) dn2 = c.d[tid] * c.d[tid];
+                }
+                block_sum4(c, zz, znp, dn2, dummy);
+                ValIdx bt{inf, 0x7fffffff};
+                for (int kk = neq + tid; kk < iq; kk += kThreads) {
+                    const double rk = c.r[kk];
+                    if (rk > 0.0) bt = vi_min(bt, ValIdx{c.u[kk] / rk, kk});
+                }
+                bt = block_argmin(c, bt);
+                const double t1 = bt.v;
+                const int l = (t1 < inf) ? c.A[bt.i] : 0;
+                const double sip = c.s[ip], uiq = c.u[iq];
+                const double t2 = (fabs(zz) > eps) ? (-sip / znp) : inf;
+                const double t = fmin(t1, t2);
+                if (t >= inf) {
+                    status = HQP_INFEASIBLE; // eiquadprog UNBOUNDED (dual) -> tsid INFEASIBLE
+                    break;
+                }
+                bsync(); // everyone has read s[ip], u[iq], A[.] before they change
+                if (t2 >= inf) {
+                    for (int j = neq + tid; j < iq; j += kThreads) c.u[j] = fma(-t, c.r[j], c.u[j]);
+                    if (tid == kThreads - 1) {
+                        c.u[iq] = uiq + t;
+                        c.iai[l] = l;
+                    }
+                    bsync();
+                    delete_constraint(c, l);
+                    continue;
+                }
+                f_value += t * znp * (0.5 * t + uiq);
+                if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
+                if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                if (tid == kThreads - 1) c.u[iq] = uiq + t;
+                if (t == t2) {
+                    bsync();
+                    if (add_constraint_hh(c, dn2)) {
+                        if (tid == 0) c.iai[ip] = -1;
+                        bsync();
+                    }
+                    else {
+                        if (tid == 0) c.iaexcl[ip] = 0;
+                        bsync();
+                        delete_constraint(c, ip);
+                        for (int i = tid; i < nin; i += kThreads) c.iai[i] = i;
+                        bsync();
+                        for (int i = tid; i < c.iq; i += kThreads) {
+                            const int av = c.Aold[i];
+                            c.A[i] = av;
+                            if (av >= 0) c.iai[av] = -1;
+                            c.u[i] = c.uold[i];
+                        }
+                        for (int i = tid; i < n; i += kThreads) c.x[i] = c.xold[i];
+                        bsync();
+                        redo_l2 = true;
+                    }
+                    break;
+                }
+                if (tid == 0) c.iai[l] = l;
+                bsync();
+                delete_constraint(c, l);
+                {
+                    double p2 = 0.0;
+                    if (tid < n) p2 = c.np[tid] * c.x[tid];
+                    p2 = block_sum(c, p2);
+                    if (tid == 0) c.s[ip] = p2 + (double)ci0[ip];
+                    bsync();
+                }
+            }
+        }
+    }
+    bsync();
+    TI* xo = static_cast<TI*>(a.x) + qp * (size_t)n;
+    for (int i = tid; i < n; i += kThreads) xo[i] = (TI)c.x[i];
+    if (tid == 0) {
+        a.status[qp] = status;
+        a.iters[qp] = iter;
+        if (a.objective) static_cast<TI*>(a.objective)[qp] = (TI)f_value;
+        if (a.n_active) a.n_active[qp] = c.iq;
+    }
+}
+
+#endif // __HIPCC__
+} // namespace wbcqp

@@ -1,0 +1,79 @@
+"""The narrow seam of SURVEY 8(b): `wbcqp_solve_dense_host` = what stands behind solver_->resize(nVar, nEq, nIn)
+(pos_tracker.cpp:102) / solver_->solve(HQPData) (controller.cpp:247) once tsid has stacked the HQPData into
+(H, g, CE, ce0, CI, ci0) -- checked against the oracle's eiquadprog-fast restatement (`wbco_eiquadprog_fast`) on the dense
+matrices the oracle's own assembly produces for the shipped stacks, on random dense QPs, and on the failure statuses."""
+import numpy as np
+import pytest
+
+from inria_wbc_amd import capi, structure, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense(oracle_mod, st, inputs, idx):
+    H, g, CE, ce0, CI, ci0 = oracle_mod.assemble(st, inputs, idx)
+    return [np.ascontiguousarray(a) for a in (H, g, CE, ce0, CI, ci0)]
+
+
+@pytest.mark.parametrize("robot,noise", [("talos", 0.5), ("talos", 3.0), ("icub", 1.0), ("franka", 0.5), ("tiago", 2.0), ("talos_single_support", 2.0)])
+def test_dense_seam_matches_eiquadprog_on_assembled_stacks(oracle_mod, robot, noise):
+    st = structure.STRUCTURES[robot]()
+    B = 6
+    inputs = synth.generate(st, B, synth.SEED_BASE[robot] + 4242, task_noise=noise)
+    qps = [_dense(oracle_mod, st, inputs, i) for i in range(B)]
+    stack = lambda j: np.stack([q[j] for q in qps])
+    h = capi.Handle(0, capi.F64)
+    got = h.solve_dense_host(stack(0), stack(1), stack(2), stack(3), stack(4), stack(5))
+    status_map = {0: 0, 1: 1, 2: 1, 3: 3, 4: 4}  # eiquadprog status -> tsid: UNBOUNDED (2) -> INFEASIBLE, REDUNDANT (4) -> ERROR
+    same_iters = 0
+    for i, (H, g, CE, ce0, CI, ci0) in enumerate(qps):
+        ref = oracle_mod.eiquadprog(H, g, CE, ce0, CI, ci0)
+        assert got["status"][i] == status_map[ref["status"]], (i, got["status"][i], ref["status"])
+        # one reflector instead of a Givens chain: the same subspaces, other rounding -- near-ties may be taken in another order
+        assert abs(int(got["iters"][i]) - ref["iters"]) <= 2, (i, got["iters"][i], ref["iters"])
+        same_iters += int(got["iters"][i] == ref["iters"])
+        assert np.abs(got["x"][i] - ref["x"]).max() <= 1e-8 * max(1.0, np.abs(ref["x"]).max())
+        assert abs(got["objective"][i] - ref["fval"]) <= 1e-7 * max(1.0, abs(ref["fval"]))
+        assert got["n_active"][i] == ref["iq"]
+    assert same_iters >= (2 * B) // 3
+    # the structured batched path solves the same QPs: the two seams agree
+    h.set_structure(0, st)
+    fast = h.solve_batch_host(0, inputs)
+    assert np.array_equal(fast["status"], got["status"])
+    assert np.abs(fast["x"] - got["x"]).max() <= 1e-8 * max(1.0, np.abs(got["x"]).max())
+    h.close()
+
+
+def test_dense_seam_on_random_qps_and_failure_statuses(oracle_mod):
+    rng = np.random.default_rng(3)
+    h = capi.Handle(0, capi.F64)
+    for n, neq, nin in ((5, 0, 0), (12, 3, 0), (20, 0, 30), (33, 7, 41), (64, 10, 100), (96, 12, 200)):
+        G = rng.standard_normal((n, n))
+        H = G @ G.T + 0.5 * np.eye(n)
+        g = rng.standard_normal(n)
+        xs = rng.standard_normal(n)
+        CE = rng.standard_normal((neq, n)); ce0 = -(CE @ xs)
+        CI = rng.standard_normal((nin, n)); ci0 = -(CI @ xs) + rng.uniform(0.0, 1.0, nin)  # xs is feasible
+        ref = oracle_mod.eiquadprog(H, g, CE, ce0, CI, ci0)
+        got = h.solve_dense_host(H, g, CE, ce0, CI, ci0)
+        assert ref["status"] == 0 and got["status"][0] == 0, (n, neq, nin)
+        assert np.abs(got["x"][0] - ref["x"]).max() <= 1e-8 * max(1.0, np.abs(ref["x"]).max()), (n, neq, nin)
+        assert abs(int(got["iters"][0]) - ref["iters"]) <= 2
+    # infeasible: x_0 >= 1 and x_0 <= -1
+    n = 8
+    H = np.eye(n); g = np.zeros(n)
+    CI = np.zeros((2, n)); CI[0, 0] = 1.0; CI[1, 0] = -1.0
+    ci0 = np.array([-1.0, -1.0])
+    got = h.solve_dense_host(H, g, None, None, CI, ci0)
+    assert oracle_mod.eiquadprog(H, g, np.zeros((0, n)), np.zeros(0), CI, ci0)["status"] == 2 and got["status"][0] == 1  # eiquadprog UNBOUNDED (dual) -> tsid INFEASIBLE
+    # redundant equalities: the same row twice
+    CE = np.zeros((2, n)); CE[:, 1] = 1.0
+    got = h.solve_dense_host(H, g, CE, np.zeros(2), None, None)
+    assert got["status"][0] == 4  # tsid ERROR
+    # the HQPOutput is owned by the handle: a second call replaces it, a copy taken before stays what it was
+    a = h.solve_dense_host(np.eye(3), np.array([1.0, 2.0, 3.0]), None, None, None, None)
+    b = h.solve_dense_host(np.eye(3), np.array([-1.0, 0.0, 0.0]), None, None, None, None)
+    assert np.allclose(a["x"][0], [-1.0, -2.0, -3.0]) and np.allclose(b["x"][0], [1.0, 0.0, 0.0])
+    with pytest.raises(capi.WbcqpError):
+        h.solve_dense_host(np.eye(120), np.zeros(120), None, None, None, None)  # does not fit one CU's LDS
+    h.close()

@@ -112,7 +112,7 @@ def test_packer_refuses_a_dump_that_is_not_the_structure(tmp_path, oracle_mod):
     # a friction block that differs from the structure's (another mu) is caught by name
     d = os.path.join(str(tmp_path), "tick00000")
     f = [p for p in os.listdir(d) if "contact0_force_A" in p][0]
-    A = np.load(os.path.join(d, f)); A[0, st.nv] *= 1.5; np.save(os.path.join(d, f), A)
+    A = np.load(os.path.join(d, f)); A[0, st.nv + 2] *= 1.5; np.save(os.path.join(d, f), A)
     with pytest.raises(prv.PackError, match="friction block"):
         prv.pack(str(tmp_path), st)
 
