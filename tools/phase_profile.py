@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--model", action="store_true", help="rows from the Talos-like model (wbcqp_problem_data) instead of the synthetic generator")
     ap.add_argument("--qnoise", type=float, default=0.01)
     ap.add_argument("--flags", type=int, default=0, help="wbcqp_desc.flags (16: the full LDS layout of round 1)")
+    ap.add_argument("--first", type=int, default=0, help="index of the first instance in the seeded stream (with --squat: its tick)")
     ap.add_argument("--squat", action="store_true", help="CoM rows follow the squat stream (bench.py's workload): heavier tail")
     args = ap.parse_args()
     import torch
@@ -55,7 +56,7 @@ def main():
         d_in["tub"] = torch.from_numpy(np.tile(m.tau_max, (B, 1))).to(dev)
         d_in["w"] = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev)
     else:
-        inputs = synth.generate(st, B, synth.SEED_BASE[args.robot], task_noise=args.noise, squat=args.squat)
+        inputs = synth.generate(st, B, synth.SEED_BASE[args.robot], first=args.first, task_noise=args.noise, squat=args.squat)
         d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
     d_out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
                  status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
@@ -98,6 +99,8 @@ def main():
     print("  fit: %.0f + %.0f per iteration" % (fit[0], fit[1]))
     by_it = [float(tot[iters == k].mean()) if (iters == k).any() else 0.0 for k in range(1, 13)]
     print("  mean cycles by iteration count 1..12:", [int(v) for v in by_it])
+    worst = int(np.argmax(iters))
+    print("  the longest QP: %d iterations, %.0f cycles:" % (iters[worst], tot[worst]), {NAMES[i]: int(t[worst, i]) for i in range(len(NAMES)) if t[worst, i] > 0})
     if args.out:
         with open(args.out, "w") as fh:
             json.dump({"robot": args.robot, "batch": B, "noise": args.noise, "iters_mean": float(iters.mean()),
