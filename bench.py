@@ -384,7 +384,9 @@ def main():
                          "algorithmic_bytes_per_qp": abytes},
             "active_set": {"iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
                            "iters_hist": np.bincount(np.minimum(iters, 15), minlength=16).tolist(),
-                           "status_optimal": int((status == 0).sum()), "batch": int(B)},
+                           "status_optimal": int((status == 0).sum()), "batch": int(B),
+                           "note": "a launch cannot end before its longest QP does: with 512 resident workgroups a 1024-QP launch of this stream is "
+                                   "bounded by the one QP that takes iters_max iterations (DESIGN.md section 4, stragglers)"},
         }
         flops = st.flops_estimate(float(iters.mean()))
         result["fp64"] = {"flops_per_qp": flops, "achieved_TFLOPs": flops * B / kern_avg_s / 1e12,
@@ -437,7 +439,12 @@ def main():
                 return r
 
             Q, HW = capi.FLAG_QUEUE, capi.FLAG_HW_DISPATCH
-            result["replayed_batch"] = variant(base_flags, "the same batch every step: the order comes from the very QPs it schedules (round 1's headline; an upper bound)", replay=True)
+            result["replayed_batch"] = variant(base_flags, "tick 0 of the stream every step: the order comes from the very QPs it schedules (perfect foresight; an upper bound)", replay=True)
+            if stream:  # round 1's workload, unchanged: SURVEY config 2's generator without the squat reference, replayed
+                plain = [{k: v for k, v in d_in.items()}]
+                result["config2_replayed"] = variant(base_flags, "SURVEY 8(d) config 2 exactly as round 1 timed it (no CoM reference stream, the same batch every step; round 1: 3.46 M QP/s): "
+                                                                 "mean 3.8 iterations, longest QP 21 -- the tick stream's longest QP takes 40 and bounds a 1024-QP launch", fresh=plain)
+                result["config2_replayed"]["frac_hbm"] = abytes * result["config2_replayed"]["value"] / 1e9 / HBM_PEAK_GBS
             result["index_order"] = variant(capi.FLAG_INDEX_ORDER, "same stream, QPs taken in index order (no schedule at all)")
             result["hw_dispatch"] = variant(HW, "same stream, longest-first, one workgroup per QP dealt out by the hardware's dispatcher")
             result["queue_packed"] = variant(Q, "same stream, queue, bin-packed order where the launch is small enough (default at one workgroup per CU only)")

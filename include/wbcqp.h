@@ -150,17 +150,16 @@ typedef struct {
 #define WBCQP_FLAG_INDEX_ORDER 1 /* launch the QPs of a batch in index order.  Default (0): longest-first -- a launch is
                                     ordered by the active-set iteration counts of the previous launch of the same shape on
                                     the same stream (control ticks change little); results do not depend on the order */
-#define WBCQP_FLAG_HW_DISPATCH 2 /* one workgroup per QP, handed to the CUs by the hardware's dispatcher.  Default (0): as
-                                    many workgroups as the chip holds take QPs from a queue in the launch order when one
-                                    workgroup fills a CU (the
-                                    dispatcher binds workgroup i to one shader engine of XCD i % 8 and waits for it; the
-                                    queue does not); results do not depend on it */
-#define WBCQP_FLAG_QUEUE 8       /* the queue also for structures small enough that several workgroups share a CU (default: those
-                                    go through the hardware's dispatcher, which has slack there and no hand-over cost) */
-#define WBCQP_FLAG_NO_PACKING 4  /* keep the plain longest-first order for the queue.  Default (0): when a launch holds between
-                                    one and eight QPs per resident workgroup, the order is bin-packed from the predicted costs
-                                    (setup + iterations of the previous launch) so that the workgroups finish together */
-
+#define WBCQP_FLAG_HW_DISPATCH 2 /* one workgroup per QP, handed to the CUs by the hardware's dispatcher (the default for
+                                    structures whose workgroup is under 48 KB of LDS: Franka, Tiago).  Default (0) for the
+                                    humanoid stacks: as many workgroups as the chip holds (two per CU on the compact layout)
+                                    take QPs from a queue in the launch order (the dispatcher binds workgroup i to one shader
+                                    engine of XCD i % 8 and waits for it; the queue does not); results do not depend on it */
+#define WBCQP_FLAG_QUEUE 8       /* the queue also for small structures, and the bin-packed order also where two workgroups share
+                                    a CU (measured no better than longest-first there: tools/dispatch_sweep.py) */
+#define WBCQP_FLAG_NO_PACKING 4  /* keep the plain longest-first order for the queue.  Default (0): where one workgroup fills a
+                                    CU and a launch holds between one and eight QPs per resident workgroup, the order is
+                                    bin-packed from the predicted costs (setup + iterations of the previous launch) */
 #define WBCQP_FLAG_FULL_LDS 16    /* keep every structure on the layout that holds M, Jc and A_c in LDS for the QP's whole life
                                     (Talos: one QP per CU).  Default (0): structures within n <= 80, nEq <= 22, nv <= 52, two
                                     contacts (every stack the reference ships) use the compact layout -- half the LDS, two
