@@ -106,3 +106,23 @@ def test_ragged_shards_balance_cost_and_cover_every_qp():
     by_count = shard.shard_costs(groups, [[(0, 0, 3000), (1, 0, 596)], [(1, 596, 1000), (2, 0, 700), (3, 0, 2000), (4, 0, 492)]])
     assert by_count[1] > 50 * by_count[0]
     assert shard.contiguous_shards(8192, 8)[3] == (3072, 4096)
+
+
+def test_bench_refuses_a_rank_count_mismatch_and_needs_a_gpu(tmp_path):
+    """bench.py --gpus N: one process per GPU.  Without N ranks it says how to launch instead of quietly running on one GPU;
+    launched as the driver launches it (torch.distributed.run, two ranks) it gets as far as the first GPU call on this
+    GPU-less box and stops there with the product's own message (there is no CPU path to fall back to)."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stdout + r.stderr) and "--nproc-per-node 2" in (r.stdout + r.stderr)
+    if torch.cuda.is_available():
+        return  # on a GPU box the two-rank run is the driver's to make
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "bench.py needs an MI355X: the product path has no CPU fallback" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
