@@ -863,6 +863,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     const double* Jr = c.J + ir * ldj;
                     double zv = dsg * dot8(Jr, 1, dsrc, 1, ca, cb);
                     zv += dpp_get<0xB1>(zv);
+                    STAMP(18)
                     double zz = 0.0, znp = 0.0, dn2 = 0.0;
                     if (hf == 0 && idx < n) {
                         c.z[idx] = zv;
@@ -943,7 +944,10 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         tau = fast_rcp(fma(nx, fabs(diq), dn2));
                     }
                     const bool accepted = fabs(alpha) > eps * c.R_norm;
-                    const bool fused = accepted && !slow;
+                    // an accepted constraint never needs the snapshot of x again, whatever partial steps came before it: the
+                    // fused phase is taken then too (x_next goes into the buffer that held the snapshot)
+                    const bool fused = accepted;
+                    STAMP(20)
                     // w_k = tau (z_k - alpha J(k,iq)); J(:, iq) was stashed in phase B, so nobody waits for anybody here
                     if (reflect) {
                         if (!fused) {
@@ -979,6 +983,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         if (!slow && tid < n) c.xold[tid] = c.x[tid];
                         bsync();
                     }
+                    STAMP(21)
                     double* Rc = c.R + roff(iq);
                     for (int i = tid; i < iq; i += kThreads) Rc[i] = c.d[i];
                     if (fused) {
@@ -988,6 +993,10 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                             const double un = fma(-t, c.r[tid - 128], c.u[tid - 128]);
                             c.u[tid - 128] = un;
                             c.uold[tid - 128] = un;
+                        }
+                        if (slow && tid < iq) { // partial steps moved entries of A and u: the snapshot of the next pick is taken whole
+                            c.Aold[tid] = c.A[tid];
+                            if (tid < neq) c.uold[tid] = c.u[tid];
                         }
                         if (tid == kThreads - 1) {
                             Rc[iq] = alpha;
@@ -1000,6 +1009,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         double psi;
                         ValIdx nb;
                         eval_rows(c.x, c.z, t, ip, psi, nb);
+                        STAMP(23)
                         tact_valid = act_ineq;
                         publish_best(psi, nb);
                         c.iq = iq + 1;
