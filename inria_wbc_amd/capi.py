@@ -498,6 +498,21 @@ class Handle:
                     iters=np.ctypeslib.as_array(o.iters, shape=(B,)).copy(), objective=np.ctypeslib.as_array(o.objective, shape=(B,)).copy(),
                     n_active=np.ctypeslib.as_array(o.n_active, shape=(B,)).copy())
 
+    def solve_dense(self, n: int, neq: int, nin: int, inputs: Dict[str, "object"], outputs: Dict[str, "object"], max_iter: int = 0,
+                    stream: int = 0):
+        """Device-pointer form of the narrow seam (wbcqp_solve_dense): inputs H, g, CE, ce0, CI, ci0 and outputs x, status, iters
+        (objective, n_active optional) are device tensors of the handle's dtype, [batch, ...]."""
+        batch = inputs["g"].shape[0]
+        ptr = lambda t: t.data_ptr() if t is not None and t.numel() else None
+        din = CDenseInputs(*[ptr(inputs.get(k)) for k in ("H", "g", "CE", "ce0", "CI", "ci0")])
+        cout = COutputs()
+        for k in ("x", "tau", "status", "iters", "objective", "n_active"):
+            setattr(cout, k, ptr(outputs.get(k)))
+        self.lib.wbcqp_solve_dense.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(CDenseInputs),
+                                               C.POINTER(COutputs), C.c_void_p]
+        self._check(self.lib.wbcqp_solve_dense(self._h, int(batch), int(n), int(neq), int(nin), int(max_iter), C.byref(din), C.byref(cout),
+                                               C.c_void_p(stream)))
+
     def allgather_tau(self, comm: int, send_ptr: int, recv_ptr: int, count: int, stream: int = 0):
         self._check(self.lib.wbcqp_allgather_tau(self._h, C.c_void_p(comm), C.c_void_p(send_ptr), C.c_void_p(recv_ptr),
                                                  count, C.c_void_p(stream)))

@@ -77,3 +77,30 @@ def test_dense_seam_on_random_qps_and_failure_statuses(oracle_mod):
     with pytest.raises(capi.WbcqpError):
         h.solve_dense_host(np.eye(120), np.zeros(120), None, None, None, None)  # does not fit one CU's LDS
     h.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_dense_seam_device_pointers_and_f32_boundary(oracle_mod, dtype):
+    """wbcqp_solve_dense on device tensors, asynchronous on a stream; an F32 handle carries float arrays at the boundary and
+    solves in f64 (same rule as the structured path)."""
+    import torch
+    st = structure.icub_structure()
+    B = 5
+    inputs = synth.generate(st, B, synth.SEED_BASE["icub"] + 999, task_noise=1.0)
+    qps = [_dense(oracle_mod, st, inputs, i) for i in range(B)]
+    tdt, ndt, cdt = (torch.float64, np.float64, capi.F64) if dtype == "f64" else (torch.float32, np.float32, capi.F32)
+    dev = torch.device("cuda", 0)
+    names = ("H", "g", "CE", "ce0", "CI", "ci0")
+    host = {k: np.stack([q[j] for q in qps]).astype(ndt) for j, k in enumerate(names)}
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in host.items()}
+    d_out = dict(x=torch.zeros(B, st.n, dtype=tdt, device=dev), status=torch.full((B,), -99, dtype=torch.int32, device=dev),
+                 iters=torch.zeros(B, dtype=torch.int32, device=dev), objective=torch.zeros(B, dtype=tdt, device=dev))
+    h = capi.Handle(0, cdt)
+    h.solve_dense(st.n, st.neq, st.nin2, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    h.close()
+    tol = 1e-8 if dtype == "f64" else 1e-3
+    for i in range(B):
+        ref = oracle_mod.eiquadprog(*[host[k][i].astype(np.float64) for k in names])  # the oracle sees what the device saw
+        assert d_out["status"][i].item() == 0 and ref["status"] == 0
+        assert np.abs(d_out["x"][i].cpu().numpy().astype(np.float64) - ref["x"]).max() <= tol * max(1.0, np.abs(ref["x"]).max())
