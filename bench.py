@@ -445,6 +445,14 @@ def main():
                 result["config2_replayed"] = variant(base_flags, "SURVEY 8(d) config 2 exactly as round 1 timed it (no CoM reference stream, the same batch every step; round 1: 3.46 M QP/s): "
                                                                  "mean 3.8 iterations, longest QP 21 -- the tick stream's longest QP takes 40 and bounds a 1024-QP launch", fresh=plain)
                 result["config2_replayed"]["frac_hbm"] = abytes * result["config2_replayed"]["value"] / 1e9 / HBM_PEAK_GBS
+                try:  # the driver's own record of round 1, when it is in the tree
+                    with open(os.path.join(ROOT, "BENCH_r01.json")) as fh:
+                        r1 = json.load(fh).get("parsed", {}).get("value")
+                    if r1 and args.robot == "talos" and B == 1024 and not f32:
+                        result["config2_replayed"]["round1_value"] = r1
+                        result["config2_replayed"]["vs_round1"] = result["config2_replayed"]["value"] / r1
+                except Exception:  # noqa: BLE001
+                    pass
             result["index_order"] = variant(capi.FLAG_INDEX_ORDER, "same stream, QPs taken in index order (no schedule at all)")
             result["hw_dispatch"] = variant(HW, "same stream, longest-first, one workgroup per QP dealt out by the hardware's dispatcher")
             result["queue_packed"] = variant(Q, "same stream, queue, bin-packed order where the launch is small enough (default at one workgroup per CU only)")
