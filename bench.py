@@ -62,6 +62,9 @@ def parse():
     p.add_argument("--traffic", type=float, default=None,
                    help="HBM bytes per launch from rocprofv3 PMC passes (default: scaled from profiles/pmc_latest.json)")
     p.add_argument("--sweep", default=None, help="also write the batch 1..8192 table to this JSON file")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to\n"
+                   "exercise the N > 1 code path where RCCL cannot run, e.g. several ranks on one GPU)")
+    p.add_argument("--single-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
     return p.parse_args()
 
 
@@ -227,11 +230,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     from inria_wbc_amd import build, capi, structure, synth
     if rank == 0:
@@ -458,6 +466,34 @@ def main():
             result["queue_packed"] = variant(Q, "same stream, queue, bin-packed order where the launch is small enough (default at one workgroup per CU only)")
             result["refresh_every_launch"] = variant(base_flags | capi.flag_refresh(1), "same stream, order renewed after every launch (default: every 4th, WBCQP_FLAG_REFRESH)")
             result["full_lds_layout"] = variant(capi.FLAG_FULL_LDS, "same stream on round 1's layout: every array of the QP in LDS (Talos: one QP per CU), queue + packed order")
+            try:  # two INDEPENDENT fleets (two handles, two HIP streams, out of phase): their launches overlap on the chip, so one
+                # fleet's stragglers run beside the other's bulk.  Not `value`: consecutive ticks of ONE fleet cannot overlap.
+                s2 = torch.cuda.Stream()
+                ha, hb = capi.Handle(device=local_rank, dtype=cdt, flags=base_flags), capi.Handle(device=local_rank, dtype=cdt, flags=base_flags)
+                ha.set_structure(0, st)
+                hb.set_structure(0, st)
+                oa, ob = new_out(), new_out()
+                n2 = max(args.steps, 100)
+
+                def both(t):
+                    ha.solve_batch(0, B, tick_dicts[t % len(tick_dicts)], oa, stream=sp)
+                    hb.solve_batch(0, B, tick_dicts[(t + 64) % len(tick_dicts)], ob, stream=s2.cuda_stream)
+
+                s2.wait_stream(torch.cuda.current_stream())
+                for t in range(8):
+                    both(t)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for t in range(n2):
+                    both(8 + t)
+                torch.cuda.synchronize()
+                result["two_independent_fleets"] = {"value": 2 * B * n2 / (time.perf_counter() - t1), "unit": "QP/s",
+                                                    "note": "two fleets of %d robots on two HIP streams, 64 ticks out of phase: launches of different "
+                                                            "fleets overlap (the tail of one beside the bulk of the other)" % B}
+                ha.close()
+                hb.close()
+            except Exception as e:  # noqa: BLE001
+                result["two_independent_fleets"] = {"error": repr(e)}
             try:  # unrelated batches: every launch is scheduled from the counts of QPs that have nothing to do with it
                 fresh = []
                 for j in range(4):
