@@ -288,3 +288,110 @@ def test_diagnostic_build_is_a_canary(tmp_path):
         for k in ("status", "iters", "x", "tau"):
             assert np.array_equal(prod["%s_%d" % (k, rep)], prod["%s_0" % k]), ("product", k, rep)
             assert np.array_equal(diag["%s_%d" % (k, rep)], prod["%s_0" % k]), ("diagnostic", k, rep)
+
+
+def _equality_and_decode_residuals(st, inputs, got, stride):
+    """size-independent properties of a solved batch: the level-0 equalities hold, tau is the decode of x"""
+    nv, nu = st.nv, st.nu
+    T = st.force_gen()
+    iu = np.tril_indices(nv)
+    worst_eq = worst_tau = 0.0
+    B = inputs["h"].shape[0]
+    for i in range(0, B, stride):
+        M = np.zeros((nv, nv)); M[iu] = inputs["M"][i]; M = M + M.T - np.diag(np.diag(M))
+        Ac = inputs["Ac"][i].reshape(st.nc, 6, nv)
+        Jc = np.concatenate([T[c].T @ Ac[c] for c in range(st.nc)], 0)
+        x = got["x"][i].astype(np.float64); dv, f = x[:nv], x[nv:]
+        h = inputs["h"][i]
+        if nu:
+            worst_eq = max(worst_eq, np.abs(M[:nu] @ dv - Jc[:, :nu].T @ f + h[:nu]).max())
+        worst_eq = max(worst_eq, np.abs(np.einsum("crj,j->cr", Ac, dv).ravel() - inputs["bc"][i]).max())
+        tau = M[nu:] @ dv + h[nu:] - Jc[:, nu:].T @ f
+        worst_tau = max(worst_tau, np.abs(tau - got["tau"][i]).max())
+    return worst_eq, worst_tau
+
+
+def test_full_size_config3_icub_b4096_f32_boundary(built_lib, oracle_mod):
+    """BASELINE config 3 at full size (iCub, foot contacts, B = 4096, f32 arrays at the boundary, the solve in f64): every QP
+    optimal, the equalities and the torque decode hold at f32 resolution on a strided sample, and 64 QPs against the fp64
+    oracle fed the same f32-rounded inputs (1e-3 relative on ddq / tau)."""
+    from inria_wbc_amd import capi
+    st = structure.icub_structure()
+    B = 4096
+    inputs = synth.generate(st, B, synth.SEED_BASE["icub"], dtype=np.float32)
+    h = capi.Handle(0, capi.F32)
+    h.set_structure(0, st)
+    got = h.solve_batch_host(0, inputs)
+    h.close()
+    assert (got["status"] == 0).all()
+    in64 = {k: v.astype(np.float64) for k, v in inputs.items()}
+    worst_eq, worst_tau = _equality_and_decode_residuals(st, in64, got, 64)
+    scale = max(1.0, float(np.abs(got["tau"]).max()))
+    assert worst_eq < 2e-3 and worst_tau < 2e-5 * scale, (worst_eq, worst_tau, scale)  # outputs are rounded to f32
+    ref = oracle_mod.tick_batch(st, {k: v[:64] for k, v in in64.items()}, nthreads=4)
+    assert np.array_equal(got["status"][:64], ref["status"])
+    xs = np.maximum(1.0, np.abs(ref["x"][:, :st.nv]).max(axis=1, keepdims=True))
+    assert (np.abs(got["x"][:64, :st.nv] - ref["x"][:, :st.nv]) / xs).max() < 1e-3
+    assert np.abs(got["tau"][:64] - ref["tau"]).max() < 1e-3 * max(1.0, np.abs(ref["tau"]).max())
+    assert (got["iters"][:64] == ref["iters"]).mean() >= 0.9
+
+
+def test_full_size_config5_ragged_b8192(handle, oracle_mod):
+    """BASELINE config 5 at full size: 8192 QPs drawn uniformly over Franka / Tiago / iCub / Talos / Talos single support in ONE
+    launch; every QP optimal, a strided sample of every group satisfies its equalities and decode, 16 per group against the oracle."""
+    import torch
+    names = ["franka", "tiago", "icub", "talos", "talos_single_support"]
+    kinds = np.random.default_rng(5_000_000).integers(0, len(names), size=8192)
+    groups, metas = [], []
+    for slot, name in enumerate(names):
+        st = structure.STRUCTURES[name]()
+        cnt = int((kinds == slot).sum())
+        nb = min(cnt, 192)
+        inp = synth.generate(st, nb, synth.SEED_BASE["ragged"] + 20_000 * slot, task_noise=1.0)
+        reps = (cnt + nb - 1) // nb
+        full = {k: np.ascontiguousarray(np.tile(v, (reps, 1))[:cnt]) for k, v in inp.items()}
+        handle.set_structure(8 + slot, st)
+        d_in = {k: torch.from_numpy(v).cuda() for k, v in full.items() if v.size}
+        d_out = dict(x=torch.zeros(cnt, st.n, dtype=torch.float64, device="cuda"), tau=torch.zeros(cnt, max(st.na, 1), dtype=torch.float64, device="cuda"),
+                     status=torch.full((cnt,), -99, dtype=torch.int32, device="cuda"), iters=torch.zeros(cnt, dtype=torch.int32, device="cuda"))
+        groups.append((8 + slot, cnt, d_in, d_out))
+        metas.append((st, full, inp))
+    handle.solve_ragged(groups, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert sum(g[1] for g in groups) == 8192
+    for (st, full, inp), (_, cnt, _, d_out) in zip(metas, groups):
+        got = dict(x=d_out["x"].cpu().numpy(), tau=d_out["tau"].cpu().numpy()[:, :st.na], status=d_out["status"].cpu().numpy(),
+                   iters=d_out["iters"].cpu().numpy())
+        assert (got["status"] == 0).all(), st.name
+        if st.nc:
+            worst_eq, worst_tau = _equality_and_decode_residuals(st, full, got, 97)
+            assert worst_eq < 1e-6 and worst_tau < 1e-9, (st.name, worst_eq, worst_tau)
+        # the batch repeats its distinct QPs: a repeated QP gives the same bits wherever it sits in the launch
+        nb = inp["h"].shape[0]
+        if cnt > nb:
+            assert np.array_equal(got["x"][:cnt - nb], got["x"][nb:cnt]), st.name
+        ref = oracle_mod.tick_batch(st, {k: v[:16] for k, v in inp.items()}, nthreads=4)
+        assert_parity(st, {k: v[:16] for k, v in got.items()}, ref, what="ragged-8192:" + st.name)
+
+
+def test_full_size_config4_squat_b8192_on_one_gpu(handle, oracle_mod):
+    """BASELINE config 4's batch on one GPU (the 8-GPU sharding is tests/test_distributed.py's and the driver's): 8192 Talos QPs,
+    instance i on tick i mod 4000 of the squat stream.  The generator repeats after 512 distinct instances here (the CoM
+    reference does not): every QP optimal, equalities and decode on a strided sample, 24 QPs of the hard end against the oracle."""
+    st = structure.talos_structure()
+    B, nb = 8192, 512
+    base = synth.generate(st, nb, synth.SEED_BASE["talos_squat"])
+    inputs = {k: np.ascontiguousarray(np.tile(v, (B // nb, 1))) for k, v in base.items()}
+    rows = np.where(st.dense_row_task == st.task_names.index("com"))[0]
+    kp = st.kp.get("com", 30.0)
+    table = np.stack([synth.squat_com_rhs(st, t, kp) for t in range(4000)])
+    inputs["b1"][:, rows] += table[np.arange(B) % 4000][:, :rows.size]
+    handle.set_structure(5, st)
+    got = handle.solve_batch_host(5, inputs)
+    assert (got["status"] == 0).all()
+    worst_eq, worst_tau = _equality_and_decode_residuals(st, inputs, got, 61)
+    assert worst_eq < 1e-6 and worst_tau < 1e-9, (worst_eq, worst_tau)
+    hard = np.argsort(-got["iters"])[:24]
+    ref = oracle_mod.tick_batch(st, {k: v[hard] for k, v in inputs.items()}, nthreads=4)
+    assert_parity(st, {k: v[hard] for k, v in got.items()}, ref, what="squat-8192-hardest")
+    assert got["iters"].max() >= 30  # the stream's stragglers are in the sample
