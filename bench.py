@@ -55,6 +55,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-compare", action="store_true", help="skip the extra runs reported beside `value`")
     p.add_argument("--no-sweep", action="store_true", help="skip the batch 1..8192 table")
+    p.add_argument("--headline-only", action="store_true", help="the warm-up and the K timed steps and nothing else on the device (no comparison lines, no\n"
+                   "before/after-path sections, no CPU baseline): the command the rocprofv3 passes of tools/profile_round.sh trace, so that\n"
+                   "the kernel's average duration in the trace is the duration of the timed launches")
     p.add_argument("--index-order", action="store_true",
                    help="launch the QPs in index order instead of longest-first (WBCQP_FLAG_INDEX_ORDER)")
     p.add_argument("--flags", type=int, default=0, help="extra wbcqp_desc.flags for the headline handle")
@@ -219,6 +222,8 @@ def cpu_model():
 
 def main():
     args = parse()
+    if args.headline_only:
+        args.no_compare = args.no_sweep = args.no_cpu_baseline = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -403,7 +408,7 @@ def main():
         if gather["err"]:
             result["config"]["allgather_error"] = gather["err"]
 
-        if world == 1 and stream:
+        if world == 1 and stream and not args.headline_only:
             # how alike are consecutive ticks?  (the launch order is built on it)
             o1, o2 = new_out(), new_out()
             h.solve_batch(0, B, tick_dicts[5], o1, stream=sp)
@@ -503,7 +508,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result["unrelated_batches"] = {"error": repr(e)}
 
-        if world == 1 and args.robot == "talos" and not f32:
+        if world == 1 and args.robot == "talos" and not f32 and not args.headline_only:
             # after the path: state integration kernel on the solver's own output, outside `value`
             nvv, nq = st.nv, st.nv + 1
             gq = torch.zeros(B, nq, dtype=torch.float64, device=dev)

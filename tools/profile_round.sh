@@ -14,10 +14,10 @@ python3 tools/phase_profile.py --model > $OUT/phase_model.txt 2>&1
 python3 tools/terms_profile.py > $OUT/terms_phase.txt 2>&1
 python3 tools/tick_latency.py --reps 100 --out $OUT/tick_latency.json > $OUT/tick_latency.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-compare > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/sq -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-compare > $OUT/sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 200 --warmup 20 --headline-only > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 20 --warmup 4 --headline-only > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 20 --warmup 4 --headline-only > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/sq -- python3 $ROOT/bench.py --steps 20 --warmup 4 --headline-only > $OUT/sq.log 2>&1
 cd $OUT
 find ./sq -name "*counter_collection.csv" -exec cp {} $OUT/pmc_sq.csv \;
 find . -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
