@@ -154,3 +154,19 @@ def test_check_model_on_the_host(built_lib):
         assert text in str(e.value), (text, str(e.value))
     with pytest.raises(capi.WbcqpError):
         capi.check_model(structure.icub_structure(), m, tm)  # another robot's structure
+
+
+def test_bench_accepts_the_drivers_command_line_and_counts_usable_cores(monkeypatch):
+    """bench.py's host-side pieces that need no GPU: the driver's flag set parses to the documented defaults, and the CPU
+    baseline is sized by what the container grants (affinity mask / cgroup quota), not by os.cpu_count() alone."""
+    import importlib
+    import sys as _sys
+    _sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup, a.batch, a.robot, a.dtype) == (1, 20, 5, 1024, "talos", "f64")
+    assert not a.replay and not a.headline_only and a.backend == "nccl"
+    n, note = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1) and "os.cpu_count()" in note
+    assert bench.ALGORITHMIC_BYTES["talos"] == 35152  # SURVEY 8(d)
