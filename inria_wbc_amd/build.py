@@ -15,8 +15,9 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwbcqp.so")
 SOURCES = ["wbcqp_api.hip"]
-HEADERS = ["wbcqp_device.hpp", "wbcqp_types.hpp", "wbcqp_prims.hpp", "wbcqp_factor.hpp", "wbcqp_equality.hpp", "wbcqp_activeset.hpp",
-           "wbcqp_integrate.hpp", "wbcqp_terms.hpp", os.path.join("..", "..", "include", "wbcqp.h")]
+# every header under csrc/ (globbed: a hand-kept list once missed wbcqp_compact.hpp and wbcqp_dense.hpp, so an edit to the
+# default solve kernel did not trigger a rebuild) + the C ABI header
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "wbcqp.h")]
 ARCH = "gfx950"
 
 

@@ -209,7 +209,7 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
     D.compact = 0;
     const int n = F.n, nv = F.nv;
     if (!(n <= 80 && F.neq <= 22 && nv <= 52 && F.nc <= 2 && F.nu <= 8 && F.na <= 64 && F.n_bound <= 64 && F.nin2 <= 256 &&
-          F.r1 <= 128 && F.n_tasks <= 64 && (!F.act_bounds || F.act_off >= 0)))
+          F.r1 <= 128 && F.n_tasks <= 64 && (!F.act_bounds || F.act_off >= 0) && n - F.neq <= 64))
         return false;
     int o = 0;
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; };
@@ -220,6 +220,11 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
     D.o_J = take(jsize);
     int rs = n * (n + 3) / 2 + 2;
     if (F.neq > 0 && 256 + (n + 4) * F.ldb + 8 > rs) rs = 256 + (n + 4) * F.ldb + 8; // N = CE', then B = J0'N
+    {   // the inequality loop keeps Ri (packed, n - neq columns) and the 2 (n - neq) rotation coefficients of a drop there
+        const int mmax = n - F.neq;
+        const int need = (((mmax + 1) * (mmax + 4) / 2 + 1) & ~1) + 2 * mmax + 4;
+        if (need > rs) rs = need;
+    }
     D.o_R = take(rs);
     D.o_vec = take(cp::COUNT);
     D.o_int = o;

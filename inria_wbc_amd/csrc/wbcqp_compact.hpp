@@ -94,37 +94,91 @@ __device__ __forceinline__ double act_dot(const Ctx& c, const ActRegs& a, const 
     return acc;
 }
 
-// update_r_wave with d read as dsg * dsrc[.] (a bound's d is a row of J that has not been copied to d yet)
-__device__ __forceinline__ void update_r_wave_src(Ctx& c, int rlo, const double* dsrc, double dsg)
+// ---- the inequality block of R is never stored: its INVERSE Ri is (packed columns like R: (i, j), i <= j, at roff(j) + i,
+// positions counted from the first inequality, mi = iq - neq of them).  r = R^-1 d restricted to the inequality rows is
+// Ri d_I: a triangular matvec with no dependent chain (the back substitution took one dependent step per active
+// constraint on one wave); a new column [d; alpha] of R is the column [-r / alpha; 1 / alpha] of the inverse, and r is at
+// hand when a constraint is added; dropping a constraint rotates Ri's columns with the SAME rotations as J's (below).
+// One lane per row (mi <= 64, host check), eight columns' operands in flight.  d_I(j) = dsg * dsrc[neq + j].  r lands in
+// c.r[neq + i]; the lane's own r is returned (0 past mi).
+__device__ __forceinline__ double ri_matvec(Ctx& c, const double* Ri, int mi, const double* dsrc, double dsg)
 {
-    const int lane = c.lane, iq = c.iq;
-    if (iq <= rlo) return;
-    double v0 = (lane < iq) ? dsg * dsrc[lane] : 0.0;
-    double v1 = (lane + kWave < iq) ? dsg * dsrc[lane + kWave] : 0.0;
-    auto step = [&](int j, double rd, double ra, double rb) {
-        const double dj = (j < kWave) ? bcast_lane(v0, j) : bcast_lane(v1, j - kWave);
-        const double rj = dj * rd;
-        if (lane == (j & (kWave - 1))) c.r[j] = rj;
-        if (lane < j) v0 = fma(-rj, ra, v0);
-        if (lane + kWave < j) v1 = fma(-rj, rb, v1);
-    };
-    int j = iq - 1;
-    for (; j >= rlo + 3; j -= 4) {
-        double rd[4], ra[4], rb[4];
+    const int lane = c.lane;
+    const double* dI = dsrc + c.neq;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int j = 0; j < mi; j += 8) {
+        double rv[8], dv[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int jj = j - u;
-            const double* Rc = c.R + roff(jj);
-            rd[u] = c.rdinv[jj];
-            ra[u] = Rc[min(lane, jj)];
-            rb[u] = Rc[min(lane + kWave, jj)];
+        for (int u = 0; u < 8; ++u) {
+            const int jj = min(j + u, mi - 1);
+            rv[u] = Ri[roff(jj) + min(lane, jj)];
+            dv[u] = dI[jj];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) step(j - u, rd[u], ra[u], rb[u]);
+        for (int u = 0; u < 8; ++u) {
+            const double dm = (lane <= j + u && j + u < mi) ? dv[u] : 0.0;
+            if ((u & 3) == 0) a0 = fma(rv[u], dm, a0);
+            else if ((u & 3) == 1) a1 = fma(rv[u], dm, a1);
+            else if ((u & 3) == 2) a2 = fma(rv[u], dm, a2);
+            else a3 = fma(rv[u], dm, a3);
+        }
     }
-    for (; j >= rlo; --j) {
-        const double* Rc = c.R + roff(j);
-        step(j, c.rdinv[j], Rc[min(lane, j)], Rc[min(lane + kWave, j)]);
+    const double r = dsg * ((a0 + a1) + (a2 + a3));
+    if (lane < mi) c.r[c.neq + lane] = r;
+    return (lane < mi) ? r : 0.0;
+}
+
+// Dropping position p of the active inequalities (eiquadprog delete_constraint): R without column p is re-triangularised
+// by rotations G of the row pairs (j, j + 1), j = p .. mi - 2; J takes J G' and the inverse takes Ri G' with row p and the
+// last column dropped.  Row p of Ri G' must vanish left of its last entry, so rotation l is fixed by the running norm of
+// rho(l) = Ri(p, p + l): with S(l) = sum_{i <= l} rho(i)^2 the pair in front of rotation l is (a, b) = (-sqrt S(l), rho(l + 1))
+// ((rho(0), rho(1)) for l = 0) and (cc, ss) = (b, -a) / sqrt S(l + 1) in eiquadprog's symmetric form
+//   new(j) = cc t1 + ss t2,  new(j + 1) = ss t1 - cc t2.
+// ONE prefix sum gives every coefficient at once -- eiquadprog's chain (and round 2's) paid a division, a square root and an
+// LDS round trip per step, sequentially.  S(0) = Ri(p, p)^2 > 0, so no step is ever skipped.  Call on one wave;
+// prm[2 l], prm[2 l + 1] = cc, ss of rotation l, l < mi - p - 1.
+__device__ __forceinline__ void drop_coefficients(Ctx& c, const double* Ri, int mi, int p, double* prm)
+{
+    const int l = c.lane, L1 = mi - p;
+    const double rho0 = (l < L1) ? Ri[roff(p + min(l, L1 - 1)) + p] : 0.0;
+    const double rho1 = (l + 1 < L1) ? Ri[roff(p + min(l + 1, L1 - 1)) + p] : 0.0;
+    const double S = wave_scan_incl(rho0 * rho0);
+    const double S1 = fma(rho1, rho1, S);
+    if (l + 1 < L1) {
+        const double rs1 = rsqrt(S1);
+        const double na = (l == 0) ? -rho0 : S * rsqrt(S); // -a
+        double2v o;
+        o.x = rho1 * rs1;
+        o.y = na * rs1;
+        *reinterpret_cast<double2v*>(__builtin_assume_aligned(prm + 2 * l, 16)) = o;
+    }
+}
+
+// One row (J's or Ri's) through the rotations of a drop, together with the entry of d that travels with it: t1 enters as the
+// row's element in the first rotated column, dch as d's; on return they are the elements that LEAVE the active block.
+// get(u, jj) loads the row's element of column index jj (the caller masks what does not exist), put(jj, v) stores the new
+// element of column jj; e(jj) is d's element.  Eight steps' operands are in flight before the dependent chain starts.
+template <typename Get, typename Put, typename PutD>
+__device__ __forceinline__ void rotate_row(const double* prm, const double* dcur, int c0, int L, double& t1, double& dch, Get get, Put put, PutD putd)
+{
+    for (int l0 = 0; l0 < L; l0 += 8) {
+        double t2[8], e2[8];
+        double2v cs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ll = min(l0 + u, L - 1);
+            t2[u] = get(ll + 1);
+            e2[u] = dcur[c0 + ll + 1];
+            cs[u] = ld2(prm + 2 * ll);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (l0 + u < L) {
+                put(l0 + u, fma(cs[u].y, t2[u], cs[u].x * t1));
+                t1 = fma(cs[u].y, t1, -(cs[u].x * t2[u]));
+                putd(l0 + u, fma(cs[u].y, e2[u], cs[u].x * dch));
+                dch = fma(cs[u].y, dch, -(cs[u].x * e2[u]));
+            }
     }
 }
 
@@ -723,6 +777,10 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             }
         };
         bsync();
+        double* const Ri = c.R;                                      // inverse of R's inequality block (R itself is dead: solve_y was its last reader)
+        double* const prm = c.R + ((roff(n - neq + 1) + 1) & ~1);    // rotation coefficients of a drop, behind the largest Ri
+        double* const dbuf0 = lds + S.o_vec + cp::D;                 // d lives in one of two buffers (a drop writes the other one);
+        double* const dbuf1 = lds + S.o_vec + cp::RDINV;             // 1/R(j,j) of the equality phase is dead by now
         const double psi_tol = (double)nin2 * eps * c1 * c2 * 100.0;
         bool redo_l2 = false;
         bool s_ready = false;    // the slot holds psi / the most violated row of the current iterate
@@ -786,7 +844,6 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
             const bool negrow = (mt >> 2) & 1;
             const double sg = negrow ? -1.0 : 1.0;
-            const int owner_tid = (kind == INEQ_ACTUATION) ? 4 * rr + (negrow ? 1 : 0) : ip; // who holds ci0(ip)
             int k0, k1;
             if (kind == INEQ_BOUNDS) {
                 k0 = col;
@@ -822,36 +879,38 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             if (kind != INEQ_BOUNDS) bsync(); // the published row
             STAMP(10)
 
-            // l2a
-            while (true) {
-                const int iq = c.iq;
-                // ---- A: d = J' n.  A bound's d is +-row `col` of J: phase B reads it there and leaves the copy in d
-                if (kind == INEQ_FORCE) {
-                    if (tid < n) {
-                        const double* F = c.np + k0;
-                        const double* Jb = c.J + k0 * ldj + tid;
-                        double a0 = 0.0, a1 = 0.0;
+            // l2a.  d, z, r and the reductions of step 2b are formed ONCE per pick; a partial or dual step then carries them
+            // through the drop (rank-one updates) instead of recomputing them.
+            const int iq0 = c.iq;
+            // ---- A: d = J' n.  A bound's d is +-row `col` of J: phase B reads it there and leaves the copy in d
+            if (kind == INEQ_FORCE) {
+                if (tid < n) {
+                    const double* F = c.np + k0;
+                    const double* Jb = c.J + k0 * ldj + tid;
+                    double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-                        for (int m = 0; m < 12; m += 2) {
-                            a0 = fma(F[m], Jb[m * ldj], a0);
-                            a1 = fma(F[m + 1], Jb[(m + 1) * ldj], a1);
-                        }
-                        c.d[tid] = a0 + a1;
+                    for (int m = 0; m < 12; m += 2) {
+                        a0 = fma(F[m], Jb[m * ldj], a0);
+                        a1 = fma(F[m + 1], Jb[(m + 1) * ldj], a1);
                     }
-                    bsync();
+                    c.d[tid] = a0 + a1;
                 }
-                else if (kind == INEQ_ACTUATION) { // two lanes per column, halves of the support
-                    const int idx = tid >> 1, hf = tid & 1;
-                    const int ic = min(idx, n - 1);
-                    const int mid = (n + 1) >> 1;
-                    const int ka = hf ? mid : 0, kb = hf ? n : mid;
-                    double acc = dot8(c.np, 1, c.J + ic, ldj, ka, kb);
-                    acc += dpp_get<0xB1>(acc);
-                    if (hf == 0 && idx < n) c.d[idx] = acc;
-                    bsync();
-                }
-                STAMP(11)
-                // ---- B: z, r and the reductions of step 2b
+                bsync();
+            }
+            else if (kind == INEQ_ACTUATION) { // two lanes per column, halves of the support
+                const int idx = tid >> 1, hf = tid & 1;
+                const int ic = min(idx, n - 1);
+                const int mid = (n + 1) >> 1;
+                const int ka = hf ? mid : 0, kb = hf ? n : mid;
+                double acc = dot8(c.np, 1, c.J + ic, ldj, ka, kb);
+                acc += dpp_get<0xB1>(acc);
+                if (hf == 0 && idx < n) c.d[idx] = acc;
+                bsync();
+            }
+            STAMP(11)
+            // ---- B: z, r and the reductions of step 2b
+            {
+                const int iq = iq0;
                 const double* dsrc = (kind == INEQ_BOUNDS) ? c.J + col * ldj : c.d;
                 const double dsg = (kind == INEQ_BOUNDS) ? sg : 1.0;
                 double* slot = c.red + c.rslot * 16;
@@ -885,13 +944,11 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     }
                 }
                 else {
-                    update_r_wave_src(c, neq, dsrc, dsg);
-                    // step 2b, partial step length t1 (dual feasibility): this wave just wrote r, LDS keeps its order
+                    // r = Ri d_I, then step 2b's partial step length t1 (dual feasibility) from the lane's own r
+                    const int mi = iq - neq;
+                    const double rl = ri_matvec(c, Ri, mi, dsrc, dsg);
                     ValIdx bt{inf, 0x7fffffff};
-                    for (int kk = neq + c.lane; kk < iq; kk += kWave) {
-                        const double rk = c.r[kk];
-                        if (rk > 0.0) bt = vi_min(bt, ValIdx{c.u[kk] / rk, kk});
-                    }
+                    if (c.lane < mi && rl > 0.0) bt = ValIdx{c.u[neq + c.lane] / rl, neq + c.lane};
                     bt = wave_argmin(bt);
                     if (c.lane == 0) {
                         slot[12] = bt.v;
@@ -899,39 +956,32 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     }
                 }
                 bsync(); // B3
-                STAMP(12)
-                // ---- step lengths
-                const double zz = (slot[0] + slot[1]) + slot[2], znp = (slot[4] + slot[5]) + slot[6];
-                const double dn2 = (slot[8] + slot[9]) + slot[10];
-                const double t1 = slot[12];
-                const int lpos = __double2loint(slot[13]);
+            }
+            STAMP(12)
+            double zz, znp, dn2, t1;
+            int lpos;
+            {
+                const double* slot = c.red + c.rslot * 16;
+                zz = (slot[0] + slot[1]) + slot[2];
+                znp = (slot[4] + slot[5]) + slot[6];
+                dn2 = (slot[8] + slot[9]) + slot[10];
+                t1 = slot[12];
+                lpos = __double2loint(slot[13]);
                 c.rslot ^= 1;
+            }
+            double uiq = 0.0; // u[iq] of the candidate: every thread carries it, LDS sees it when the constraint is added
+            while (true) {
+                const int iq = c.iq;
+                // ---- step lengths
                 const int l = (t1 < inf) ? c.A[lpos] : 0;
-                const double uiq = c.u[iq];
                 const double t2 = (fabs(zz) > eps) ? (-sip / znp) : inf;
                 const double t = fmin(t1, t2);
                 if (t >= inf) {
                     status = HQP_INFEASIBLE; // eiquadprog UNBOUNDED (dual) -> tsid INFEASIBLE
                     break;
                 }
-                if (t2 >= inf) {
-                    // (ii) dual step only, drop l
-                    if (!slow && tid < n) c.xold[tid] = c.x[tid]; // leaving the common path: snapshot of x for a later rejection
-                    slow = true;
-                    bsync(); // everyone has read u[iq], A[lpos] before they change
-                    for (int j = neq + tid; j < iq; j += kThreads) c.u[j] = fma(-t, c.r[j], c.u[j]);
-                    if (tid == kThreads - 1) {
-                        c.u[iq] = uiq + t;
-                        act[l] = 0;
-                    }
-                    bsync();
-                    STAMP(13)
-                    delete_constraint(c, l);
-                    STAMP(15)
-                    continue;
-                }
-                f_value += t * znp * (0.5 * t + uiq);
-                if (t == t2) {
+                if (t2 < inf) f_value += t * znp * (0.5 * t + uiq);
+                if (t2 < inf && t == t2) {
                     // (iii) full step: add ip to the active set with one reflector H = I - tau v v' (v = d[iq:] - alpha e_0)
                     const double diq = c.d[iq];
                     double alpha = diq, v0 = 0.0, tau = 0.0;
@@ -943,24 +993,35 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         v0 = diq - alpha;
                         tau = fast_rcp(fma(nx, fabs(diq), dn2));
                     }
-                    const bool accepted = fabs(alpha) > eps * c.R_norm;
-                    // an accepted constraint never needs the snapshot of x again, whatever partial steps came before it: the
-                    // fused phase is taken then too (x_next goes into the buffer that held the snapshot)
-                    const bool fused = accepted;
                     STAMP(20)
-                    // w_k = tau (z_k - alpha J(k,iq)); J(:, iq) was stashed in phase B, so nobody waits for anybody here
-                    if (reflect) {
-                        if (!fused) {
-                            if (tid < n) c.part[tid] = tau * (c.z[tid] - alpha * c.part[tid]);
-                            if (!slow && tid < n) c.xold[tid] = c.x[tid];
-                            bsync(); // B4 (the slow path keeps x in place)
+                    if (!(fabs(alpha) > eps * c.R_norm)) {
+                        // numerically dependent on the active set: eiquadprog adds it, takes it out again (the last position:
+                        // no rotation), returns to the saved iterate and picks another.  Nothing has been written yet, so the
+                        // reflector is not applied at all (it would only turn the basis of the null space).
+                        if (tid == 0) excl[ip] = 0;
+                        excl_dirty = true;
+                        if (tid < nin2) act[tid] = 0;
+                        bsync();
+                        for (int i = tid; i < iq; i += kThreads) {
+                            const int av = c.Aold[i];
+                            c.A[i] = av;
+                            if (av >= 0) act[av] = 1;
+                            c.u[i] = c.uold[i];
                         }
+                        if (slow && tid < n) c.x[tid] = c.xold[tid];
+                        tact_valid = false;
+                        bsync();
+                        redo_l2 = true;
+                        break; // -> l2 again
+                    }
+                    // w_k = tau (z_k - alpha J(k,iq)); J(:, iq) was stashed in phase B (or by the last drop), so nobody waits
+                    if (reflect) {
                         const int kr = tid & 127, half = tid >> 7;
                         if (kr < n) {
                             const int span = n - iq;
                             const int ca = iq + half * ((span + 1) >> 1), cb = half ? n : iq + ((span + 1) >> 1);
                             double* Jk = c.J + kr * ldj;
-                            const double wk = fused ? tau * (c.z[kr] - alpha * c.part[kr]) : c.part[kr];
+                            const double wk = tau * (c.z[kr] - alpha * c.part[kr]);
                             int cc = ca;
                             if (cc == iq && cc < cb) {
                                 Jk[cc] = fma(-wk, v0, Jk[cc]);
@@ -979,104 +1040,144 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                             for (; cc < cb; ++cc) Jk[cc] = fma(-wk, c.d[cc], Jk[cc]);
                         }
                     }
-                    else if (!fused) {
-                        if (!slow && tid < n) c.xold[tid] = c.x[tid];
-                        bsync();
-                    }
                     STAMP(21)
-                    double* Rc = c.R + roff(iq);
-                    for (int i = tid; i < iq; i += kThreads) Rc[i] = c.d[i];
-                    if (fused) {
-                        // ---- C: the rest of the step and the next iterate's s in one phase
-                        if (tid < n) c.xold[tid] = fma(t, c.z[tid], c.x[tid]); // x_next: the buffers swap below
-                        if (tid >= 128 + neq && tid - 128 < iq) {
-                            const double un = fma(-t, c.r[tid - 128], c.u[tid - 128]);
-                            c.u[tid - 128] = un;
-                            c.uold[tid - 128] = un;
-                        }
-                        if (slow && tid < iq) { // partial steps moved entries of A and u: the snapshot of the next pick is taken whole
-                            c.Aold[tid] = c.A[tid];
-                            if (tid < neq) c.uold[tid] = c.u[tid];
-                        }
-                        if (tid == kThreads - 1) {
-                            Rc[iq] = alpha;
-                            c.rdinv[iq] = 1.0 / alpha;
-                            c.u[iq] = uiq + t;
-                            c.uold[iq] = uiq + t;
-                            c.Aold[iq] = ip;
-                            act[ip] = 1;
-                        }
-                        double psi;
-                        ValIdx nb;
-                        eval_rows(c.x, c.z, t, ip, psi, nb);
-                        STAMP(23)
-                        tact_valid = act_ineq;
-                        publish_best(psi, nb);
-                        c.iq = iq + 1;
-                        c.R_norm = fmax(c.R_norm, fabs(alpha));
-                        bsync(); // C = B1 of the next iteration
-                        double* xt = c.x;
-                        c.x = c.xold;
-                        c.xold = xt;
-                        s_ready = true;
-                        STAMP(14)
-                        break; // -> l1
+                    // ---- C: the rest of the step and the next iterate's s in one phase
+                    const double ralpha = fast_rcp(alpha);
+                    const int mi = iq - neq;
+                    double* Ric = Ri + roff(mi); // the new column of the inverse: [-r / alpha; 1 / alpha]
+                    if (tid < n) c.xold[tid] = fma(t, c.z[tid], c.x[tid]); // x_next: the buffers swap below
+                    if (tid >= 128 + neq && tid - 128 < iq) {
+                        const double rk = c.r[tid - 128];
+                        const double un = fma(-t, rk, c.u[tid - 128]);
+                        c.u[tid - 128] = un;
+                        c.uold[tid - 128] = un;
+                        Ric[tid - 128 - neq] = -rk * ralpha;
                     }
-                    // the plain path: x in place (its snapshot is in c.xold), the next pick evaluates s from scratch
-                    tact_valid = false;
-                    if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
-                    if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                    if (slow && tid < iq) { // drops moved entries of A and u: the snapshot of the next pick is taken whole
+                        c.Aold[tid] = c.A[tid];
+                        if (tid < neq) c.uold[tid] = c.u[tid];
+                    }
                     if (tid == kThreads - 1) {
-                        Rc[iq] = alpha;
-                        c.rdinv[iq] = 1.0 / alpha;
+                        Ric[mi] = ralpha;
                         c.u[iq] = uiq + t;
-                        if (accepted) act[ip] = 1;
+                        c.uold[iq] = uiq + t;
+                        c.Aold[iq] = ip;
+                        act[ip] = 1;
                     }
-                    slow = true;
+                    double psi;
+                    ValIdx nb;
+                    eval_rows(c.x, c.z, t, ip, psi, nb);
+                    STAMP(23)
+                    tact_valid = act_ineq;
+                    publish_best(psi, nb);
                     c.iq = iq + 1;
-                    bsync(); // B5
+                    c.R_norm = fmax(c.R_norm, fabs(alpha));
+                    bsync(); // C = B1 of the next iteration
+                    double* xt = c.x;
+                    c.x = c.xold;
+                    c.xold = xt;
+                    s_ready = true;
                     STAMP(14)
-                    if (accepted) c.R_norm = fmax(c.R_norm, fabs(alpha));
-                    else {
-                        // numerically dependent: take the constraint out again, back to the saved iterate, pick another
-                        if (tid == 0) excl[ip] = 0;
-                        excl_dirty = true;
-                        bsync();
-                        delete_constraint(c, ip);
-                        if (tid < nin2) act[tid] = 0;
-                        bsync();
-                        for (int i = tid; i < c.iq; i += kThreads) {
-                            const int av = c.Aold[i];
-                            c.A[i] = av;
-                            if (av >= 0) act[av] = 1;
-                            c.u[i] = c.uold[i];
-                        }
-                        for (int i = tid; i < n; i += kThreads) c.x[i] = c.xold[i];
-                        bsync();
-                        redo_l2 = true;
-                    }
-                    break; // -> l1 (or l2 again)
+                    break; // -> l1
                 }
-                // (iii) partial step: primal + dual step, drop l, refresh s(ip)
-                if (!slow && tid < n) c.xold[tid] = c.x[tid];
-                slow = true;
-                tact_valid = false;
-                bsync(); // everyone has read u[iq], A[lpos] before they change
-                if (tid < n) c.x[tid] = fma(t, c.z[tid], c.x[tid]);
-                if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
-                if (tid == kThreads - 1) c.u[iq] = uiq + t;
-                if (tid == 0) act[l] = 0;
+                // ---- (ii) dual step / (iii) partial step: move, then drop l.  Two barriers; d, z, r, z'n, |d2|^2, s(ip) follow
+                //      the drop by rank-one updates (delta = the entry of d that leaves the active block):
+                //      z += delta J(:, iq'), r_i -= delta Z(i, last), z'n += delta^2, |d2|^2 += delta^2, s(ip) += t z'n.
+                const bool primal = t2 < inf;
+                const int qq = lpos, p = lpos - neq, mi = iq - neq;
+                const int L = iq - 1 - qq; // rotations
+                {
+                    if (tid < n) {
+                        const double xv = c.x[tid];
+                        if (!slow) c.xold[tid] = xv; // leaving the common path: snapshot of x for a later rejection
+                        if (primal) c.x[tid] = fma(t, c.z[tid], xv);
+                    }
+                    if (tid >= 128 + neq && tid - 128 < iq) c.u[tid - 128] = fma(-t, c.r[tid - 128], c.u[tid - 128]);
+                    if (tid == kThreads - 1) act[l] = 0;
+                    if (c.wave == 1) drop_coefficients(c, Ri, mi, p, prm);
+                    if (primal) sip = fma(t, znp, sip);
+                    uiq += t;
+                    slow = true;
+                    tact_valid = false;
+                }
                 bsync();
                 STAMP(13)
-                delete_constraint(c, l);
+                double* const dnx = (c.d == dbuf0) ? dbuf1 : dbuf0; // d after the drop goes to the other buffer: readers of d race nobody
+                {
+                    double* slot = c.red + c.rslot * 16;
+                    if (c.wave < 2) {
+                        // rows of J: columns qq .. iq - 1
+                        const int kr = min(tid, n - 1);
+                        const bool live = tid < n;
+                        double* Jk = c.J + kr * ldj + qq;
+                        double tj = Jk[0], dch = c.d[qq];
+                        rotate_row(prm, c.d, qq, L, tj, dch,
+                                   [&](int jj) { return Jk[jj]; },
+                                   [&](int jj, double v) { if (live) Jk[jj] = v; },
+                                   [&](int jj, double v) { if (tid == 0) dnx[qq + jj] = v; });
+                        double zq = 0.0;
+                        if (live) {
+                            Jk[L] = tj;
+                            const double zn = fma(dch, tj, c.z[kr]);
+                            c.z[kr] = zn;
+                            c.part[kr] = tj; // column iq' of J, for the w of phase C
+                            zq = zn * zn;
+                        }
+                        zq = wave_sum(zq);
+                        if (c.lane == 0) slot[c.wave] = zq;
+                        if (tid == 0) {
+                            dnx[iq - 1] = dch;
+                            slot[14] = dch;
+                        }
+                    }
+                    else if (c.wave == 2) {
+                        // rows of Ri (one wave: lane i writes what lane i - 1 has read a step earlier), r, u, A, t1
+                        const int i = c.lane;
+                        const bool row = i < mi;
+                        const bool has = row && i != p;
+                        const int i2 = i - ((i > p) ? 1 : 0);
+                        double tj = (row && i <= p) ? Ri[roff(p) + min(i, p)] : 0.0;
+                        double dch = c.d[qq];
+                        rotate_row(prm, c.d, qq, L, tj, dch,
+                                   [&](int jj) { const int j = p + jj; const double v = Ri[roff(j) + min(i, j)]; return (row && i <= j) ? v : 0.0; },
+                                   [&](int jj, double v) { if (has && i2 <= p + jj) Ri[roff(p + jj) + i2] = v; },
+                                   [&](int, double) {});
+                        const double rn = row ? fma(-dch, tj, c.r[neq + min(i, mi - 1)]) : 0.0;
+                        const double uu = c.u[neq + min(i, mi - 1)];
+                        const int aa = c.A[neq + min(i, mi - 1)];
+                        if (has) {
+                            c.r[neq + i2] = rn;
+                            c.u[neq + i2] = uu;
+                            c.A[neq + i2] = aa;
+                        }
+                        if (i == mi) c.A[iq - 1] = ip; // the candidate moves with its position
+                        ValIdx bt{inf, 0x7fffffff};
+                        if (has && rn > 0.0) bt = ValIdx{uu / rn, neq + i2};
+                        bt = wave_argmin(bt);
+                        if (c.lane == 0) {
+                            slot[12] = bt.v;
+                            slot[13] = __hiloint2double(0, bt.i);
+                        }
+                    }
+                    else {
+                        // the entries of d the drop does not touch
+                        for (int j = c.lane; j < n; j += kWave)
+                            if (j < qq || j >= iq) dnx[j] = c.d[j];
+                    }
+                }
+                bsync();
                 STAMP(15)
                 {
-                    double part = 0.0;
-                    for (int j = k0 + tid; j < k1; j += kThreads) part = fma(c.np[j], c.x[j], part);
-                    part = block_sum(c, part);
-                    if (tid == owner_tid) c.red[31] = part + ((kind == INEQ_ACTUATION) ? aci0 : own.ci0);
-                    bsync();
-                    sip = c.red[31];
+                    const double* slot = c.red + c.rslot * 16;
+                    const double delta = slot[14];
+                    zz = slot[0] + slot[1];
+                    znp = fma(delta, delta, znp);
+                    dn2 = fma(delta, delta, dn2);
+                    t1 = slot[12];
+                    lpos = __double2loint(slot[13]);
+                    c.rslot ^= 1;
+                    c.d = dnx;
+                    c.iq = iq - 1;
                 }
             }
         }

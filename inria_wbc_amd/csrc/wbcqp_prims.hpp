@@ -342,6 +342,26 @@ __device__ __forceinline__ double grp8_sum(double v)
     return v;
 }
 
+// inclusive prefix sum over the 64 lanes: row_shr 1/2/4/8 inside each row of 16, then the two gfx9 row broadcasts
+// (lane 15 of rows 0 / 2 into rows 1 / 3, lane 31 into rows 2 and 3).  Lanes without a source add the `old` operand, 0.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_add0(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_scan_incl(double v)
+{
+    v = dpp_add0<0x111, 0xf>(v); // row_shr:1
+    v = dpp_add0<0x112, 0xf>(v); // row_shr:2
+    v = dpp_add0<0x114, 0xf>(v); // row_shr:4
+    v = dpp_add0<0x118, 0xf>(v); // row_shr:8
+    v = dpp_add0<0x142, 0xa>(v); // row_bcast:15 -> rows 1, 3
+    v = dpp_add0<0x143, 0xc>(v); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // sum over the 4 lanes of a quad (every lane gets the total)
 __device__ __forceinline__ double quad_sum(double v)
 {

@@ -1,0 +1,43 @@
+"""The arithmetic of the round-3 active-set loop (R^-1 carried instead of R, drop rotations from one prefix sum, rank-one
+updates of d / z / r after a drop: tools/gi_rinv_proto.py) against the C oracle's eiquadprog-fast restatement
+(oracle/wbc_oracle.c).  CPU only: pins the MATH the HIP kernel implements before any GPU is involved."""
+import numpy as np
+import pytest
+
+from inria_wbc_amd import structure, synth
+from oracle import oracle
+from tools import gi_rinv_proto as proto
+
+
+@pytest.mark.parametrize("name,first,count,kw", [
+    ("talos", 0, 6, dict(task_noise=5.0)),          # 20-50 iterations, up to 20 drops each
+    ("talos", 725, 8, dict(squat=True)),            # bench.py's stream around its heavy ticks
+    ("icub", 0, 6, dict(task_noise=2.0)),
+    ("talos_single_support", 0, 4, dict(task_noise=2.0)),
+])
+def test_proto_matches_oracle(name, first, count, kw):
+    st = structure.STRUCTURES[name]()
+    seed = synth.SEED_BASE["talos_squat" if kw.get("squat") else name]
+    inp = synth.generate(st, count, seed, first=first, **kw)
+    ref = oracle.tick_batch(st, inp)
+    drops = 0
+    for i in range(count):
+        H, g, CE, ce0, CI, ci0 = oracle.assemble(st, inp, i)
+        tr = {}
+        out = proto.solve(H, g, CE, ce0, CI, ci0, trace=tr)
+        assert out["status"] == ref["status"][i]
+        scale = max(1.0, float(np.abs(ref["x"][i]).max()))
+        assert np.abs(out["x"] - ref["x"][i]).max() <= 1e-8 * scale
+        assert abs(out["iters"] - ref["iters"][i]) <= 2
+        drops += tr.get("partial_steps", 0)
+    if kw.get("task_noise", 0) >= 5.0:
+        assert drops > 10  # the drop path is what this test is about
+
+
+def test_proto_reports_infeasible():
+    # x >= 1 and -x >= 0 cannot both hold
+    H = np.eye(2); g = np.zeros(2)
+    CI = np.array([[1.0, 0.0], [-1.0, 0.0]]); ci0 = np.array([-1.0, 0.0])
+    out = proto.solve(H, g, np.zeros((0, 2)), np.zeros(0), CI, ci0)
+    ref = oracle.eiquadprog(H, g, np.zeros((0, 2)), np.zeros(0), CI, ci0)
+    assert out["status"] == proto.INFEASIBLE and ref["status"] != 0

@@ -1,0 +1,166 @@
+"""numpy model of the round-3 active-set loop (csrc/wbcqp_compact.hpp, phase 4) -- the arithmetic only, no parallelism.
+
+What changed against eiquadprog's bookkeeping, and why each piece is still the same algorithm:
+  * the inequality block of R is never stored; its INVERSE Ri is.  r = R^-1 d restricted to the inequality rows is
+    Ri d_I (a triangular MATVEC instead of a back substitution: no dependent chain); a new column of R, [d; alpha],
+    is the column [-r / alpha; 1 / alpha] of the inverse, and r is at hand when a constraint is added.
+  * delete_constraint: R without column p is re-triangularised by rotations G; the inverse takes Ri G' with row p and
+    the last column dropped.  Row p of Ri G' must vanish left of its last entry, so rotation j is fixed by the running
+    norm of row p of Ri: every (cc, ss) follows from ONE prefix sum of squares -- no sequential division / sqrt chain.
+  * after a drop nothing is recomputed from scratch: d <- G d, and with delta = the entry of d that leaves the active
+    block,  z += delta J(:, iq),  r_i -= delta Z(i, last),  z'n += delta^2,  |d2|^2 += delta^2,  s(ip) += t z'n.
+
+Used by tests/test_gi_rinv_proto.py against the C oracle.  Test infrastructure, not product code.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EPS = np.finfo(float).eps
+OPTIMAL, INFEASIBLE, MAX_ITER, ERROR = 0, 1, 3, 4
+
+
+def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None):
+    n = g.size
+    neq, m = CE.shape[0], CI.shape[0]
+    U = np.linalg.cholesky(H).T
+    J = np.linalg.inv(U)
+    c1, c2 = np.trace(H), np.trace(J)
+    x = -J @ (J.T @ g)
+    iq = 0
+    R_norm = 1.0
+    if neq:
+        B = J.T @ CE.T
+        Q, Rq = np.linalg.qr(B, mode="complete")
+        if np.any(np.abs(np.diag(Rq[:neq])) <= EPS * max(1.0, np.abs(np.diag(Rq[:neq])).max())):
+            return dict(x=x, status=ERROR, iters=0)
+        J = J @ Q
+        y = np.linalg.solve(Rq[:neq].T, -(CE @ x + ce0))
+        x = x + J[:, :neq] @ y
+        iq = neq
+        R_norm = max(1.0, np.abs(np.diag(Rq[:neq])).max())
+    Ri = np.zeros((n, n))  # inverse of the inequality block of R, position space (0 .. iq - neq)
+    A = [-(i + 1) for i in range(neq)]
+    u = np.zeros(n + 2)
+    act = np.zeros(m, bool)
+    it = 0
+    partial_steps = 0
+    psi_tol = m * EPS * c1 * c2 * 100.0
+    excl = np.ones(m, bool)
+    while True:
+        it += 1
+        if it >= max_iter:
+            return dict(x=x, status=MAX_ITER, iters=it)
+        s = CI @ x + ci0
+        excl[:] = True
+        psi = np.minimum(s, 0.0).sum()
+        if abs(psi) <= psi_tol:
+            break
+        x_old, u_old, A_old = x.copy(), u.copy(), list(A)
+        done = False
+        while True:  # l2
+            cand = np.where(~act & excl & (s < 0.0), s, 0.0)
+            ip = int(np.argmin(cand))
+            if cand[ip] >= 0.0:
+                done = True
+                break
+            npv = CI[ip]
+            sip = s[ip]
+            u[iq] = 0.0
+            A = A[:iq] + [ip]
+            d = J.T @ npv
+            z = J[:, iq:] @ d[iq:]
+            mi = iq - neq
+            r = Ri[:mi, :mi] @ d[neq:iq]
+            zz, znp, dn2 = z @ z, z @ npv, d[iq:] @ d[iq:]
+            rejected = False
+            while True:  # l2a with everything carried across drops
+                mi = iq - neq
+                t1, lpos = np.inf, -1
+                for kk in range(mi):
+                    if r[kk] > 0.0 and u[neq + kk] / r[kk] < t1:
+                        t1, lpos = u[neq + kk] / r[kk], kk
+                t2 = -sip / znp if abs(zz) > EPS else np.inf
+                t = min(t1, t2)
+                if t == np.inf:
+                    return dict(x=x, status=INFEASIBLE, iters=it)
+                if t2 == np.inf:  # dual step
+                    u[neq:iq] -= t * r
+                    u[iq] += t
+                else:
+                    x = x + t * z
+                    u[neq:iq] -= t * r
+                    u[iq] += t
+                    if t == t2:
+                        break
+                    sip = sip + t * znp
+                partial_steps += 1
+                # ---- drop position lpos: rotations from the prefix sum over row p of Ri
+                p = lpos
+                act[A[neq + p]] = False
+                rho = Ri[p, p:mi].copy()
+                S = np.cumsum(rho * rho)
+                Z = Ri[:mi, :mi].copy()
+                for j in range(mi - 1 - p):  # columns (p + j, p + j + 1)
+                    a = rho[0] if j == 0 else -np.sqrt(S[j])
+                    b = rho[j + 1]
+                    hh = np.sqrt(S[j + 1])
+                    cc, ss = b / hh, -a / hh
+                    for Mx, c0 in ((Z, p + j), (J, neq + p + j)):
+                        t1c, t2c = Mx[:, c0].copy(), Mx[:, c0 + 1].copy()
+                        Mx[:, c0] = cc * t1c + ss * t2c
+                        Mx[:, c0 + 1] = ss * t1c - cc * t2c
+                    da, db = d[neq + p + j], d[neq + p + j + 1]
+                    d[neq + p + j] = cc * da + ss * db
+                    d[neq + p + j + 1] = ss * da - cc * db
+                delta = d[iq - 1]
+                r_full = r - delta * Z[:, mi - 1]
+                keep = [i for i in range(mi) if i != p]
+                Ri[:mi, :mi] = 0.0
+                Ri[:mi - 1, :mi - 1] = Z[np.ix_(keep, range(mi - 1))]
+                r = r_full[keep]
+                u[neq + p:iq] = u[neq + p + 1:iq + 1]
+                u[iq] = 0.0
+                A = A[:neq + p] + A[neq + p + 1:]
+                iq -= 1
+                z = z + delta * J[:, iq]
+                znp += delta * delta
+                dn2 += delta * delta
+                zz = z @ z
+            # ---- full step: add ip with one reflector (v = d[iq:] - alpha e0)
+            diq = d[iq]
+            alpha = diq
+            if iq + 1 < n and dn2 > 0.0:
+                nx = np.sqrt(dn2)
+                alpha = -nx if diq >= 0.0 else nx
+                v = d[iq:].copy()
+                v[0] -= alpha
+                tau = 1.0 / (nx * abs(diq) + dn2)
+                w = tau * (z - alpha * J[:, iq])
+                J[:, iq:] -= np.outer(w, v)
+            if abs(alpha) <= EPS * R_norm:  # dependent: back to the saved iterate, pick another
+                excl[ip] = False
+                for i in range(min(iq, len(A_old))):
+                    pass
+                A = list(A_old[:iq])
+                act[:] = False
+                for a in A:
+                    if a >= 0:
+                        act[a] = True
+                u[:iq] = u_old[:iq]
+                x = x_old.copy()
+                continue
+            mi = iq - neq
+            Ri[:mi, mi] = -r / alpha
+            Ri[mi, mi] = 1.0 / alpha
+            Ri[mi, :mi] = 0.0
+            R_norm = max(R_norm, abs(alpha))
+            act[ip] = True
+            iq += 1
+            break
+        if done:
+            break
+    if trace is not None:
+        trace["partial_steps"] = partial_steps
+        trace["n_active"] = iq
+    return dict(x=x, status=OPTIMAL, iters=it)
