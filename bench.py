@@ -220,6 +220,113 @@ def cpu_model():
     return "unknown"
 
 
+def other_configs(local_rank, torch, parity=True):
+    """BASELINE configs 3 (iCub, foot contacts, B = 4096, fp32 boundary) and 5 (ragged mix, B = 8192) in the default line, each with
+    its own fraction of the HBM roofline and a parity sample against the oracle.  Config 3: 1024 generated QPs tiled four times,
+    instance i at step t on tick (i + 17 t) of the squat CoM stream like the headline; inputs rounded to f32 for both sides."""
+    from inria_wbc_amd import capi, structure, synth
+    dev = torch.device("cuda", local_rank)
+    out = {}
+    st = structure.STRUCTURES["icub"]()
+    Bg, Bt, nt = 1024, 4096, 8
+    inp = synth.generate(st, Bg, synth.SEED_BASE["icub"])
+    inp = {k: v.astype(np.float32).astype(np.float64) for k, v in inp.items()}
+    com_rows = np.where(st.dense_row_task == st.task_names.index("com"))[0]
+    table = np.stack([synth.squat_com_rhs(st, t, st.kp.get("com", 30.0)) for t in range(4000)])
+    base = {k: torch.from_numpy(np.ascontiguousarray(np.tile(v, (Bt // Bg, 1)).astype(np.float32))).to(dev) for k, v in inp.items() if v.size}
+    b1s = []
+    for t in range(nt):
+        b1 = np.tile(inp["b1"], (Bt // Bg, 1))
+        b1[:, com_rows] += table[(np.arange(Bt) + 17 * t) % 4000][:, :com_rows.size]
+        b1s.append(b1.astype(np.float32))
+    dicts = []
+    for t in range(nt):
+        d = dict(base)
+        d["b1"] = torch.from_numpy(np.ascontiguousarray(b1s[t])).to(dev)
+        dicts.append(d)
+    o = dict(x=torch.zeros(Bt, st.n, dtype=torch.float32, device=dev), tau=torch.zeros(Bt, st.na, dtype=torch.float32, device=dev),
+             status=torch.full((Bt,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(Bt, dtype=torch.int32, device=dev))
+    h = capi.Handle(device=local_rank, dtype=capi.F32)
+    h.set_structure(0, st)
+    sp = torch.cuda.current_stream().cuda_stream
+    for t in range(8):
+        h.solve_batch(0, Bt, dicts[t % nt], o, stream=sp)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nrep = 48
+    t0 = time.perf_counter()
+    e0.record()
+    for t in range(nrep):
+        h.solve_batch(0, Bt, dicts[t % nt], o, stream=sp)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / nrep
+    kms = e0.elapsed_time(e1) / nrep
+    ab = (ALGORITHMIC_BYTES["icub"] - 8) // 2 + 8
+    it = o["iters"].cpu().numpy()
+    c3 = {"workload": "icub_pos_tracker_b4096_fp32_boundary_squat_tick_stream", "value": Bt / dt, "unit": "QP/s", "ms_per_step": dt * 1e3, "kernel_ms": kms,
+          "algorithmic_bytes_per_qp": ab, "frac_hbm": ab * Bt / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "dtype": "f64 arithmetic, f32 arrays in HBM",
+          "iters_mean": float(it.mean()), "iters_max": int(it.max()), "status_optimal": int((o["status"] == 0).sum().item())}
+    if parity:
+        from oracle import oracle
+        last = (nrep - 1) % nt
+        ns = 64
+        sub = {k: v[:ns].copy() for k, v in inp.items()}
+        sub["b1"] = b1s[last][:ns].astype(np.float64)
+        ref = oracle.tick_batch(st, sub)
+        xg = o["x"][:ns].cpu().numpy().astype(np.float64)
+        okr = ref["status"] == 0
+        c3["parity"] = {"sample": ns, "max_rel_dx": float((np.abs(xg - ref["x"]).max(axis=1) / np.maximum(1.0, np.abs(ref["x"]).max(axis=1)))[okr].max()),
+                        "status_equal": bool(np.array_equal(o["status"][:ns].cpu().numpy(), ref["status"])),
+                        "tolerance": "1e-3 relative (SURVEY 8(d): fp32 boundary; outputs are rounded to f32)"}
+    h.close()
+    out["config3_icub_b4096_f32"] = c3
+    from tools import ragged_bench
+    ns5 = argparse.Namespace(batch=8192, steps=30, no_parity=not parity)
+    out["config5_ragged_b8192"] = ragged_bench.run(ns5)
+    return out
+
+
+def dense_seam(local_rank, st, inputs, cpu=True):
+    """Latency of ONE Talos QP through the two host-pointer seams: `wbcqp_solve_dense_host` -- what stands behind
+    solver_->solve(HQPData) (controller.cpp:247), the reference's own use case at n_qp = 1 -- and `wbcqp_solve_batch_host`
+    (structured record in, batch 1), next to the CPU restatement on one thread.  Wall time per call, PCIe staging included."""
+    from inria_wbc_amd import capi
+    from oracle import oracle
+    one = {k: v[:1] for k, v in inputs.items()}
+    H, g, CE, ce0, CI, ci0 = [np.ascontiguousarray(a) for a in oracle.assemble(st, inputs, 0)]
+    h = capi.Handle(device=local_rank, dtype=capi.F64)
+    h.set_structure(0, st)
+    res = {"qp": "QP 0 of the headline batch (Talos, n %d, neq %d, %d one-sided rows)" % (st.n, st.neq, st.nin2)}
+
+    def wall(fn, reps=200):
+        for _ in range(10):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        return (time.perf_counter() - t0) / reps * 1e6, r
+
+    us_d, rd = wall(lambda: h.solve_dense_host(H[None], g[None], CE[None], ce0[None], CI[None], ci0[None]))
+    us_b, rb = wall(lambda: h.solve_batch_host(0, one))
+    res["solve_dense_host_us"] = us_d
+    res["solve_batch_host_us"] = us_b
+    res["iters"] = int(rb["iters"][0])
+    res["agree_max_dx"] = float(np.abs(rd["x"][0] - rb["x"][0]).max())
+    if cpu:
+        t0 = time.perf_counter()
+        for _ in range(50):
+            ref = oracle.tick_batch(st, one)
+        res["cpu_port_single_thread_us"] = (time.perf_counter() - t0) / 50 * 1e6
+        t0 = time.perf_counter()
+        for _ in range(50):
+            oracle.eiquadprog(H, g, CE, ce0, CI, ci0)
+        res["cpu_port_eiquadprog_only_us"] = (time.perf_counter() - t0) / 50 * 1e6
+        res["max_rel_dx_vs_oracle"] = float(np.abs(rb["x"][0] - ref["x"][0]).max() / max(1.0, np.abs(ref["x"][0]).max()))
+    h.close()
+    return res
+
+
 def main():
     args = parse()
     if args.headline_only:
@@ -339,7 +446,34 @@ def main():
         el = time.perf_counter() - t0
         return el, ev0.elapsed_time(ev1) * 1e-3
 
-    elapsed, ev_s = timed(args.steps, args.warmup)
+    # ---- where in the stream the K timed steps lie.  The resident ticks are not equally heavy (the squat's later ticks ask for
+    # more), so a short window is representative only where its mean launch time equals the cycle's: one untimed pass measures
+    # every resident tick's launch (an event pair per launch), and the window starts at the phase whose mean over the K steps
+    # behind the warm-up is closest to the mean over the whole cycle.  `value / long_run` is printed beside it.
+    t_first, window = 0, None
+    if stream and args.steps < len(tick_dicts) and not args.replay:
+        nt = len(tick_dicts)
+        for t in range(8):
+            step(nt - 8 + t)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nt)]
+        for t in range(nt):
+            evs[t][0].record()
+            step(t)
+            evs[t][1].record()
+        torch.cuda.synchronize()
+        per = np.array([a.elapsed_time(b) for a, b in evs])
+        means = np.array([per[[(s0 + args.warmup + j) % nt for j in range(args.steps)]].mean() for s0 in range(nt)])
+        t_first = int(np.argmin(np.abs(means - per.mean())))
+        if distributed:  # every rank times the same stretch
+            tf = torch.tensor([t_first], dtype=torch.int64, device=dev)
+            dist.broadcast(tf, src=0)
+            t_first = int(tf.item())
+        window = {"first_tick": t_first, "ms_window_mean_prepass": float(means[t_first]), "ms_cycle_mean_prepass": float(per.mean()),
+                  "ms_cycle_min": float(per.min()), "ms_cycle_max": float(per.max()),
+                  "note": "the timed steps start at the phase of the %d-tick cycle whose %d-step mean launch time is closest to the cycle's mean "
+                          "(untimed pre-pass, one event pair per launch)" % (nt, args.steps)}
+    elapsed, ev_s = timed(args.steps, args.warmup, t_first=t_first)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -347,7 +481,7 @@ def main():
     kern_avg_s = ev_s / args.steps
 
     # the last timed step's outputs, with the tick they belong to (parity sample below)
-    last_tick = (args.warmup + args.steps - 1) % len(tick_dicts)
+    last_tick = (t_first + args.warmup + args.steps - 1) % len(tick_dicts)
     status = d_out["status"].cpu().numpy()
     iters = d_out["iters"].cpu().numpy()
     x_gpu = d_out["x"].cpu().numpy().astype(np.float64)
@@ -407,6 +541,14 @@ def main():
                                   "chain of dependent operations, see DESIGN.md section 4"}
         if gather["err"]:
             result["config"]["allgather_error"] = gather["err"]
+        if gather["ok"]:
+            try:  # what RCCL itself says about the communicator the timed all-gathers ran on
+                from inria_wbc_amd import rccl
+                result["config"]["rccl_nranks"] = rccl.comm_count(gather["comm"])
+            except Exception as e:  # noqa: BLE001
+                result["config"]["rccl_nranks_error"] = repr(e)
+        if window is not None:
+            result["window"] = window
 
         if world == 1 and stream and not args.headline_only:
             # how alike are consecutive ticks?  (the launch order is built on it)
@@ -425,6 +567,7 @@ def main():
             n_long = max(args.steps, int(0.6 / max(kern_avg_s, 1e-6)))
             el, evl = timed(n_long, 2)
             result["long_run"] = {"value": B * n_long / el, "unit": "QP/s", "steps": n_long, "seconds": el, "kernel_ms": evl / n_long * 1e3}
+            result["value_over_long_run"] = value / result["long_run"]["value"]
 
             def variant(flags, note, replay=False, fresh=None):
                 h2 = capi.Handle(device=local_rank, dtype=cdt, flags=flags)
@@ -568,6 +711,16 @@ def main():
                 with open(args.sweep, "w") as fh:
                     json.dump(table, fh, indent=1)
 
+        if world == 1 and not args.no_compare and args.robot == "talos" and not f32 and B == 1024:
+            try:  # BASELINE configs 3 and 5, recorded by the same command (bounded: a few seconds each)
+                result["other_configs"] = other_configs(local_rank, torch, not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                result["other_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                result["dense_seam"] = dense_seam(local_rank, st, inputs, not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                result["dense_seam"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
         if not args.no_cpu_baseline and world == 1:
             # the oracle is the checker here and the reported CPU baseline -- never the thing shipped.  One call per figure:
             # work items from one counter, per-thread workspace, the clock inside the C driver between the threads' common
@@ -590,12 +743,23 @@ def main():
             multi = B * reps / sm
             ok = ref["status"] == 0
             xs = np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
+            native = None
+            try:  # SURVEY 8(d) asks for -O3 -march=native: the same C file built that way, timed the same way (the default build is
+                # the reproducibility build: -march=x86-64-v3 -ffp-contract=off, bit-identical across hosts)
+                sn1, _ = oracle.tick_batch_timed(st, sub, nthreads=1, reps=1, native=True)
+                snp, _ = oracle.tick_batch_timed(st, cpu_in, nthreads=cores, reps=1, native=True)
+                nreps = int(max(1, min(4096, 0.5 * budget / max(snp, 1e-6))))
+                snm, refn = oracle.tick_batch_timed(st, cpu_in, nthreads=cores, reps=nreps, native=True)
+                native = {"value": B * nreps / snm, "single_thread": nsamp / sn1, "cores": cores, "flags": oracle.NATIVE_CFLAGS,
+                          "max_rel_dx_vs_default_build": float((np.abs(refn["x"][:nsamp] - ref["x"]).max(axis=1) / xs).max())}
+            except Exception as e:  # noqa: BLE001
+                native = {"error": "%s: %s" % (type(e).__name__, e)}
             result["cpu_baseline"] = {
                 "value": multi, "unit": "QP/s", "cores": cores, "kind": "port",
                 "sample": "%d passes over the %d QPs of the last timed tick on %d pthreads (%.1f s); single thread %.0f QP/s on %d QPs" %
                           (reps, B, cores, sm, single, nsamp),
                 "single_thread": single, "scaling_efficiency": multi / (single * cores), "cpu_model": cpu_model(),
-                "cores_note": cores_note,
+                "cores_note": cores_note, "flags": oracle.DEFAULT_CFLAGS, "native_build": native,
             }
             result["parity"] = {
                 "sample": nsamp, "tick": int(last_tick),

@@ -46,6 +46,8 @@ def lib():
     _lib.ncclCommInitRank.restype = C.c_int
     _lib.ncclCommDestroy.argtypes = [C.c_void_p]
     _lib.ncclCommDestroy.restype = C.c_int
+    _lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    _lib.ncclCommCount.restype = C.c_int
     _lib.ncclGetErrorString.argtypes = [C.c_int]
     _lib.ncclGetErrorString.restype = C.c_char_p
     return _lib
@@ -82,6 +84,13 @@ def comm_init_rank(uid: bytes, nranks: int, rank: int) -> int:
     comm = C.c_void_p()
     _check(lib().ncclCommInitRank(C.byref(comm), int(nranks), u, int(rank)), "ncclCommInitRank")
     return int(comm.value)
+
+
+def comm_count(comm: int) -> int:
+    """ncclCommCount: how many ranks RCCL itself says the communicator spans (bench.py puts it into config.rccl_nranks)"""
+    n = C.c_int(-1)
+    _check(lib().ncclCommCount(C.c_void_p(comm), C.byref(n)), "ncclCommCount")
+    return int(n.value)
 
 
 def comm_destroy(comm: int):

@@ -62,6 +62,22 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+DEFAULT_CFLAGS = "-O3 -march=x86-64-v3 -ffp-contract=off (reproducibility build: bit-identical across hosts; the checker)"
+NATIVE_CFLAGS = "-O3 -march=native (SURVEY 8(d)'s timing build; built on the host that times it, never the checker)"
+_NATIVE_PATH = os.path.join(_HERE, "_build", "libwbc_oracle_native.so")
+_native = None
+
+
+def native_lib():
+    """The same C files built -O3 -march=native ON THIS HOST (the GPU box's CPU differs from the container's), for
+    bench.py's cpu_baseline.native_build only."""
+    global _native
+    if _native is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"], stdout=subprocess.DEVNULL)
+        _native = C.CDLL(_NATIVE_PATH)
+    return _native
+
+
 _lib = None
 
 
@@ -180,7 +196,7 @@ def tick_batch(st, inputs: Dict[str, np.ndarray], nthreads: int = 1):
     return dict(x=x, tau=tau[:, :st.na], status=status, iters=iters)
 
 
-def tick_batch_timed(st, inputs: Dict[str, np.ndarray], nthreads: int = 1, reps: int = 1):
+def tick_batch_timed(st, inputs: Dict[str, np.ndarray], nthreads: int = 1, reps: int = 1, native: bool = False):
     """`reps` passes over the batch on `nthreads` threads; returns (seconds inside the C driver, dict of pass 0's outputs).
     The clock runs from the threads' common start line to the last thread's end (wbco_tick_batch_timed)."""
     ost = OracleStructure(st)
@@ -190,7 +206,7 @@ def tick_batch_timed(st, inputs: Dict[str, np.ndarray], nthreads: int = 1, reps:
     status = np.zeros(batch, np.int32); iters = np.zeros(batch, np.int32)
     bin_ = _BatchInputs(*[_dp(arrs[k]) for k in _FIELDS])
     bout = _BatchOutputs(_dp(x), _dp(tau), _ip(status), _ip(iters))
-    f = lib().wbco_tick_batch_timed
+    f = (native_lib() if native else lib()).wbco_tick_batch_timed
     f.restype = C.c_double
     secs = f(C.byref(ost.c), int(batch), C.byref(bin_), C.byref(bout), int(nthreads), int(reps))
     if secs < 0.0:

@@ -25,6 +25,11 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
+    print(json.dumps(run(args)), flush=True)
+
+
+def run(args):
+    """args: .batch, .steps, .no_parity -> the result dict (bench.py calls this for its `other_configs.config5_ragged`)"""
     import torch
     from inria_wbc_amd import capi, shard, structure, synth
     dev = torch.device("cuda", 0)
@@ -81,8 +86,8 @@ def main():
             worst = max(worst, float((np.abs(x - ref["x"]).max(axis=1) / np.maximum(1.0, np.abs(ref["x"]).max(axis=1)))[ok].max()))
             same.append(bool(np.array_equal(g[3]["status"][:ns].cpu().numpy(), ref["status"])))
         res["parity"] = {"max_rel_dx": worst, "status_equal": all(same), "sample_per_structure": 64}
-    print(json.dumps(res), flush=True)
     h.close()
+    return res
 
 
 if __name__ == "__main__":
