@@ -222,7 +222,7 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
     if (F.neq > 0 && 256 + (n + 4) * F.ldb + 8 > rs) rs = 256 + (n + 4) * F.ldb + 8; // N = CE', then B = J0'N
     {   // the inequality loop keeps Ri (packed, n - neq columns) and the 2 (n - neq) rotation coefficients of a drop there
         const int mmax = n - F.neq;
-        const int need = (((mmax + 1) * (mmax + 4) / 2 + 1) & ~1) + 2 * mmax + 4;
+        const int need = (((mmax + 1) * (mmax + 4) / 2 + 1) & ~1) + 2 * mmax + 16 + F.nc * 34 * 12 + 2; // + the friction rows' table
         if (need > rs) rs = need;
     }
     D.o_R = take(rs);
