@@ -508,6 +508,8 @@ def main():
         compact = per_cu >= 2 or layout["lds_bytes"] <= 80 * 1024
         tname = "float" if f32 else "double"
         kernel = "wbcqp::%s<%s, %s>" % ("solve_queue_kernel" if queued else "solve_kernel", tname, "true" if compact and not (base_flags & capi.FLAG_FULL_LDS) else "false")
+        if layout.get("wave_per_qp") and not (base_flags & capi.FLAG_WORKGROUP_PER_QP):
+            kernel = "wbcqp::solve_small_kernel<%s>" % tname  # one wavefront per QP (csrc/wbcqp_small.hpp)
         result = {
             "metric": "QP solves/sec (Talos ~50-var WBC tick)" if args.robot == "talos" else "QP solves/sec (%s)" % args.robot,
             "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

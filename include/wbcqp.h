@@ -116,6 +116,10 @@ typedef struct {
     int32_t lds_bytes;         /* dynamic LDS one QP (one 256-thread workgroup) needs */
     int32_t waves_per_cu;      /* resident QPs (workgroups) per CU that LDS admits */
     int64_t algorithmic_bytes; /* compact in+out bytes per QP at WBCQP_F64 */
+    int32_t wave_per_qp;       /* 1: the structure runs one WAVEFRONT per QP (n <= 16, fixed base, no contacts, bounds only: Franka, Tiago),
+                                  four QPs per workgroup, 7.7 KB of LDS per QP; lds_bytes / waves_per_cu then describe the four-wave
+                                  kernel that WBCQP_FLAG_WORKGROUP_PER_QP selects */
+    int32_t reserved_;
 } wbcqp_layout;
 
 /*
@@ -165,6 +169,9 @@ typedef struct {
                                     contacts (every stack the reference ships) use the compact layout -- half the LDS, two
                                     QPs resident per CU; same algorithm, results agree to rounding */
 
+#define WBCQP_FLAG_WORKGROUP_PER_QP 32 /* keep the small structures (n <= 16 without contacts: Franka, Tiago) on the four-wave kernels too.
+                                     Default (0): one WAVEFRONT per QP for them, four QPs per 256-thread workgroup and no workgroup
+                                     barrier (csrc/wbcqp_small.hpp); in a ragged launch they go out as a launch of their own */
 #define WBCQP_FLAG_REFRESH_SHIFT 8
 #define WBCQP_FLAG_REFRESH(n) (((n) & 0xff) << WBCQP_FLAG_REFRESH_SHIFT) /* renew the launch order every n-th launch of a shape
                                     (1: after every launch; 0: the default, 4).  Between renewals the same order is used:

@@ -55,7 +55,7 @@ class CStructure(C.Structure):
 class CLayout(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n", "neq", "nin", "nin2", "r1", "len_M", "len_h", "len_A", "len_b1", "len_Ac",
                                          "len_bc", "len_blb", "len_bub", "len_tlb", "len_tub", "len_w", "lds_bytes",
-                                         "waves_per_cu")] + [("algorithmic_bytes", C.c_int64)]
+                                         "waves_per_cu")] + [("algorithmic_bytes", C.c_int64), ("wave_per_qp", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class CInputs(C.Structure):
@@ -266,6 +266,7 @@ FLAG_INDEX_ORDER = 1  # wbcqp_desc.flags: launch in index order (default: longes
 FLAG_NO_PACKING = 4   # wbcqp_desc.flags: plain longest-first order for the queue (default: bin-packed order for small launches)
 FLAG_QUEUE = 8        # wbcqp_desc.flags: the queue also when several workgroups share a CU (default there: hardware dispatch)
 FLAG_FULL_LDS = 16    # wbcqp_desc.flags: keep the one-QP-per-CU LDS layout (default: compact layout, two QPs per CU, where eligible)
+FLAG_WORKGROUP_PER_QP = 32  # wbcqp_desc.flags: four waves per QP also for n <= 16 (default there: one wavefront per QP, wbcqp_small.hpp)
 FLAG_HW_DISPATCH = 2  # wbcqp_desc.flags: one workgroup per QP through the hardware dispatcher (default: resident workgroups + queue)
 
 

@@ -7,6 +7,7 @@
 #include "wbcqp_device.hpp"
 #include "wbcqp_terms.hpp"
 #include "wbcqp_dense.hpp"
+#include "wbcqp_small.hpp"
 
 #include "../../include/wbcqp.h"
 
@@ -34,6 +35,7 @@ struct Slot {
     std::vector<void*> allocs;  // device arrays owned by this slot
     wbcqp_layout layout{};      // what wbcqp_layout_of reports: the compact layout where the structure is eligible
     int lds_full = 0, lds_cp = 0;
+    bool small = false;         // eligible for the one-wavefront-per-QP kernel (wbcqp_small.hpp)
     bool has_model = false;     // wbcqp_set_model: tree + task bindings for wbcqp_problem_data
     TermsDev terms{};
     std::vector<void*> model_allocs;
@@ -123,6 +125,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
     if (st->n_dense < 0 || st->n_sel < 0 || st->n_tasks <= 0 || st->n_bound < 0) { why = "bad level-1 sizes"; return WBCQP_ERR_INVALID; }
     if (st->n_ineq_blocks < 0 || st->n_ineq_blocks > WBCQP_MAX_INEQ_BLOCKS) { why = "too many inequality blocks"; return WBCQP_ERR_INVALID; }
     std::memset(&D, 0, sizeof(D));
+    std::memset(&L, 0, sizeof(L));
     D.nv = st->nv; D.na = st->na; D.nc = st->nc; D.k = 12 * st->nc; D.n = D.nv + D.k; D.nu = D.nv - D.na;
     if (D.n > WBCQP_MAX_VARS) { why = "n = nv + 12 nc exceeds WBCQP_MAX_VARS"; return WBCQP_ERR_UNSUPPORTED; }
     if (D.nv > 64) { why = "nv exceeds 64 (the dv block is factorised on a 64 x 64 register grid)"; return WBCQP_ERR_UNSUPPORTED; }
@@ -203,6 +206,17 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
 
 // The compact LDS layout of an eligible structure (wbcqp_compact.hpp): J region | R region | vectors | ints; everything
 // else is staged inside the first two while they are idle, or never enters LDS.  Returns false when not eligible.
+// one wavefront per QP (wbcqp_small.hpp): fixed base, no contacts, n = nv <= 16, bounds as the only inequality rows
+bool small_ok(const DevStruct& D, const HostBlocks& HB)
+{
+    if (!(D.nc == 0 && D.nu == 0 && D.neq == 0 && D.n == D.nv && D.n >= 1 && D.n <= 16 && D.na <= 16 && D.n_dense <= 16 && D.n_sel <= 16 &&
+          D.n_tasks >= 1 && D.n_tasks <= 16 && D.n_bound <= 16 && D.nin2 <= 32 && D.r1 >= 1 && D.r1 <= 32 && !D.act_bounds))
+        return false;
+    for (int b = 0; b < HB.n_blocks; ++b)
+        if (HB.blk_kind[b] != WBCQP_INEQ_BOUNDS) return false;
+    return true;
+}
+
 bool derive_compact(const DevStruct& F, DevStruct& D)
 {
     D = F;
@@ -402,6 +416,19 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     return WBCQP_OK;
 }
 
+// the small structures of a launch: one wavefront per QP, four per workgroup, in table order (no launch order: the QPs are
+// short and alike, and 32 of them are resident per CU)
+template <typename TI>
+int launch_small(wbcqp_handle* h, GroupTable<TI>& tab, int total, hipStream_t stream)
+{
+    if (total == 0) return WBCQP_OK;
+    tab.order = nullptr;
+    const int lds_bytes = kWaves * sm::COUNT * (int)sizeof(double);
+    hipLaunchKernelGGL((solve_small_kernel<TI>), dim3((unsigned)((total + kWaves - 1) / kWaves)), dim3(kThreads), lds_bytes, stream, tab, total);
+    HIP_TRY(h, hipGetLastError());
+    return WBCQP_OK;
+}
+
 int ensure(wbcqp_handle* h, Staging& s, size_t bytes)
 {
     if (s.bytes >= bytes) return WBCQP_OK;
@@ -431,6 +458,7 @@ int wbcqp_layout_of(const wbcqp_structure* st, wbcqp_layout* out)
     if (rc != WBCQP_OK) return fail(nullptr, rc, why);
     DevStruct C;
     if (derive_compact(D, C)) set_lds(L, C.lds_doubles * 8);
+    L.wave_per_qp = small_ok(D, HB) ? 1 : 0;
     if (out) *out = L;
     return WBCQP_OK;
 }
@@ -558,6 +586,8 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
         s.lds_cp = s.host_cp.lds_doubles * 8;
         set_lds(L, s.lds_cp);
     }
+    s.small = small_ok(D, HB);
+    L.wave_per_qp = s.small ? 1 : 0;
     s.layout = L;
     s.set = true;
     return WBCQP_OK;
@@ -569,16 +599,17 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
     if (n_groups < 0 || n_groups > kMaxGroups) return fail(h, WBCQP_ERR_INVALID, "n_groups must be in [0, 8]");
     if (n_groups > 0 && !groups) return fail(h, WBCQP_ERR_INVALID, "groups is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
-    int total = 0, lds = 0, used = 0;
-    GroupTable<double> t64{};
-    GroupTable<float> t32{};
+    int total = 0, lds = 0, used = 0, total_small = 0, used_small = 0;
+    GroupTable<double> t64{}, s64{};
+    GroupTable<float> t32{}, s32{};
+    const bool wave_per_qp = !(h->flags & WBCQP_FLAG_WORKGROUP_PER_QP) && !h->dbg; // (the stamped diagnostic build profiles the four-wave kernels)
     // the compact kernel runs a launch whose groups are all eligible; one group that is not puts the launch on the full layout
     bool compact = true;
     for (int g = 0; g < n_groups; ++g) {
         const wbcqp_group& G = groups[g];
         if (G.slot < 0 || G.slot >= WBCQP_MAX_STRUCTURES || !h->slots[G.slot].set)
             return fail(h, WBCQP_ERR_INVALID, "group uses a slot with no structure");
-        if (G.batch > 0 && !h->slots[G.slot].host_cp.compact) compact = false;
+        if (G.batch > 0 && !(wave_per_qp && h->slots[G.slot].small) && !h->slots[G.slot].host_cp.compact) compact = false;
     }
     for (int g = 0; g < n_groups; ++g) {
         const wbcqp_group& G = groups[g];
@@ -586,6 +617,13 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
         int rc = check_io(h, s, G.batch, &G.in, &G.out);
         if (rc != WBCQP_OK) return rc;
         if (G.batch == 0) continue;
+        if (wave_per_qp && s.small) { // one wavefront per QP: a launch of their own (wbcqp_small.hpp)
+            if (h->dtype == WBCQP_F64) fill_group(s64.g[used_small], s, false, G.batch, &G.in, &G.out);
+            else fill_group(s32.g[used_small], s, false, G.batch, &G.in, &G.out);
+            ++used_small;
+            total_small += G.batch;
+            continue;
+        }
         if (h->dtype == WBCQP_F64) { fill_group(t64.g[used], s, compact, G.batch, &G.in, &G.out); t64.g[used].dbg = h->dbg; }
         else { fill_group(t32.g[used], s, compact, G.batch, &G.in, &G.out); t32.g[used].dbg = h->dbg; }
         ++used;
@@ -595,8 +633,14 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
     }
     t64.n = used;
     t32.n = used;
+    s64.n = used_small;
+    s32.n = used_small;
     if (h->lds_pad > 0) lds = std::min(lds + h->lds_pad, 160 * 1024);
     hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (total_small > 0) {
+        const int rc = (h->dtype == WBCQP_F64) ? launch_small<double>(h, s64, total_small, hs) : launch_small<float>(h, s32, total_small, hs);
+        if (rc != WBCQP_OK) return rc;
+    }
     if (h->dtype == WBCQP_F64) return compact ? launch<double, true>(h, t64, total, lds, hs) : launch<double, false>(h, t64, total, lds, hs);
     return compact ? launch<float, true>(h, t32, total, lds, hs) : launch<float, false>(h, t32, total, lds, hs);
 }

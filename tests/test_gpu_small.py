@@ -1,0 +1,86 @@
+"""One wavefront per QP for the small structures (csrc/wbcqp_small.hpp: Franka etc/franka/tasks.yaml:1-10, Tiago etc/tiago/tasks.yaml)
+against the C oracle and against the four-wave kernels (WBCQP_FLAG_WORKGROUP_PER_QP) on the same inputs: batches that do not
+fill the last workgroup, bounds that bind (Tiago at high task noise: drops and re-picks), both boundary dtypes, and a ragged
+launch where the small groups go out as a launch of their own beside the humanoids."""
+import numpy as np
+import pytest
+
+from tests.util import TOL_F64
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(st, inputs, flags=0, dtype=None):
+    import torch
+    from inria_wbc_amd import capi
+    dtype = capi.F64 if dtype is None else dtype
+    tdt = torch.float64 if dtype == capi.F64 else torch.float32
+    ndt = np.float64 if dtype == capi.F64 else np.float32
+    B = next(iter(inputs.values())).shape[0]
+    dev = torch.device("cuda", 0)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v.astype(ndt))).to(dev) for k, v in inputs.items() if v.size}
+    h = capi.Handle(0, dtype, flags=flags)
+    h.set_structure(0, st)
+    d_out = dict(x=torch.full((B, st.n), float("nan"), dtype=tdt, device=dev), tau=torch.full((B, st.na), float("nan"), dtype=tdt, device=dev),
+                 status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.full((B,), -1, dtype=torch.int32, device=dev))
+    h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    h.close()
+    return {k: v.cpu().numpy() for k, v in d_out.items()}
+
+
+@pytest.mark.parametrize("robot,batch,noise", [("franka", 1, 0.5), ("franka", 7, 0.5), ("franka", 1025, 2.0), ("tiago", 5, 0.5), ("tiago", 258, 2.0),
+                                               ("tiago", 1024, 8.0), ("tiago", 333, 30.0)])
+def test_wave_per_qp_matches_oracle_and_the_four_wave_kernel(oracle_mod, robot, batch, noise):
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.STRUCTURES[robot]()
+    inputs = synth.generate(st, batch, synth.SEED_BASE[robot] + 777, task_noise=noise, p_bnd=0.3)
+    got = _solve(st, inputs)
+    wg = _solve(st, inputs, flags=capi.FLAG_WORKGROUP_PER_QP)
+    ref = oracle_mod.tick_batch(st, inputs)
+    assert np.array_equal(got["status"], ref["status"]) and np.array_equal(wg["status"], ref["status"])
+    ok = ref["status"] == 0
+    scale = np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
+    assert (np.abs(got["x"] - ref["x"]).max(axis=1)[ok] <= TOL_F64 * scale[ok]).all()
+    assert (np.abs(got["tau"] - ref["tau"]).max(axis=1)[ok] <= TOL_F64 * np.maximum(1.0, np.abs(ref["tau"]).max(axis=1))[ok]).all()
+    assert (np.abs(got["x"] - wg["x"]).max(axis=1)[ok] <= 1e-9 * scale[ok]).all()
+    assert (got["iters"] == ref["iters"]).mean() >= 0.9, (got["iters"][:20], ref["iters"][:20])
+    if robot == "tiago" and noise >= 8.0:
+        assert ref["iters"].max() >= 4  # bounds bind: the active-set loop and its drop path are exercised
+
+
+def test_wave_per_qp_f32_boundary(oracle_mod):
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.STRUCTURES["tiago"]()
+    inputs = synth.generate(st, 130, synth.SEED_BASE["tiago"] + 5, task_noise=4.0, p_bnd=0.3)
+    inputs = {k: v.astype(np.float32).astype(np.float64) for k, v in inputs.items()}
+    got = _solve(st, inputs, dtype=capi.F32)
+    ref = oracle_mod.tick_batch(st, inputs)
+    assert np.array_equal(got["status"], ref["status"])
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max())
+
+
+def test_ragged_launch_sends_small_groups_to_their_own_kernel(oracle_mod):
+    import torch
+    from inria_wbc_amd import capi, structure, synth
+    dev = torch.device("cuda", 0)
+    names = ["franka", "talos", "tiago", "icub"]
+    counts = [37, 9, 50, 11]
+    h = capi.Handle(0, capi.F64)
+    groups, refs = [], []
+    for slot, (name, cnt) in enumerate(zip(names, counts)):
+        st = structure.STRUCTURES[name]()
+        inp = synth.generate(st, cnt, synth.SEED_BASE["ragged"] + 31 * slot, task_noise=2.0, p_bnd=0.3)
+        d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items() if v.size}
+        d_out = dict(x=torch.full((cnt, st.n), float("nan"), dtype=torch.float64, device=dev), tau=torch.full((cnt, max(st.na, 1)), float("nan"), dtype=torch.float64, device=dev),
+                     status=torch.full((cnt,), -99, dtype=torch.int32, device=dev), iters=torch.full((cnt,), -1, dtype=torch.int32, device=dev))
+        h.set_structure(slot, st)
+        groups.append((slot, cnt, d_in, d_out))
+        refs.append((st, oracle_mod.tick_batch(st, inp)))
+    h.solve_ragged(groups, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for (slot, cnt, _, d_out), (st, ref) in zip(groups, refs):
+        assert np.array_equal(d_out["status"].cpu().numpy(), ref["status"]), st.name
+        x = d_out["x"].cpu().numpy()
+        assert np.abs(x[:, :st.nv] - ref["x"][:, :st.nv]).max() <= TOL_F64 * max(1.0, np.abs(ref["x"]).max()), st.name
+    h.close()
