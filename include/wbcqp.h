@@ -339,6 +339,9 @@ typedef struct {
     const void* q;    /* [batch][nq] */
     const void* v;    /* [batch][nv] */
     const void* ref;  /* [batch][nref] */
+    void* momentum;   /* OUT, may be NULL: [batch][6] centroidal momentum Ag(q) v of this state -- linear (3), then angular about the CoM
+                         (3): what Controller::_solve keeps as momentum_ = momentumJacobian(data).bottomRows(3) * dq
+                         (controller.cpp:245) is entries 3..5.  The rows kernel forms it anyway (momentum task, CoM velocity). */
 } wbcqp_state;
 
 /* Binds a tree and its task bindings to a slot that already holds the matching structure (same nv, na, nc, n_dense,

@@ -103,7 +103,7 @@ class CTaskMap(C.Structure):
 
 
 class CState(C.Structure):
-    _fields_ = [("q", C.c_void_p), ("v", C.c_void_p), ("ref", C.c_void_p)]
+    _fields_ = [("q", C.c_void_p), ("v", C.c_void_p), ("ref", C.c_void_p), ("momentum", C.c_void_p)]
 
 
 class CTickIO(C.Structure):
@@ -358,7 +358,8 @@ class Handle:
         """q, v, ref -> M, h, A, b1, Ac, bc, blb, bub on device tensors (wbcqp_problem_data)."""
         st = self._structs[slot]
         L = st.field_lengths()
-        cs = CState(state["q"].data_ptr(), state["v"].data_ptr(), state["ref"].data_ptr() if state.get("ref") is not None else None)
+        cs = CState(state["q"].data_ptr(), state["v"].data_ptr(), state["ref"].data_ptr() if state.get("ref") is not None else None,
+                    state["momentum"].data_ptr() if state.get("momentum") is not None else None)  # momentum: [batch, 6] output, optional
         cin = CInputs()
         for k in FIELDS:
             t = rows.get(k)
@@ -375,12 +376,15 @@ class Handle:
         q, v, ref = (np.ascontiguousarray(a, dtype=self.np_dtype) for a in (q, v, ref))
         batch = q.shape[0]
         out = {k: np.zeros((batch, max(L[k], 1)), self.np_dtype) for k in ROW_FIELDS}
-        cs = CState(q.ctypes.data, v.ctypes.data, ref.ctypes.data)
+        mom = np.zeros((batch, 6), self.np_dtype)
+        cs = CState(q.ctypes.data, v.ctypes.data, ref.ctypes.data, mom.ctypes.data)
         cin = CInputs()
         for k in FIELDS:
             setattr(cin, k, out[k].ctypes.data if k in ROW_FIELDS and L[k] else None)
         self._check(self.lib.wbcqp_problem_data_host(self._h, slot, batch, C.byref(cs), C.byref(cin)))
-        return {k: a[:, :L[k]] for k, a in out.items()}
+        res = {k: a[:, :L[k]] for k, a in out.items()}
+        res["momentum"] = mom  # centroidal momentum Ag v: linear, then angular about the CoM (controller.cpp:245 keeps the last three)
+        return res
 
     def _tick_io(self, slot: int, batch: int, state, rows, out, q_next, v_next, dt: float, q_solver=None) -> CTickIO:
         cin, cout = self._pack(slot, batch, rows, out)
@@ -409,7 +413,8 @@ class Handle:
                    iters=np.zeros(B, np.int32), q_next=np.zeros_like(q), v_next=np.zeros_like(v), q_solver=np.zeros_like(v))
         rows = {k: np.zeros((B, max(L[k], 1)), self.np_dtype) for k in ROW_FIELDS} if want_rows else {}
         io = CTickIO()
-        io.state = CState(q.ctypes.data, v.ctypes.data, ref.ctypes.data)
+        out["momentum"] = np.zeros((B, 6), self.np_dtype)
+        io.state = CState(q.ctypes.data, v.ctypes.data, ref.ctypes.data, out["momentum"].ctypes.data)
         cin = CInputs()
         for k in FIELDS:
             setattr(cin, k, None)

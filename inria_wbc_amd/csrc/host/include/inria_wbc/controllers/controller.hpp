@@ -7,6 +7,7 @@
 #ifndef IWBC_HIP_CONTROLLER_HPP
 #define IWBC_HIP_CONTROLLER_HPP
 
+#include <algorithm>
 #include <cmath>
 #include <memory>
 #include <string>
@@ -101,6 +102,9 @@ namespace inria_wbc {
                 dt_ = IWBC_CHECK(c["dt"].as<double>());
                 floating_base_ = IWBC_CHECK(c["floating_base"].as<bool>());
                 verbose_ = c["verbose"] ? c["verbose"].as<bool>() : false;
+                // controller.cpp:63,72 (the reference requires both keys; here they default to what a model without mimic joints has)
+                fb_joint_name_ = c["floating_base_joint_name"] ? c["floating_base_joint_name"].as<std::string>() : std::string("root_joint");
+                if (c["mimic_dof_names"]) mimic_dof_names_ = c["mimic_dof_names"].as<std::vector<std::string>>();
                 t_ = 0.0;
             }
             Controller(const Controller&) = delete;
@@ -160,12 +164,60 @@ namespace inria_wbc {
 
             // one row per instance (the reference returns one Eigen::VectorXd), in the reference's "DART" format
             // (controller.cpp:262-281): ndofs = nv entries; a floating base is [position(3), angle * axis(3)] in q and six
-            // leading zeros in tau.  There are no mimic joints in the stacks this facade loads, so filter_mimics is the identity.
-            const MatrixXd& tau() const { return tau_dart_; }
-            const MatrixXd& ddq() const { return a_tsid_; }
-            const MatrixXd& dq() const { return v_tsid_; }
-            const MatrixXd& q() const { return q_solver_; }
-            const MatrixXd& q_solver() const { return q_solver_; }
+            // leading zeros in tau.  filter_mimics (default true, as in the reference, controller.cpp:369-397) drops the columns of
+            // the joints named in CONTROLLER.mimic_dof_names: slice_vec(x, non_mimic_indexes_) per instance.
+            MatrixXd tau(bool filter_mimics = true) const { return filter_mimics ? filter_cmd(tau_dart_) : tau_dart_; }
+            MatrixXd ddq(bool filter_mimics = true) const { return filter_mimics ? filter_cmd(a_tsid_) : a_tsid_; }
+            MatrixXd dq(bool filter_mimics = true) const { return filter_mimics ? filter_cmd(v_tsid_) : v_tsid_; }
+            MatrixXd q(bool filter_mimics = true) const { return filter_mimics ? filter_cmd(q_solver_) : q_solver_; }
+            MatrixXd q_solver(bool filter_mimics = true) const { return filter_mimics ? filter_cmd(q_solver_) : q_solver_; }
+            // controller.cpp:245: momentum_ = momentumJacobian(data).bottomRows(3) * dq -- the angular momentum about the CoM of the
+            // state the last tick was solved at, one row per instance (zero until a tick has run on a model-driven source)
+            const MatrixXd& momentum() const { return momentum_; }
+            // controller.hpp:60-64,114-115 of the reference
+            const std::vector<std::string>& mimic_names() const { return mimic_dof_names_; }
+            const std::vector<int>& non_mimic_indexes() const { return non_mimic_indexes_; }
+            MatrixXd filter_cmd(const MatrixXd& cmd) const
+            {
+                if (non_mimic_indexes_.empty() || (int)non_mimic_indexes_.size() == cmd.cols) return cmd;
+                MatrixXd out(cmd.rows, (int)non_mimic_indexes_.size());
+                for (int i = 0; i < cmd.rows; ++i)
+                    for (size_t j = 0; j < non_mimic_indexes_.size(); ++j) out(i, (int)j) = cmd(i, non_mimic_indexes_[j]);
+                return out;
+            }
+            // Removes the universe and root (floating base) joint names (controller.cpp:316-331)
+            std::vector<std::string> controllable_dofs(bool filter_mimics = true) const
+            {
+                std::vector<std::string> out;
+                for (const auto& n : joint_names_)
+                    if (!filter_mimics || std::find(mimic_dof_names_.begin(), mimic_dof_names_.end(), n) == mimic_dof_names_.end()) out.push_back(n);
+                return out;
+            }
+            // Order of the floating base in q_ according to dart naming convention (controller.cpp:333-363)
+            std::vector<std::string> floating_base_dofs() const
+            {
+                if (!floating_base_) return {};
+                const std::string b = (fb_joint_name_ == "root_joint") ? std::string("rootJoint") : fb_joint_name_;
+                return {b + "_pos_x", b + "_pos_y", b + "_pos_z", b + "_rot_x", b + "_rot_y", b + "_rot_z"};
+            }
+            std::vector<std::string> all_dofs(bool filter_mimics = true) const
+            {
+                std::vector<std::string> all = floating_base_dofs(), ctl = controllable_dofs(filter_mimics);
+                all.insert(all.end(), ctl.begin(), ctl.end());
+                return all;
+            }
+            // controller.cpp:445-450 / controller.hpp:170-171: back to the state the last tick started from (the reference also
+            // restores pinocchio's data; here every tick recomputes the rigid-body terms from (q, dq) on the device)
+            void qp_step_back(const MatrixXd& q, const MatrixXd& dq)
+            {
+                IWBC_ASSERT(q.rows == batch_ && dq.rows == batch_ && q.cols == q_tsid_.cols && dq.cols == v_tsid_.cols, "qp_step_back: wrong size");
+                q_tsid_ = q;
+                v_tsid_ = dq;
+            }
+            void qp_step_back()
+            {
+                if (q_tsid_prev_.rows == batch_ && batch_ > 0) qp_step_back(q_tsid_prev_, v_tsid_prev_);
+            }
             // tsid's own forms: q with the base quaternion (nq = nv + 1 entries), tau of the actuated joints only (na entries)
             const MatrixXd& q_tsid() const { return q_tsid_; }
             const MatrixXd& tau_tsid() const { return tau_; }
@@ -192,7 +244,24 @@ namespace inria_wbc {
             virtual int _slot() const = 0;
             virtual const wbcqp_layout& _layout() const = 0;
 
-            void _solve() { _solve(q_tsid_, v_tsid_); }
+            void _solve() { _solve(MatrixXd(q_tsid_), MatrixXd(v_tsid_)); }
+
+            // tsid_joint_names_ = all_dofs(false), non_mimic_indexes_ = get_non_mimics_indexes() (controller.cpp:157-158,208-229):
+            // called by the derived controller once the model's joint names are known (without a model: no names, no mimic joints)
+            void _set_joint_names(const std::vector<std::string>& actuated_joint_names)
+            {
+                joint_names_ = actuated_joint_names;
+                const std::vector<std::string> tsid_joint_names = all_dofs(false);
+                std::vector<int> mimic_indexes;
+                for (const auto& m : mimic_dof_names_) {
+                    auto it = std::find(tsid_joint_names.begin(), tsid_joint_names.end(), m);
+                    IWBC_ASSERT(it != tsid_joint_names.end(), " joint ", m, " not found");
+                    mimic_indexes.push_back((int)std::distance(tsid_joint_names.begin(), it));
+                }
+                non_mimic_indexes_.clear();
+                for (int i = 0; i < (int)tsid_joint_names.size(); ++i)
+                    if (std::find(mimic_indexes.begin(), mimic_indexes.end(), i) == mimic_indexes.end()) non_mimic_indexes_.push_back(i);
+            }
 
             // Controller::_solve (controller.cpp:231-313) for B instances
             void _solve(const MatrixXd& q, const MatrixXd& dq)
@@ -212,6 +281,10 @@ namespace inria_wbc {
                                    in_.blb.data(), in_.bub.data(), in_.tlb.data(), in_.tub.data(), in_.w.data()};
                 wbcqp_outputs out = {x_.data(), tau_.data.data(), status_.data(), iters_.data(), objective_.data(), nullptr};
                 IWBC_ASSERT(q.cols == (floating_base_ ? nv + 1 : nv), "q must hold ", floating_base_ ? nv + 1 : nv, " entries per instance");
+                q_tsid_prev_ = q; // controller.cpp:237-241 (the reference keeps them when send_cmd_ is set; qp_step_back() returns here)
+                v_tsid_prev_ = dq;
+                momentum_ = MatrixXd(B, 3);
+                std::vector<double> mom6((size_t)B * 6, 0.0);
                 MatrixXd vnew(B, nv);
                 MatrixXd qnew(B, q.cols);
                 MatrixXd qsol(B, nv);
@@ -220,7 +293,7 @@ namespace inria_wbc {
                     // rows, QP and integration in one trip to the device: only the state and the references go up, the solution
                     // and the integrated state come back.  The rows stay on the device; cost() fetches them when somebody asks.
                     wbcqp_tick_io io{};
-                    io.state = {q.data.data(), dq.data.data(), source_->reference_data()};
+                    io.state = {q.data.data(), dq.data.data(), source_->reference_data(), mom6.data()};
                     io.rows = in;
                     io.rows.M = io.rows.h = io.rows.A = io.rows.b1 = io.rows.Ac = io.rows.bc = io.rows.blb = io.rows.bub = nullptr;
                     last_q_ = q;
@@ -232,6 +305,8 @@ namespace inria_wbc {
                     io.q_solver = qsol.data.data();
                     io.dt = dt_;
                     if (wbcqp_tick_host(handle_, _slot(), B, &io) != WBCQP_OK) IWBC_ERROR("wbcqp_tick_host failed: ", wbcqp_last_error(handle_));
+                    for (int i = 0; i < B; ++i)
+                        for (int k = 0; k < 3; ++k) momentum_(i, k) = mom6[(size_t)i * 6 + 3 + k];
                 }
                 else {
                     int rc = wbcqp_solve_batch_host(handle_, _slot(), B, &in, &out);
@@ -288,7 +363,10 @@ namespace inria_wbc {
             std::string base_path_, behavior_type_, solver_to_use_;
             int batch_ = 0;
 
-            MatrixXd q_tsid_, v_tsid_, a_tsid_, tau_, tau_dart_, q_solver_;
+            MatrixXd q_tsid_, v_tsid_, a_tsid_, tau_, tau_dart_, q_solver_, momentum_, q_tsid_prev_, v_tsid_prev_;
+            std::string fb_joint_name_;
+            std::vector<std::string> mimic_dof_names_, joint_names_; // joint_names_: the 1-dof joints in model order (no universe, no root)
+            std::vector<int> non_mimic_indexes_;
             std::vector<double> x_, objective_;
             VectorXi status_, iters_;
             std::vector<std::string> activated_contacts_, all_contacts_;

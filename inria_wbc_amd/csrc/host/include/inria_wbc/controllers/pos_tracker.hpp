@@ -28,6 +28,10 @@ namespace inria_wbc {
                     nv = robot_->nv();
                     na = robot_->na();
                     IWBC_ASSERT(robot_->floating_base() == floating_base_, "floating_base and the model disagree");
+                    {   // the 1-dof joints in model order: what tsid_joint_names_ holds behind the floating base (controller.cpp:157)
+                        const auto& jn = robot_->joint_names();
+                        _set_joint_names(std::vector<std::string>(jn.begin() + (floating_base_ ? 1 : 0), jn.end()));
+                    }
                     // create additional frames if needed (optional) (pos_tracker.cpp:51-55)
                     if (c["frames"]) {
                         auto ff = c["frames"].as<std::string>();
@@ -37,6 +41,7 @@ namespace inria_wbc {
                 else {
                     nv = IWBC_CHECK(c["nv"].as<int>());
                     na = IWBC_CHECK(c["na"].as<int>());
+                    IWBC_ASSERT(mimic_dof_names_.empty(), "mimic_dof_names needs the joint names of a model (CONTROLLER.model)");
                 }
                 closed_loop_ = c["closed_loop"] ? c["closed_loop"].as<bool>() : false;
 

@@ -6,6 +6,7 @@
 // With `-` for the batch file the controller must carry its own model (CONTROLLER.model): the rows come from the robot
 // state on the device (ModelSource), the loop is closed through the integrated state, and the final q can be written too.
 #include <algorithm>
+#include <cmath>
 #include <csignal>
 #include <cstdlib>
 #include <fstream>
@@ -84,6 +85,33 @@ int main(int argc, char** argv)
                 std::cout.precision(17);
                 std::cout << "cost com: " << pt->cost("com") << std::endl; // |A ddq - b| of the CoM rows, last tick (controller.hpp:148-152)
             }
+        {   // what a robot-side consumer reads each tick (reference: examples and robot_dart glue): the filtered command and momentum()
+            const auto tau_cmd = controller->tau(), q_cmd = controller->q();
+            std::cout << "command columns: " << tau_cmd.cols << " of " << controller->tau(false).cols << " dofs ("
+                      << controller->mimic_names().size() << " mimic joints filtered)" << std::endl;
+            const auto& mom = controller->momentum();
+            if (mom.rows > 0) {
+                std::cout.precision(17);
+                std::cout << "momentum[0]: " << mom(0, 0) << " " << mom(0, 1) << " " << mom(0, 2) << std::endl;
+            }
+            if (const char* fp = std::getenv("IWBC_DUMP_COMMAND")) {
+                std::ofstream f(fp, std::ios::binary);
+                f.write(reinterpret_cast<const char*>(tau_cmd.data.data()), (std::streamsize)(tau_cmd.data.size() * sizeof(double)));
+                f.write(reinterpret_cast<const char*>(q_cmd.data.data()), (std::streamsize)(q_cmd.data.size() * sizeof(double)));
+            }
+            if (std::getenv("IWBC_STEP_BACK")) { // qp_step_back(): the next tick starts from the state this one started from
+                const auto q_before = controller->q_tsid();
+                controller->qp_step_back();
+                const auto& q_after = controller->q_tsid();
+                double moved = 0.0;
+                for (size_t i = 0; i < q_after.data.size(); ++i) moved = std::max(moved, std::fabs(q_after.data[i] - q_before.data[i]));
+                controller->update(controllers::SensorData{}); // same references as the tick just undone (the behavior is not advanced)
+                const auto& q_redo = controller->q_tsid();
+                double diff = 0.0;
+                for (size_t i = 0; i < q_redo.data.size(); ++i) diff = std::max(diff, std::fabs(q_redo.data[i] - q_before.data[i]));
+                std::cout << "step back moved q by " << moved << ", redoing the tick differs from the first time by " << diff << std::endl;
+            }
+        }
         if (argc > 5) {
             std::ofstream f(argv[5], std::ios::binary);
             const auto& tau = controller->tau_tsid(); // na entries per instance (tau() pads a floating base with six zeros)

@@ -1163,6 +1163,7 @@ int wbcqp_problem_data(wbcqp_handle* h, int slot, int batch, const wbcqp_state* 
         a.q = static_cast<const double*>(st->q); a.v = static_cast<const double*>(st->v); a.ref = static_cast<const double*>(st->ref);
         a.M = (double*)rows->M; a.h = (double*)rows->h; a.A = (double*)rows->A; a.b1 = (double*)rows->b1; a.Ac = (double*)rows->Ac;
         a.bc = (double*)rows->bc; a.blb = (double*)rows->blb; a.bub = (double*)rows->bub;
+        a.momentum = static_cast<double*>(st->momentum);
         hipLaunchKernelGGL(terms_kernel<double>, dim3(batch), dim3(kTermsThreads), lds, sm, a);
     }
     else {
@@ -1171,6 +1172,7 @@ int wbcqp_problem_data(wbcqp_handle* h, int slot, int batch, const wbcqp_state* 
         a.q = static_cast<const float*>(st->q); a.v = static_cast<const float*>(st->v); a.ref = static_cast<const float*>(st->ref);
         a.M = (float*)rows->M; a.h = (float*)rows->h; a.A = (float*)rows->A; a.b1 = (float*)rows->b1; a.Ac = (float*)rows->Ac;
         a.bc = (float*)rows->bc; a.blb = (float*)rows->blb; a.bub = (float*)rows->bub;
+        a.momentum = static_cast<float*>(st->momentum);
         hipLaunchKernelGGL(terms_kernel<float>, dim3(batch), dim3(kTermsThreads), lds, sm, a);
     }
     HIP_TRY(h, hipGetLastError());
@@ -1198,6 +1200,8 @@ int wbcqp_problem_data_host(wbcqp_handle* h, int slot, int batch, const wbcqp_st
     void* odst[8] = {(void*)rows->M, (void*)rows->h, (void*)rows->A, (void*)rows->b1, (void*)rows->Ac, (void*)rows->bc, (void*)rows->blb, (void*)rows->bub};
     size_t ooff[8], out_bytes = 0;
     for (int f = 0; f < 8; ++f) { ooff[f] = out_bytes; out_bytes += al((size_t)olen[f] * batch * es); }
+    const size_t omom = out_bytes;
+    out_bytes += al((size_t)6 * batch * es);
     int rc = ensure(h, h->stage_in, in_bytes + 256);
     if (rc != WBCQP_OK) return rc;
     rc = ensure(h, h->stage_out, out_bytes + 256);
@@ -1208,7 +1212,7 @@ int wbcqp_problem_data_host(wbcqp_handle* h, int slot, int batch, const wbcqp_st
         if (ilen[f] > 0 && !isrc[f]) return fail(h, WBCQP_ERR_INVALID, "state arrays q / v / ref are required");
         if (ilen[f] > 0) HIP_TRY(h, hipMemcpy(din + ioff[f], isrc[f], (size_t)ilen[f] * batch * es, hipMemcpyHostToDevice));
     }
-    wbcqp_state ds = {din + ioff[0], din + ioff[1], din + ioff[2]};
+    wbcqp_state ds = {din + ioff[0], din + ioff[1], din + ioff[2], st->momentum ? dout + omom : nullptr};
     wbcqp_inputs dr{};
     dr.M = dout + ooff[0]; dr.h = dout + ooff[1]; dr.A = dout + ooff[2]; dr.b1 = dout + ooff[3]; dr.Ac = dout + ooff[4];
     dr.bc = dout + ooff[5]; dr.blb = dout + ooff[6]; dr.bub = dout + ooff[7];
@@ -1219,6 +1223,7 @@ int wbcqp_problem_data_host(wbcqp_handle* h, int slot, int batch, const wbcqp_st
         if (olen[f] > 0 && !odst[f]) return fail(h, WBCQP_ERR_INVALID, "row arrays M, h, A, b1, Ac, bc, blb, bub are required");
         if (olen[f] > 0) HIP_TRY(h, hipMemcpy(odst[f], dout + ooff[f], (size_t)olen[f] * batch * es, hipMemcpyDeviceToHost));
     }
+    if (st->momentum) HIP_TRY(h, hipMemcpy(st->momentum, dout + omom, (size_t)6 * batch * es, hipMemcpyDeviceToHost));
     return WBCQP_OK;
 }
 
@@ -1271,7 +1276,7 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     for (int f = 0; f < 8; ++f) { roff[f] = in_bytes; in_bytes += al((size_t)rlen[f] * B * es); }
     const size_t o_x = 0, o_tau = o_x + al((size_t)L.n * B * es), o_obj = o_tau + al((size_t)s.host.na * B * es), o_st = o_obj + al(B * es),
                  o_it = o_st + al(B * 4), o_na = o_it + al(B * 4), o_qn = o_na + al(B * 4), o_vn = o_qn + al((size_t)T.nq * B * es),
-                 o_qs = o_vn + al((size_t)T.nv * B * es), out_bytes = o_qs + al((size_t)T.nv * B * es);
+                 o_qs = o_vn + al((size_t)T.nv * B * es), o_mom = o_qs + al((size_t)T.nv * B * es), out_bytes = o_mom + al((size_t)6 * B * es);
     int rc = ensure(h, h->stage_in, in_bytes + 256);
     if (rc != WBCQP_OK) return rc;
     rc = ensure(h, h->stage_out, out_bytes + 256);
@@ -1281,7 +1286,7 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     for (int f = 0; f < 6; ++f)
         if (ilen[f] > 0) HIP_TRY(h, hipMemcpyAsync(din + ioff[f], isrc[f], (size_t)ilen[f] * B * es, hipMemcpyHostToDevice, nullptr));
     wbcqp_tick_io d{};
-    d.state = {din + ioff[0], din + ioff[1], din + ioff[2]};
+    d.state = {din + ioff[0], din + ioff[1], din + ioff[2], io->state.momentum ? dout + o_mom : nullptr};
     d.rows.M = din + roff[0]; d.rows.h = din + roff[1]; d.rows.A = din + roff[2]; d.rows.b1 = din + roff[3]; d.rows.Ac = din + roff[4];
     d.rows.bc = din + roff[5]; d.rows.blb = din + roff[6]; d.rows.bub = din + roff[7];
     d.rows.tlb = din + ioff[3]; d.rows.tub = din + ioff[4]; d.rows.w = din + ioff[5];
@@ -1301,6 +1306,7 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     HIP_TRY(h, hipMemcpyAsync(io->q_next, d.q_next, (size_t)T.nq * B * es, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipMemcpyAsync(io->v_next, d.v_next, (size_t)T.nv * B * es, hipMemcpyDeviceToHost, nullptr));
     if (io->q_solver) HIP_TRY(h, hipMemcpyAsync(io->q_solver, d.q_solver, (size_t)T.nv * B * es, hipMemcpyDeviceToHost, nullptr));
+    if (io->state.momentum) HIP_TRY(h, hipMemcpyAsync(io->state.momentum, d.state.momentum, (size_t)6 * B * es, hipMemcpyDeviceToHost, nullptr));
     for (int f = 0; f < 8; ++f)
         if (rlen[f] > 0 && rdst[f]) HIP_TRY(h, hipMemcpyAsync(rdst[f], din + roff[f], (size_t)rlen[f] * B * es, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipStreamSynchronize(nullptr));

@@ -71,6 +71,7 @@ struct TermsArgs {
     TermsDev T;
     const TI *q, *v, *ref;
     TI *M, *h, *A, *b1, *Ac, *bc, *blb, *bub;
+    TI* momentum; // [batch][6] centroidal momentum (linear, angular about the CoM), or null
     int batch;
     long long* dbg; // per-instance phase cycle counters, only written by the WBCQP_STAMPS diagnostic build
 };
@@ -702,6 +703,12 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     const double mass = tot[0], imass = 1.0 / mass;
     const V3 com = imass * ld3(tot + 1);
     const V3 htl = ld3(tots), hta = ld3(tots + 3);
+    if (args.momentum && tid == 0) { // Ag v: total momentum, the angular part taken about the CoM (controller.cpp:245 reads its last three)
+        const V3 La = hta - cross(com, htl);
+        TI* mo = args.momentum + (size_t)inst * 6;
+        mo[0] = (TI)htl.x; mo[1] = (TI)htl.y; mo[2] = (TI)htl.z;
+        mo[3] = (TI)La.x; mo[4] = (TI)La.y; mo[5] = (TI)La.z;
+    }
     const bool colv = lane < nv;
     const int cj = colv ? lane : 0;
     const int bj = ip[T.i_bodyof + cj], lastj = ip[T.i_last + bj];

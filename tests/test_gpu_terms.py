@@ -98,6 +98,21 @@ def test_problem_data_parity(handle, rbd, name):
     _compare(dev, ora)
 
 
+@pytest.mark.parametrize("name", ["talos", "icub"])
+def test_momentum_output_is_Ag_v(handle, rbd, name):
+    """wbcqp_state.momentum = the centroidal momentum Ag(q) v of the tick's state (linear, then angular about the CoM): its last
+    three entries are what the reference keeps as momentum_ (controller.cpp:245, momentumJacobian(data).bottomRows(3) * dq)."""
+    m, st, tm = CASES[name]()
+    handle.set_structure(3, st)
+    handle.set_model(3, m, tm)
+    s = mdl.sample_states(m, tm, 24, 35_000, q_noise=0.2, v_noise=0.5)
+    dev = handle.problem_data_host(3, s["q"], s["v"], s["ref"])
+    for i in range(24):
+        t = rbd.rbd_terms(m, s["q"][i], s["v"][i])
+        want = t["Ag"] @ s["v"][i]
+        assert np.abs(dev["momentum"][i] - want).max() <= 1e-10 * max(1.0, np.abs(want).max()), (i, dev["momentum"][i], want)
+
+
 def test_problem_data_far_from_the_origin(handle, rbd):
     """The device works about the floating base: a robot 1 km away must give the same rows as the oracle's absolute arithmetic
     (up to what the oracle itself loses there)."""

@@ -119,6 +119,65 @@ def test_qp_timer_test_closed_loop_on_the_model(host_build, oracle_mod, tmp_path
 
 
 @pytest.mark.gpu
+def test_mimic_filter_momentum_and_step_back(host_build, oracle_mod, tmp_path):
+    """What the reference's robot-side consumers read after a tick (controller.cpp:208-229,245,369-397,445-450): tau() / q() with the
+    mimic joints of CONTROLLER.mimic_dof_names filtered out (the real Talos has twelve: etc/talos/talos_pos_tracker.yaml:20-31),
+    momentum() = the angular momentum about the CoM of the state the tick was solved at, and qp_step_back()."""
+    from inria_wbc_amd import model as mdl, structure, trajs
+    from oracle import rbd
+    mimics = ["gripper_left_inner_double_joint", "gripper_left_fingertip_1_joint", "gripper_left_fingertip_2_joint",
+              "gripper_left_inner_single_joint", "gripper_left_fingertip_3_joint", "gripper_left_motor_single_joint",
+              "gripper_right_inner_double_joint", "gripper_right_fingertip_1_joint", "gripper_right_fingertip_2_joint",
+              "gripper_right_inner_single_joint", "gripper_right_fingertip_3_joint", "gripper_right_motor_single_joint"]
+    base = open(os.path.join(ROOT, "configs/talos/pos_tracker_model.yaml")).read()
+    for key in ("model", "frames", "tasks"):  # the harness sets base_path to the configuration file's directory: absolute paths
+        base = base.replace("  %s: " % key, "  %s: %s/" % (key, os.path.join(ROOT, "configs/talos")))
+    cfg = tmp_path / "pos_tracker_mimic.yaml"
+    cfg.write_text(base + "  floating_base_joint_name: root_joint\n  mimic_dof_names: [%s]\n" % ", ".join('"%s"' % m for m in mimics))
+    n_ticks = 6
+    tau_path, q_path, cmd_path = str(tmp_path / "tau.bin"), str(tmp_path / "q.bin"), str(tmp_path / "cmd.bin")
+    env = dict(os.environ, IWBC_DUMP_COMMAND=cmd_path, IWBC_STEP_BACK="1")
+    r = subprocess.run([host_build["qp_timer_test"], str(cfg), os.path.join(ROOT, "configs/talos/squat.yaml"), "-", str(n_ticks), tau_path, "0", q_path],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = mdl.talos_like()
+    st = structure.talos_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    assert "command columns: %d of %d dofs (12 mimic joints filtered)" % (st.nv - 12, st.nv) in r.stdout, r.stdout
+    # the filtered command = the non-mimic columns of [0 x 6, tau_tsid] (the dump of tau_tsid is taken after the extra tick of the
+    # step-back check, so the command is compared with the oracle loop instead)
+    names = ["rootJoint_pos_x", "rootJoint_pos_y", "rootJoint_pos_z", "rootJoint_rot_x", "rootJoint_rot_y", "rootJoint_rot_z"] + list(m.joint_names[1:])
+    assert len(names) == st.nv
+    keep = [i for i, nme in enumerate(names) if nme not in mimics]
+    cmd = np.fromfile(cmd_path, dtype=np.float64)
+    ncol = st.nv - 12
+    tau_cmd, q_cmd = cmd[:8 * ncol].reshape(8, ncol), cmd[8 * ncol:].reshape(8, ncol)
+    s = mdl.sample_states(m, tm, 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+    oq, ov, oref = s["q"], s["v"], s["ref"]
+    com_blk = next(b for b in tm.blocks if b.kind == mdl.T_COM)
+    pos, vel, acc = trajs.move_com_stream(m.com(m.q0), [[0.0, 0.0, -0.2]], "001", tm.dt, 2.0, loop=True, absolute=False)
+    tl, tu, w = -m.tau_max[None], m.tau_max[None], st.default_weights[None]
+    for k in range(n_ticks):
+        oref[:, com_blk.ref:com_blk.ref + 9] = np.concatenate([pos[k], vel[k], acc[k]])
+        rows = rbd.task_rows(m, tm, st, oq, ov, oref)
+        oo = oracle_mod.tick_batch(st, dict(rows, tlb=tl, tub=tu, w=w))
+        q_start, v_start = oq.copy(), ov.copy()
+        nxt = oracle_mod.integrate(True, tm.dt, oq, ov, oo["x"][:, :st.nv])
+        oq, ov = nxt["q_next"], nxt["v_next"]
+    tau_full = np.concatenate([np.zeros(6), oo["tau"][0]])
+    assert np.abs(tau_cmd[0] - tau_full[keep]).max() < 1e-6 * max(1.0, np.abs(tau_full).max())
+    assert np.abs(q_cmd[0] - nxt["q_solver"][0][keep]).max() < 1e-8
+    # momentum(): Ag(q) v at the state the last tick was solved at, angular part
+    want = (rbd.rbd_terms(m, q_start[0], v_start[0])["Ag"] @ v_start[0])[3:]
+    got = np.array([float(x) for x in [ln for ln in r.stdout.splitlines() if ln.startswith("momentum[0]:")][0].split(":")[1].split()])
+    assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max()), (got, want)
+    # qp_step_back(): q returns to where the tick started and the redone tick lands where the first one did
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("step back moved q by")][0]
+    moved, diff = float(line.split("by")[1].split(",")[0]), float(line.rsplit("by", 1)[1])
+    assert moved > 0.0 and diff < 1e-12, line
+
+
+@pytest.mark.gpu
 def test_closed_loop_takes_reference_shaped_sensor_data(host_build, tmp_path):
     """Controller::update in closed loop (controller.cpp:161-205): the sensor keys the reference requires are required here,
     a floating base arrives split into floating_base_position / _velocity + joints, and feeding the controller's own
