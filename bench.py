@@ -287,6 +287,53 @@ def other_configs(local_rank, torch, parity=True):
     return out
 
 
+def warm_start(local_rank, torch, st, tick_dicts, new_out, B, cdt, base_flags, steps, inputs, b1_ticks, parity=True):
+    """The same tick stream with WBCQP_FLAG_WARM_START: the active set of an instance's previous tick (a 256-bit mask per instance that
+    stays on the device, in / out of every launch) goes first among the violated rows.  Not what the reference does -- reported
+    beside `value`.  The QP is strictly convex, so the solution is the cold start's up to rounding, EXCEPT where eiquadprog's own
+    stopping rule (|sum min(s, 0)| <= nIneq eps tr(H) tr(J) 100, about 0.3 for these stacks) ends the two pick orders on different
+    iterates: `parity` counts those QPs instead of hiding them."""
+    from inria_wbc_amd import capi
+    dev = torch.device("cuda", local_rank)
+    sp = torch.cuda.current_stream().cuda_stream
+    h = capi.Handle(device=local_rank, dtype=cdt, flags=base_flags | capi.FLAG_WARM_START)
+    h.set_structure(0, st)
+    out = new_out()
+    out["active_mask"] = torch.zeros(B, 8, dtype=torch.int32, device=dev)
+    nt = len(tick_dicts)
+    for t in range(8):
+        h.solve_batch(0, B, tick_dicts[t % nt], out, stream=sp)
+    torch.cuda.synchronize()
+    n2 = max(steps, 100)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for t in range(n2):
+        h.solve_batch(0, B, tick_dicts[(8 + t) % nt], out, stream=sp)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n2
+    it = out["iters"].cpu().numpy()
+    res = {"value": B / dt, "unit": "QP/s", "steps": n2, "kernel_ms": e0.elapsed_time(e1) / n2, "iters_mean": float(it.mean()), "iters_max": int(it.max()),
+           "iters_hist": np.bincount(np.minimum(it, 15), minlength=16).tolist(), "status_optimal": int((out["status"] == 0).sum().item()),
+           "note": "opt-in pick priority for the previous tick's active set (WBCQP_FLAG_WARM_START); eiquadprog-fast has no such rule: never the headline"}
+    if parity:
+        from oracle import oracle
+        last = (8 + n2 - 1) % nt
+        ns = min(B, 256)
+        cpu_in = {k: v[:ns].copy() for k, v in inputs.items()}
+        cpu_in["b1"] = b1_ticks[last][:ns].cpu().numpy().astype(np.float64)
+        ref = oracle.tick_batch(st, cpu_in, nthreads=8)
+        x = out["x"][:ns].cpu().numpy().astype(np.float64)
+        e = np.abs(x[:, :st.nv] - ref["x"][:, :st.nv]).max(axis=1) / np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
+        res["parity"] = {"sample": ns, "tick": int(last), "status_equal": bool(np.array_equal(out["status"][:ns].cpu().numpy(), ref["status"])),
+                         "frac_within_1e-8_of_cold_oracle": float((e <= 1e-8).mean()), "max_rel_dx": float(e.max()),
+                         "iters_cold_mean": float(ref["iters"].mean()), "iters_cold_max": int(ref["iters"].max()),
+                         "iters_warm_mean": float(it[:ns].mean()), "iters_warm_max": int(it[:ns].max())}
+    h.close()
+    return res
+
+
 def dense_seam(local_rank, st, inputs, cpu=True):
     """Latency of ONE Talos QP through the two host-pointer seams: `wbcqp_solve_dense_host` -- what stands behind
     solver_->solve(HQPData) (controller.cpp:247), the reference's own use case at n_qp = 1 -- and `wbcqp_solve_batch_host`
@@ -652,6 +699,13 @@ def main():
                 result["unrelated_batches"] = variant(base_flags, "four unrelated batches in rotation: the order of a launch comes from other QPs (a lower bound: worse than no order only if the library mis-orders)", fresh=fresh)
             except Exception as e:  # noqa: BLE001
                 result["unrelated_batches"] = {"error": repr(e)}
+
+        if world == 1 and stream and not args.no_compare:
+            try:  # OPT-IN, beside the headline and never it: eiquadprog-fast has no warm start (include/wbcqp.h, WBCQP_FLAG_WARM_START)
+                result["warm_start"] = warm_start(local_rank, torch, st, tick_dicts, new_out, B, cdt, base_flags, args.steps, inputs,
+                                                  b1_ticks, not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                result["warm_start"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
         if world == 1 and args.robot == "talos" and not f32 and not args.headline_only:
             # after the path: state integration kernel on the solver's own output, outside `value`

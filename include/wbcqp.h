@@ -148,6 +148,9 @@ typedef struct {
     int32_t* iters;   /* [batch] active-set iterations (eiquadprog `iter`)                   */
     void* objective;  /* [batch] 0.5x'Hx + g'x (SolverHQPBase::getObjectiveValue), may be NULL */
     int32_t* n_active;/* [batch] size of the final active set incl. equalities, may be NULL  */
+    uint32_t* active_mask; /* [batch][8], may be NULL.  OUT: bit r of the 256-bit mask = one-sided inequality row r is active at the
+                         solution.  With WBCQP_FLAG_WARM_START also IN: the mask a previous tick left for the same instance (zeros: no
+                         hint).  Device pointer on the device entry points.  Structures on the compact layout only (nin2 <= 256). */
 } wbcqp_outputs;
 
 /* wbcqp_desc.flags */
@@ -172,6 +175,13 @@ typedef struct {
 #define WBCQP_FLAG_WORKGROUP_PER_QP 32 /* keep the small structures (n <= 16 without contacts: Franka, Tiago) on the four-wave kernels too.
                                      Default (0): one WAVEFRONT per QP for them, four QPs per 256-thread workgroup and no workgroup
                                      barrier (csrc/wbcqp_small.hpp); in a ragged launch they go out as a launch of their own */
+#define WBCQP_FLAG_WARM_START 64 /* OPT-IN, not what the reference does: among the violated constraints the active-set loop first picks
+                                    those that were active at the previous tick's solution (wbcqp_outputs.active_mask, in/out), the most
+                                    violated of them first; when none of them is violated, eiquadprog's rule (the most violated row).
+                                    Still Goldfarb-Idnani -- any violated constraint is a legal pick, the QP is strictly convex, so x
+                                    and tau are those of the cold start up to rounding -- but the add / drop churn of a cold start is
+                                    avoided: iteration counts fall to about the number of constraints active at the solution.
+                                    eiquadprog-fast has no such thing: bench.py reports it BESIDE the headline, never as it */
 #define WBCQP_FLAG_REFRESH_SHIFT 8
 #define WBCQP_FLAG_REFRESH(n) (((n) & 0xff) << WBCQP_FLAG_REFRESH_SHIFT) /* renew the launch order every n-th launch of a shape
                                     (1: after every launch; 0: the default, 4).  Between renewals the same order is used:

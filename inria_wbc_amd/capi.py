@@ -64,7 +64,7 @@ class CInputs(C.Structure):
 
 class COutputs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("tau", C.c_void_p), ("status", C.c_void_p), ("iters", C.c_void_p),
-                ("objective", C.c_void_p), ("n_active", C.c_void_p)]
+                ("objective", C.c_void_p), ("n_active", C.c_void_p), ("active_mask", C.c_void_p)]
 
 
 class CDesc(C.Structure):
@@ -266,6 +266,7 @@ FLAG_INDEX_ORDER = 1  # wbcqp_desc.flags: launch in index order (default: longes
 FLAG_NO_PACKING = 4   # wbcqp_desc.flags: plain longest-first order for the queue (default: bin-packed order for small launches)
 FLAG_QUEUE = 8        # wbcqp_desc.flags: the queue also when several workgroups share a CU (default there: hardware dispatch)
 FLAG_FULL_LDS = 16    # wbcqp_desc.flags: keep the one-QP-per-CU LDS layout (default: compact layout, two QPs per CU, where eligible)
+FLAG_WARM_START = 64  # wbcqp_desc.flags: OPT-IN pick priority for the rows of outputs["active_mask"] (not eiquadprog's rule; include/wbcqp.h)
 FLAG_WORKGROUP_PER_QP = 32  # wbcqp_desc.flags: four waves per QP also for n <= 16 (default there: one wavefront per QP, wbcqp_small.hpp)
 FLAG_HW_DISPATCH = 2  # wbcqp_desc.flags: one workgroup per QP through the hardware dispatcher (default: resident workgroups + queue)
 
@@ -323,7 +324,7 @@ class Handle:
             assert t.is_cuda and t.is_contiguous() and t.numel() == batch * L[k], (k, tuple(t.shape), batch, L[k])
             setattr(cin, k, t.data_ptr())
         cout = COutputs()
-        for k in ("x", "tau", "status", "iters", "objective", "n_active"):
+        for k in ("x", "tau", "status", "iters", "objective", "n_active", "active_mask"):  # active_mask: int32 [batch, 8], in/out
             t = outputs.get(k)
             setattr(cout, k, t.data_ptr() if t is not None and t.numel() else None)
         return cin, cout

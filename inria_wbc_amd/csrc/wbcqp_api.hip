@@ -294,6 +294,8 @@ void fill_group(GroupArgs<TI>& g, const Slot& s, bool compact, int batch, const 
     g.tlb = static_cast<const TI*>(in->tlb); g.tub = static_cast<const TI*>(in->tub); g.w = static_cast<const TI*>(in->w);
     g.x = static_cast<TI*>(out->x); g.tau = static_cast<TI*>(out->tau); g.objective = static_cast<TI*>(out->objective);
     g.status = out->status; g.iters = out->iters; g.n_active = out->n_active;
+    g.amask = compact ? out->active_mask : nullptr; // (the compact kernel keeps the mask; the other kernels ignore it)
+    g.warm = 0;
     g.dbg = nullptr;
     g.count = batch;
 }
@@ -624,8 +626,8 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
             total_small += G.batch;
             continue;
         }
-        if (h->dtype == WBCQP_F64) { fill_group(t64.g[used], s, compact, G.batch, &G.in, &G.out); t64.g[used].dbg = h->dbg; }
-        else { fill_group(t32.g[used], s, compact, G.batch, &G.in, &G.out); t32.g[used].dbg = h->dbg; }
+        if (h->dtype == WBCQP_F64) { fill_group(t64.g[used], s, compact, G.batch, &G.in, &G.out); t64.g[used].dbg = h->dbg; t64.g[used].warm = (h->flags & WBCQP_FLAG_WARM_START) ? 1 : 0; }
+        else { fill_group(t32.g[used], s, compact, G.batch, &G.in, &G.out); t32.g[used].dbg = h->dbg; t32.g[used].warm = (h->flags & WBCQP_FLAG_WARM_START) ? 1 : 0; }
         ++used;
         total += G.batch;
         const int need = compact ? s.lds_cp : s.lds_full;
@@ -684,7 +686,8 @@ int wbcqp_solve_batch_host(wbcqp_handle* h, int slot, int batch, const wbcqp_inp
     const size_t o_st = (o_obj + (size_t)batch * es + 255) & ~(size_t)255;
     const size_t o_it = o_st + (((size_t)batch * 4 + 255) & ~(size_t)255);
     const size_t o_na = o_it + (((size_t)batch * 4 + 255) & ~(size_t)255);
-    const size_t out_bytes = o_na + (size_t)batch * 4 + 256;
+    const size_t o_am = o_na + (((size_t)batch * 4 + 255) & ~(size_t)255);
+    const size_t out_bytes = o_am + (size_t)batch * 32 + 256;
     rc = ensure(h, h->stage_out, out_bytes);
     if (rc != WBCQP_OK) return rc;
     char* din = static_cast<char*>(h->stage_in.dev);
@@ -693,12 +696,17 @@ int wbcqp_solve_batch_host(wbcqp_handle* h, int slot, int batch, const wbcqp_inp
         if (lens[f] > 0) HIP_TRY(h, hipMemcpyAsync(din + offs[f], src[f], (size_t)lens[f] * batch * es, hipMemcpyHostToDevice, nullptr));
     wbcqp_inputs di = {din + offs[0], din + offs[1], din + offs[2], din + offs[3], din + offs[4], din + offs[5],
                        din + offs[6], din + offs[7], din + offs[8], din + offs[9], din + offs[10]};
-    wbcqp_outputs dso;
+    wbcqp_outputs dso{};
     dso.x = dout + o_x; dso.tau = dout + o_tau; dso.objective = dout + o_obj;
     dso.status = reinterpret_cast<int32_t*>(dout + o_st); dso.iters = reinterpret_cast<int32_t*>(dout + o_it);
     dso.n_active = reinterpret_cast<int32_t*>(dout + o_na);
+    if (out->active_mask) { // in/out: the hint goes up (zeros where the caller has none), the solution's active set comes back
+        dso.active_mask = reinterpret_cast<uint32_t*>(dout + o_am);
+        HIP_TRY(h, hipMemcpyAsync(dso.active_mask, out->active_mask, (size_t)batch * 32, hipMemcpyHostToDevice, nullptr));
+    }
     rc = wbcqp_solve_batch(h, slot, batch, &di, &dso, nullptr);
     if (rc != WBCQP_OK) return rc;
+    if (out->active_mask) HIP_TRY(h, hipMemcpyAsync(out->active_mask, dso.active_mask, (size_t)batch * 32, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipMemcpyAsync(out->x, dso.x, (size_t)L.n * batch * es, hipMemcpyDeviceToHost, nullptr));
     if (s.host.na > 0) HIP_TRY(h, hipMemcpyAsync(out->tau, dso.tau, (size_t)s.host.na * batch * es, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipMemcpyAsync(out->status, dso.status, (size_t)batch * 4, hipMemcpyDeviceToHost, nullptr));

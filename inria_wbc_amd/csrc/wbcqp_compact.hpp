@@ -773,12 +773,23 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         const double aci0 = act_owner ? (aq ? c.tu[arr] : -c.tl[arr]) : 0.0;
         const double asg = aq ? -1.0 : 1.0;
         double s_own = 0.0, s_act = 0.0; // s of the owned rows at the iterate of the last evaluation
+        // WBCQP_FLAG_WARM_START (opt-in, include/wbcqp.h): rows that were active at the previous tick's solution are picked first
+        // (among the violated ones; the most violated of them first).  Any violated row is a legal Goldfarb-Idnani pick, so only
+        // the order of the picks changes -- and with it the add / drop churn a cold start goes through.
+        const bool use_warm = ga.warm != 0 && ga.amask != nullptr;
+        bool warm_own = false, warm_act = false;
+        if (use_warm) {
+            const unsigned* am = ga.amask + qp * 8;
+            if (tid < nin2) warm_own = (am[tid >> 5] >> (tid & 31)) & 1u;
+            if (act_owner) warm_act = (am[arow >> 5] >> (arow & 31)) & 1u;
+        }
 
         // s = CI (xp + t zp) + ci0 for the rows this thread owns (kept in s_own / s_act); returns its most violated eligible row
         // (row ipx counts as active: its flag is being set while this runs).  tau' of that iterate lands in tact[] and tau_q.
         double tau_q = 0.0; // tau' of the quad's actuation row at the iterate of the last evaluation (all four lanes)
-        auto eval_rows = [&](const double* xp, const double* zp, double t, int ipx, ValIdx& best) __attribute__((always_inline)) {
+        auto eval_rows = [&](const double* xp, const double* zp, double t, int ipx, ValIdx& best, ValIdx& bestw) __attribute__((always_inline)) {
             best = ValIdx{0.0, 0x7fffffff};
+            bestw = ValIdx{0.0, 0x7fffffff};
             if (act_ineq) {
                 const double acc = act_dot(c, ar, xp, zp, t);
                 tau_q = acc;
@@ -786,7 +797,10 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 if (act_owner) {
                     const double v = fma(asg, acc, aci0);
                     s_act = v;
-                    if (v < 0.0 && !act[arow] && arow != ipx) best = ValIdx{v, arow};
+                    if (v < 0.0 && !act[arow] && arow != ipx) {
+                        best = ValIdx{v, arow};
+                        if (warm_act) bestw = best;
+                    }
                 }
             }
             const int mt = own.meta;
@@ -808,21 +822,28 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
                 v += own.ci0;
                 s_own = v;
-                if (v < 0.0 && !act[tid] && tid != ipx) best = vi_min(best, ValIdx{v, tid});
+                if (v < 0.0 && !act[tid] && tid != ipx) {
+                    best = vi_min(best, ValIdx{v, tid});
+                    if (warm_own) bestw = vi_min(bestw, ValIdx{v, tid});
+                }
             }
         };
         // the same for the iterate x + t z when s_own / s_act / tau_q hold the values AT x (the common, fused step): only the
         // increments t (CI z) are formed -- half the LDS reads and a third of the arithmetic of the evaluation from scratch.
         // tau' of the final iterate is evaluated from scratch in the decode, so the output never carries the accumulated sum.
-        auto eval_rows_inc = [&](const double* zp, double t, int ipx, ValIdx& best) __attribute__((always_inline)) {
+        auto eval_rows_inc = [&](const double* zp, double t, int ipx, ValIdx& best, ValIdx& bestw) __attribute__((always_inline)) {
             best = ValIdx{0.0, 0x7fffffff};
+            bestw = ValIdx{0.0, 0x7fffffff};
             if (act_ineq) {
                 const double acc = fma(t, act_dot1(c, ar, zp), tau_q);
                 tau_q = acc;
                 if (act_owner) {
                     const double v = fma(asg, acc, aci0);
                     s_act = v;
-                    if (v < 0.0 && !act[arow] && arow != ipx) best = ValIdx{v, arow};
+                    if (v < 0.0 && !act[arow] && arow != ipx) {
+                        best = ValIdx{v, arow};
+                        if (warm_act) bestw = best;
+                    }
                 }
             }
             const int mt = own.meta;
@@ -846,17 +867,25 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
                 const double v = fma(t, dz, s_own);
                 s_own = v;
-                if (v < 0.0 && !act[tid] && tid != ipx) best = vi_min(best, ValIdx{v, tid});
+                if (v < 0.0 && !act[tid] && tid != ipx) {
+                    best = vi_min(best, ValIdx{v, tid});
+                    if (warm_own) bestw = vi_min(bestw, ValIdx{v, tid});
+                }
             }
         };
         // psi = sum min(s, 0) decides the termination only when it is small: |psi| >= |s(most violated row)|, so the sum is
         // formed (one more reduction) only when that row alone does not already exceed the tolerance
-        auto publish_best = [&](ValIdx best) __attribute__((always_inline)) {
+        auto publish_best = [&](ValIdx best, ValIdx bestw) __attribute__((always_inline)) {
             best = wave_argmin(best);
+            if (use_warm) bestw = wave_argmin(bestw);
             double* slot = c.red + c.rslot * 16;
             if (c.lane == 0) {
                 slot[4 + c.wave] = best.v;
                 slot[8 + c.wave] = __hiloint2double(0, best.i);
+                if (use_warm) {
+                    slot[c.wave] = bestw.v;
+                    slot[12 + c.wave] = __hiloint2double(0, bestw.i);
+                }
             }
         };
         bsync();
@@ -883,8 +912,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         c.uold[i] = c.u[i];
                         c.Aold[i] = c.A[i];
                     }
-                    eval_rows(c.x, c.z, 0.0, -1, best);
-                    publish_best(best);
+                    ValIdx bw;
+                    eval_rows(c.x, c.z, 0.0, -1, best, bw);
+                    publish_best(best, bw);
                     bsync(); // B1
                 }
                 slow = false;
@@ -897,6 +927,11 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 best = ValIdx{slot[4], __double2loint(slot[8])};
 #pragma unroll
                 for (int w = 1; w < kWaves; ++w) best = vi_min(best, ValIdx{slot[4 + w], __double2loint(slot[8 + w])});
+                ValIdx bestw{0.0, 0x7fffffff};
+                if (use_warm) {
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) bestw = vi_min(bestw, ValIdx{slot[w], __double2loint(slot[12 + w])});
+                }
                 c.rslot ^= 1;
                 s_ready = false;
                 if (!(best.v < 0.0)) { // nothing violated (psi = 0)
@@ -910,14 +945,26 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         break;
                     }
                 }
+                if (use_warm && bestw.v < 0.0) best = bestw; // a hinted row is violated: it goes first
                 STAMP(9)
             }
             else {
                 // l2 again after a rejected constraint: the owners still hold s of the (restored) iterate, the rejected row is excluded
                 best = ValIdx{0.0, 0x7fffffff};
-                if (act_owner && s_act < 0.0 && !act[arow] && excl[arow]) best = ValIdx{s_act, arow};
-                if (own.meta >= 0 && s_own < 0.0 && !act[tid] && excl[tid]) best = vi_min(best, ValIdx{s_own, tid});
+                ValIdx bw{0.0, 0x7fffffff};
+                if (act_owner && s_act < 0.0 && !act[arow] && excl[arow]) {
+                    best = ValIdx{s_act, arow};
+                    if (warm_act) bw = best;
+                }
+                if (own.meta >= 0 && s_own < 0.0 && !act[tid] && excl[tid]) {
+                    best = vi_min(best, ValIdx{s_own, tid});
+                    if (warm_own) bw = vi_min(bw, ValIdx{s_own, tid});
+                }
                 best = block_argmin(c, best);
+                if (use_warm) {
+                    bw = block_argmin(c, bw);
+                    if (bw.v < 0.0) best = bw;
+                }
                 redo_l2 = false;
             }
             if (best.v >= 0.0) {
@@ -1177,11 +1224,11 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         c.Aold[iq] = ip;
                         act[ip] = 1;
                     }
-                    ValIdx nb;
-                    if (slow) eval_rows(c.x, c.z, t, ip, nb); // drops moved x since the last evaluation: from scratch
-                    else eval_rows_inc(c.z, t, ip, nb);
+                    ValIdx nb, nbw;
+                    if (slow) eval_rows(c.x, c.z, t, ip, nb, nbw); // drops moved x since the last evaluation: from scratch
+                    else eval_rows_inc(c.z, t, ip, nb, nbw);
                     STAMP(23)
-                    publish_best(nb);
+                    publish_best(nb, nbw);
                     c.iq = iq + 1;
                     c.R_norm = fmax(c.R_norm, fabs(alpha));
                     bsync(); // C = B1 of the next iteration
@@ -1316,6 +1363,15 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             bsync();
         }
         if (tid < na) to[tid] = (TI)((double)hav + tact[tid]);
+    }
+    if (ga.amask) { // bit r = one-sided row r is active at the solution (the next tick's hint under WBCQP_FLAG_WARM_START)
+        const signed char* actf = reinterpret_cast<const signed char*>(reinterpret_cast<int*>(lds + S.o_int) + cp::IACT);
+        const bool on = (status == HQP_OPTIMAL) && nin2 > 0 && tid < nin2 && actf[tid] != 0;
+        const unsigned long long m = __ballot(on);
+        if (c.lane == 0) {
+            ga.amask[qp * 8 + 2 * c.wave] = (unsigned)(m & 0xffffffffull);
+            ga.amask[qp * 8 + 2 * c.wave + 1] = (unsigned)(m >> 32);
+        }
     }
     if (tid == 0) {
         ga.status[qp] = status;

@@ -73,6 +73,8 @@ struct GroupArgs {
     const TI *M, *h, *A, *b1, *Ac, *bc, *blb, *bub, *tlb, *tub, *w;
     TI *x, *tau, *objective;
     int *status, *iters, *n_active;
+    unsigned* amask; // [count][8] active-set mask of the solution (out; in as the pick hint when warm != 0), or null
+    int warm;        // WBCQP_FLAG_WARM_START
     long long* dbg; // per-QP phase cycle counters, only written by the WBCQP_STAMPS diagnostic build
     int count;
 };
