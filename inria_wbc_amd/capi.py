@@ -106,6 +106,11 @@ class CState(C.Structure):
     _fields_ = [("q", C.c_void_p), ("v", C.c_void_p), ("ref", C.c_void_p), ("momentum", C.c_void_p)]
 
 
+class CRolloutIO(C.Structure):
+    _fields_ = [("state", CState), ("tlb", C.c_void_p), ("tub", C.c_void_p), ("w", C.c_void_p), ("out", COutputs), ("q_next", C.c_void_p),
+                ("v_next", C.c_void_p), ("q_solver", C.c_void_p), ("dt", C.c_double), ("iters_sum", C.c_void_p), ("ticks_ok", C.c_void_p)]
+
+
 class CTickIO(C.Structure):
     pass  # fields set below (needs CInputs / COutputs)
 
@@ -390,7 +395,8 @@ class Handle:
     def _tick_io(self, slot: int, batch: int, state, rows, out, q_next, v_next, dt: float, q_solver=None) -> CTickIO:
         cin, cout = self._pack(slot, batch, rows, out)
         io = CTickIO()
-        io.state = CState(state["q"].data_ptr(), state["v"].data_ptr(), state["ref"].data_ptr())
+        io.state = CState(state["q"].data_ptr(), state["v"].data_ptr(), state["ref"].data_ptr(),
+                          state["momentum"].data_ptr() if state.get("momentum") is not None else None)
         io.rows, io.out = cin, cout
         io.q_next, io.v_next = q_next.data_ptr(), v_next.data_ptr()
         io.q_solver = q_solver.data_ptr() if q_solver is not None else None
@@ -401,6 +407,30 @@ class Handle:
         """rows -> QP -> integration for one control tick (wbcqp_tick), device tensors."""
         io = self._tick_io(slot, batch, state, rows, out, q_next, v_next, dt, q_solver)
         self._check(self.lib.wbcqp_tick(self._h, slot, batch, C.byref(io), C.c_void_p(stream)))
+
+    def rollout(self, slot: int, batch: int, n_ticks: int, state, limits, out, q_next, v_next, dt: float, q_solver=None, iters_sum=None,
+                ticks_ok=None, stream: int = 0):
+        """n_ticks control ticks of every instance in one launch, no batch barrier (wbcqp_rollout).  state: q [B, nq], v [B, nv],
+        ref [n_ticks, B, nref] (+ optional momentum [B, 6]); limits: tlb, tub, w; out: x, tau, status, iters of the LAST tick."""
+        st = self._structs[slot]
+        io = CRolloutIO()
+        io.state = CState(state["q"].data_ptr(), state["v"].data_ptr(), state["ref"].data_ptr(),
+                          state["momentum"].data_ptr() if state.get("momentum") is not None else None)
+        assert state["ref"].is_contiguous() and state["ref"].shape[0] == n_ticks and state["ref"].shape[1] == batch
+        io.tlb = limits["tlb"].data_ptr() if limits.get("tlb") is not None and st.act_bounds else None
+        io.tub = limits["tub"].data_ptr() if limits.get("tub") is not None and st.act_bounds else None
+        io.w = limits["w"].data_ptr()
+        cout = COutputs()
+        for k in ("x", "tau", "status", "iters", "objective", "n_active", "active_mask"):
+            t = out.get(k)
+            setattr(cout, k, t.data_ptr() if t is not None and t.numel() else None)
+        io.out = cout
+        io.q_next, io.v_next = q_next.data_ptr(), v_next.data_ptr()
+        io.q_solver = q_solver.data_ptr() if q_solver is not None else None
+        io.dt = float(dt)
+        io.iters_sum = iters_sum.data_ptr() if iters_sum is not None else None
+        io.ticks_ok = ticks_ok.data_ptr() if ticks_ok is not None else None
+        self._check(self.lib.wbcqp_rollout(self._h, slot, batch, n_ticks, C.byref(io), C.c_void_p(stream)))
 
     def tick_host(self, slot: int, q: np.ndarray, v: np.ndarray, ref: np.ndarray, tlb, tub, w, dt: float, want_rows: bool = False):
         """One whole tick with host arrays (wbcqp_tick_host): returns dict(x, tau, status, iters, q_next, v_next, q_solver[, rows])."""

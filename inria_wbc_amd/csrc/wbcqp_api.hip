@@ -94,6 +94,16 @@ struct wbcqp_handle {
     wbcqp_dense_output dense_out{};
     int lds_pad = 0; // diagnostic (env WBCQP_DEBUG_LDS_PAD): extra dynamic LDS per workgroup, to force a lower residency
     int queue_lds[2] = {-1, -1}, queue_occ[2] = {0, 0}; // occupancy of solve_queue_kernel<., CP> at queue_lds bytes of LDS
+    // wbcqp_rollout: sub-batches on streams of their own (each with its own launch-order state and queue counter), the record
+    // arrays and the state ping-pong of the whole batch
+    struct RollSub {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        OrderState ord;
+    };
+    std::vector<RollSub> roll_subs;
+    hipEvent_t roll_start = nullptr;
+    Staging roll_rec, roll_state;
 };
 
 namespace {
@@ -498,6 +508,15 @@ int wbcqp_destroy(wbcqp_handle* h)
     for (auto& s : h->slots) release(s);
     if (h->stage_in.dev) (void)hipFree(h->stage_in.dev);
     if (h->stage_out.dev) (void)hipFree(h->stage_out.dev);
+    if (h->roll_rec.dev) (void)hipFree(h->roll_rec.dev);
+    if (h->roll_state.dev) (void)hipFree(h->roll_state.dev);
+    for (auto& r : h->roll_subs) {
+        if (r.stream) (void)hipStreamDestroy(r.stream);
+        if (r.done) (void)hipEventDestroy(r.done);
+        if (r.ord.order) (void)hipFree(r.ord.order);
+        if (r.ord.queue) (void)hipFree(r.ord.queue);
+    }
+    if (h->roll_start) (void)hipEventDestroy(h->roll_start);
     if (h->ord.order) (void)hipFree(h->ord.order);
     for (auto& q : h->queues) (void)hipFree(q.ctr);
     delete h;
@@ -1251,6 +1270,120 @@ int wbcqp_tick(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io, vo
     if (rc != WBCQP_OK) return rc;
     return wbcqp_integrate(h, batch, s.terms.nv, s.terms.floating_base, io->dt, io->state.q, io->state.v, io->out.x, s.host.n,
                            io->out.status, io->q_next, io->v_next, io->q_solver, stream);
+}
+
+int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp_rollout_io* io, void* stream)
+{
+    if (!h) return WBCQP_ERR_INVALID;
+    if (!io) return fail(h, WBCQP_ERR_INVALID, "io is NULL");
+    if (slot < 0 || slot >= WBCQP_MAX_STRUCTURES || !h->slots[slot].set || !h->slots[slot].has_model)
+        return fail(h, WBCQP_ERR_INVALID, "slot has no model (wbcqp_set_model)");
+    if (batch < 0 || n_ticks < 0) return fail(h, WBCQP_ERR_INVALID, "negative batch / n_ticks");
+    if (batch == 0 || n_ticks == 0) return WBCQP_OK;
+    const Slot& s = h->slots[slot];
+    const wbcqp_layout& L = s.layout;
+    const TermsDev& T = s.terms;
+    if (!io->state.q || !io->state.v || (T.nref > 0 && !io->state.ref)) return fail(h, WBCQP_ERR_INVALID, "state arrays q / v / ref are required");
+    if ((L.len_tlb && (!io->tlb || !io->tub)) || !io->w) return fail(h, WBCQP_ERR_INVALID, "tlb / tub / w are required");
+    if (!io->out.x || !io->out.status || !io->out.iters || (s.host.na > 0 && !io->out.tau) || !io->q_next || !io->v_next)
+        return fail(h, WBCQP_ERR_INVALID, "x, tau, status, iters, q_next, v_next are required");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t sm = static_cast<hipStream_t>(stream);
+    const size_t es = (h->dtype == WBCQP_F64) ? 8 : 4;
+    const size_t B = (size_t)batch;
+    // two sub-batches from 512 instances on (measured, tools/rollout_bench.py, B = 1024, 64 ticks: 1.04x of the tick loop with two streams,
+    // 1.02x with three, 0.57x with four -- the launches of four streams no longer overlap, they queue behind one another); WBCQP_ROLLOUT_STREAMS
+    // overrides (1 = what K calls of wbcqp_tick do)
+    int S = batch >= 512 ? 2 : 1;
+    if (const char* ev = std::getenv("WBCQP_ROLLOUT_STREAMS")) S = std::max(1, std::min({std::atoi(ev), 8, batch}));
+    while ((int)h->roll_subs.size() < S) {
+        wbcqp_handle::RollSub r;
+        HIP_TRY(h, hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+        HIP_TRY(h, hipMalloc(&r.ord.queue, 2 * sizeof(int)));
+        HIP_TRY(h, hipMemset(r.ord.queue, 0, 2 * sizeof(int)));
+        h->roll_subs.push_back(r);
+    }
+    if (!h->roll_start) HIP_TRY(h, hipEventCreateWithFlags(&h->roll_start, hipEventDisableTiming));
+    // the record of every instance (the rows kernel's output, the solve's input) and the state ping-pong
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int rlen[8] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub};
+    size_t roff[8], rec_bytes = 0;
+    for (int f = 0; f < 8; ++f) { roff[f] = rec_bytes; rec_bytes += al((size_t)rlen[f] * B * es); }
+    const size_t qb = al((size_t)T.nq * B * es), vb = al((size_t)T.nv * B * es);
+    const int sub_cap = (batch + S - 1) / S;
+    bool grow = h->roll_rec.bytes < rec_bytes || h->roll_state.bytes < 2 * (qb + vb);
+    for (int k = 0; k < S; ++k) grow = grow || h->roll_subs[k].ord.cap < sub_cap;
+    if (grow) { // first call of a larger shape: nothing of an earlier call may still be running on what is replaced
+        HIP_TRY(h, hipDeviceSynchronize());
+        int rc = ensure(h, h->roll_rec, rec_bytes);
+        if (rc != WBCQP_OK) return rc;
+        rc = ensure(h, h->roll_state, 2 * (qb + vb));
+        if (rc != WBCQP_OK) return rc;
+        for (int k = 0; k < S; ++k) {
+            OrderState& os = h->roll_subs[k].ord;
+            if (os.cap < sub_cap) {
+                if (os.order) (void)hipFree(os.order);
+                os.order = nullptr;
+                os.cap = os.total = 0;
+                HIP_TRY(h, hipMalloc(&os.order, 2 * sizeof(int) * (size_t)sub_cap));
+                os.cap = sub_cap;
+            }
+        }
+    }
+    char* rec = static_cast<char*>(h->roll_rec.dev);
+    char* stt = static_cast<char*>(h->roll_state.dev);
+    char* qbuf[2] = {stt, stt + qb};
+    char* vbuf[2] = {stt + 2 * qb, stt + 2 * qb + vb};
+    HIP_TRY(h, hipMemcpyAsync(qbuf[0], io->state.q, (size_t)T.nq * B * es, hipMemcpyDeviceToDevice, sm));
+    HIP_TRY(h, hipMemcpyAsync(vbuf[0], io->state.v, (size_t)T.nv * B * es, hipMemcpyDeviceToDevice, sm));
+    HIP_TRY(h, hipEventRecord(h->roll_start, sm));
+    auto at = [es](const void* p, size_t elems) -> const void* { return p ? static_cast<const char*>(p) + elems * es : nullptr; };
+    auto atw = [es](void* p, size_t elems) -> void* { return p ? static_cast<char*>(p) + elems * es : nullptr; };
+    int rc_all = WBCQP_OK;
+    for (int k = 0; k < S; ++k) HIP_TRY(h, hipStreamWaitEvent(h->roll_subs[k].stream, h->roll_start, 0));
+    // tick t of every sub-batch is enqueued before tick t + 1 of any: the streams then advance together on the device (enqueued one
+    // sub-batch after the other, the last stream's first tick would reach the device when the first stream is almost through), and the
+    // tail of one sub-batch's solve (its longest QP) runs beside the bulk of another's
+    for (int t = 0; t < n_ticks && rc_all == WBCQP_OK; ++t) {
+        const bool last = t + 1 == n_ticks;
+        for (int k = 0; k < S && rc_all == WBCQP_OK; ++k) {
+            const size_t b0 = (size_t)k * batch / S, b1 = (size_t)(k + 1) * batch / S;
+            const int nb = (int)(b1 - b0);
+            if (nb == 0) continue;
+            wbcqp_handle::RollSub& sub = h->roll_subs[k];
+            wbcqp_tick_io d{};
+            d.rows.M = rec + roff[0] + b0 * rlen[0] * es; d.rows.h = rec + roff[1] + b0 * rlen[1] * es; d.rows.A = rec + roff[2] + b0 * rlen[2] * es;
+            d.rows.b1 = rec + roff[3] + b0 * rlen[3] * es; d.rows.Ac = rec + roff[4] + b0 * rlen[4] * es; d.rows.bc = rec + roff[5] + b0 * rlen[5] * es;
+            d.rows.blb = rec + roff[6] + b0 * rlen[6] * es; d.rows.bub = rec + roff[7] + b0 * rlen[7] * es;
+            d.rows.tlb = at(io->tlb, b0 * L.len_tlb); d.rows.tub = at(io->tub, b0 * L.len_tub); d.rows.w = at(io->w, b0 * L.len_w);
+            d.out.x = atw(io->out.x, b0 * L.n); d.out.tau = atw(io->out.tau, b0 * s.host.na); d.out.objective = atw(io->out.objective, b0);
+            d.out.status = io->out.status + b0; d.out.iters = io->out.iters + b0;
+            d.out.n_active = io->out.n_active ? io->out.n_active + b0 : nullptr;
+            d.out.active_mask = io->out.active_mask ? io->out.active_mask + b0 * 8 : nullptr;
+            d.state.q = qbuf[t & 1] + b0 * T.nq * es;
+            d.state.v = vbuf[t & 1] + b0 * T.nv * es;
+            d.state.ref = at(io->state.ref, ((size_t)t * B + b0) * T.nref);
+            d.state.momentum = last ? atw(io->state.momentum, b0 * 6) : nullptr;
+            d.q_next = last ? atw(io->q_next, b0 * T.nq) : (void*)(qbuf[(t + 1) & 1] + b0 * T.nq * es);
+            d.v_next = last ? atw(io->v_next, b0 * T.nv) : (void*)(vbuf[(t + 1) & 1] + b0 * T.nv * es);
+            d.q_solver = last ? atw(io->q_solver, b0 * T.nv) : nullptr;
+            d.dt = io->dt;
+            h->graph_ord = &sub.ord; // this sub-batch's own launch-order state and queue counter (as a captured tick has)
+            rc_all = wbcqp_tick(h, slot, nb, &d, sub.stream);
+            h->graph_ord = nullptr;
+            if (rc_all == WBCQP_OK && (io->iters_sum || io->ticks_ok)) {
+                hipLaunchKernelGGL(accumulate_kernel, dim3((nb + 255) / 256), dim3(256), 0, sub.stream, nb, t == 0 ? 1 : 0, io->out.iters + b0, io->out.status + b0,
+                                   io->iters_sum ? io->iters_sum + b0 : nullptr, io->ticks_ok ? io->ticks_ok + b0 : nullptr);
+                HIP_TRY(h, hipGetLastError());
+            }
+        }
+    }
+    for (int k = 0; k < S; ++k) {
+        HIP_TRY(h, hipEventRecord(h->roll_subs[k].done, h->roll_subs[k].stream));
+        HIP_TRY(h, hipStreamWaitEvent(sm, h->roll_subs[k].done, 0));
+    }
+    return rc_all;
 }
 
 int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io)

@@ -229,7 +229,7 @@ struct OwnRow {
 };
 
 template <typename TI>
-__device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const DevStruct& S, const int b, double* lds, const int tid)
+__device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const DevStruct& S, const int b, double* lds, const int tid, const int brec = -1)
 {
     Ctx c;
     c.S = &S;
@@ -262,20 +262,21 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     c.R_norm = 1.0;
 
     const int n_dense = S.n_dense, n_sel = S.n_sel, n_bound = S.n_bound, r1 = S.r1, n_tasks = S.n_tasks;
-    const size_t qp = (size_t)b;
+    const size_t qp = (size_t)b;                       // torque limits, weights and every output: the QP's index in the batch
+    const size_t qr = (size_t)(brec >= 0 ? brec : b);  // the record (M .. bub): wbcqp_rollout's workgroups keep one record slot each
     double* const As = c.J;                  // dense task rows are staged in the J region (J appears after the elimination)
     double* const RB = c.J + S.o_pan;        // the elimination's panels, behind the staged rows
     double* const YB = RB + 512;
     double* const Nm = c.R + 256;            // N = CE' (n x ldb), then B = J0'N: tail of the R region
     const int lenM = nv * (nv + 1) / 2, lenA = n_dense * nv, lenAc = nc * 6 * nv;
-    const TI* const pM = ga.M + qp * lenM;
-    const TI* const pAc = ga.Ac + qp * (size_t)lenAc;
+    const TI* const pM = ga.M + qr * lenM;
+    const TI* const pAc = ga.Ac + qr * (size_t)lenAc;
 
     STAMP_DECL
     // ---------------- phase 0: the record's loads all in flight, then land where they are used ----------------
     {
         constexpr int RA = 9, RC = 3; // rounds of 256 covered by registers; longer arrays finish in tail loops
-        const TI* pA = ga.A + qp * (size_t)lenA;
+        const TI* pA = ga.A + qr * (size_t)lenA;
         TI vA[RA], vC[RC];
         unsigned vQ[RA], vCq[RC];
         if (lenA > 0) {
@@ -309,21 +310,21 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             }
         }
         // the short vectors: one (clamped) element per thread each
-        const TI vb1 = ga.b1[qp * r1 + min(tid, r1 - 1)];
+        const TI vb1 = ga.b1[qr * r1 + min(tid, r1 - 1)];
         const TI vw = ga.w[qp * n_tasks + min(tid, n_tasks - 1)];
         TI vce = TI(0), vbl = TI(0), vbu = TI(0), vtl = TI(0), vtu = TI(0), vha = TI(0);
         if (neq > 0) {
-            if (tid < nu) vce = ga.h[qp * nv + tid];
-            else if (nc > 0) vce = ga.bc[qp * (nc * 6) + min(tid - nu, nc * 6 - 1)];
+            if (tid < nu) vce = ga.h[qr * nv + tid];
+            else if (nc > 0) vce = ga.bc[qr * (nc * 6) + min(tid - nu, nc * 6 - 1)];
         }
         if (n_bound > 0) {
-            vbl = ga.blb[qp * n_bound + min(tid, n_bound - 1)];
-            vbu = ga.bub[qp * n_bound + min(tid, n_bound - 1)];
+            vbl = ga.blb[qr * n_bound + min(tid, n_bound - 1)];
+            vbu = ga.bub[qr * n_bound + min(tid, n_bound - 1)];
         }
         if (S.act_bounds) {
             vtl = ga.tlb[qp * na + min(tid, na - 1)];
             vtu = ga.tub[qp * na + min(tid, na - 1)];
-            vha = ga.h[qp * nv + nu + min(tid, na - 1)];
+            vha = ga.h[qr * nv + nu + min(tid, na - 1)];
         }
         const int meta0 = (nin2 > 0) ? S.rowmeta[min(tid, nin2 - 1)] : 0;
         const int drt = (n_dense > 0) ? S.dense_row_task[min(tid, n_dense - 1)] : 0;
@@ -1355,7 +1356,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     for (int i = tid; i < n; i += kThreads) xo[i] = (TI)c.x[i];
     if (na > 0) {
         TI* to = ga.tau + qp * na;
-        const TI hav = ga.h[qp * nv + nu + min(tid, na - 1)];
+        const TI hav = ga.h[qr * nv + nu + min(tid, na - 1)];
         // tau' of the final iterate, from scratch (inside the loop it is carried by increments)
         {
             const double acc = act_dot(c, ar, c.x, c.z, 0.0);

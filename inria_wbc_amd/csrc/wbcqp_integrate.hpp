@@ -13,22 +13,12 @@ namespace wbcqp {
 // joint j, lane 0 the SE(3) part (exp6, M0 * exp6, rotation -> quaternion, sign continuity, first-order normalisation:
 // pinocchio's free-flyer integrate; Eigen's AngleAxis(quaternion)).  HBM-bound: (3 nq + 3 nv) words per instance.
 // ------------------------------------------------------------------------------------------------
+// one instance on one wavefront: (qi, dqi) the state, dvi the accelerations of the solution, ok = the QP was solved
 template <typename TI>
-__global__ __launch_bounds__(256) void integrate_kernel(int batch, int nv, int floating_base, double dt, const TI* __restrict__ q,
-                                                        const TI* __restrict__ dq, const TI* __restrict__ x, int ldx,
-                                                        const int* __restrict__ status, TI* __restrict__ q_next,
-                                                        TI* __restrict__ v_next, TI* __restrict__ q_solver)
+__device__ __forceinline__ void integrate_one(const int nv, const int floating_base, const double dt, const TI* qi, const TI* dqi, const TI* dvi,
+                                              const bool ok, TI* qo, TI* vo, TI* so, const int lane)
 {
-    const int inst = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (inst >= batch) return;
-    const int nq = floating_base ? nv + 1 : nv, nqs = floating_base ? nv : nv;
-    const TI* qi = q + (size_t)inst * nq;
-    const TI* dqi = dq + (size_t)inst * nv;
-    const TI* dvi = x + (size_t)inst * ldx;
-    TI* qo = q_next + (size_t)inst * nq;
-    TI* vo = v_next + (size_t)inst * nv;
-    TI* so = q_solver ? q_solver + (size_t)inst * nqs : nullptr;
-    const bool ok = !status || status[inst] == HQP_OPTIMAL;
+    const int nq = floating_base ? nv + 1 : nv;
     if (!ok) { // the reference throws here; the state stays where it was
         for (int j = lane; j < nq; j += 64) qo[j] = qi[j];
         for (int j = lane; j < nv; j += 64) vo[j] = dqi[j];
@@ -158,6 +148,19 @@ __global__ __launch_bounds__(256) void integrate_kernel(int batch, int nv, int f
             so[3] = (TI)(angle * a0); so[4] = (TI)(angle * a1); so[5] = (TI)(angle * a2);
         }
     }
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void integrate_kernel(int batch, int nv, int floating_base, double dt, const TI* __restrict__ q,
+                                                        const TI* __restrict__ dq, const TI* __restrict__ x, int ldx,
+                                                        const int* __restrict__ status, TI* __restrict__ q_next,
+                                                        TI* __restrict__ v_next, TI* __restrict__ q_solver)
+{
+    const int inst = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (inst >= batch) return;
+    const int nq = floating_base ? nv + 1 : nv;
+    integrate_one<TI>(nv, floating_base, dt, q + (size_t)inst * nq, dq + (size_t)inst * nv, x + (size_t)inst * ldx, !status || status[inst] == HQP_OPTIMAL,
+                      q_next + (size_t)inst * nq, v_next + (size_t)inst * nv, q_solver ? q_solver + (size_t)inst * nv : nullptr, lane);
 }
 
 #endif // __HIPCC__

@@ -215,17 +215,18 @@ constexpr int kTermsThreads = 256; // four wavefronts per instance: one runs the
 //            rows;  wave 2: self-collision frames and pairs;  wave 3: the other two thirds of the Jacobian rows
 //   phase 3  every wave: S_j and F_j of its lanes' columns (from wave 0, through LDS), then a quarter of the remaining rows each -- rows of M,
 //            CoM / momentum / self-collision rows
+// inst: which instance's state and references are read; rinst: where the record goes in the row arrays (the same index for the
+// kernel below; wbcqp_rollout's persistent workgroups keep ONE record slot each and pass their own index)
 template <typename TI>
-__global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs<TI> args)
+__device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* gq, const TI* gv, const TI* gr, TI* gmom, const int inst,
+                                          const int rinst, double* lds, const int tid)
 {
-    extern __shared__ double lds[];
     const TermsDev& T = args.T;
-    const int inst = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int lane = tid & (kWave - 1);
     // no rotation of the roles: the hardware itself starts co-resident workgroups on different SIMDs (measured with
     // tools/ubench/wave_placement.hip: wave 0 of the four workgroups of a CU lands on SIMD 2, 1, 3, 0), so their tree waves
     // already sit on four different SIMDs
     const int wave = uni(tid >> 6); // told to the compiler as wave-uniform: scalar branches on the role, scalar row counters
-    if (inst >= args.batch) return;
 #ifdef WBCQP_STAMPS
     long long tacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
 #endif
@@ -245,9 +246,6 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
 
     // ---- state and references into LDS ----------------------------------------------------------------------------
     {
-        const TI* gq = args.q + (size_t)inst * nq;
-        const TI* gv = args.v + (size_t)inst * nv;
-        const TI* gr = args.ref + (size_t)inst * T.nref;
         // one pass: every thread fetches its elements of the three arrays before any of them is stored
         const int n1 = nq, n2 = nq + nv, n3 = nq + nv + T.nref;
         TI buf[2];
@@ -484,7 +482,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
                 const V3 gvec = {T.g[0], T.g[1], T.g[2]};
                 const V3 gl = ld3(Y + 10) - Y[0] * gvec;
                 const V3 ga = ld3(Y + 13) - cross(hc, gvec);
-                args.h[(size_t)inst * nv + lane] = (TI)(dot(c.Sv, gl) + dot(c.Sw, ga));
+                args.h[(size_t)rinst * nv + lane] = (TI)(dot(c.Sv, gl) + dot(c.Sw, ga));
             }
         }
         TSTAMP(3)
@@ -528,8 +526,8 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
                 if (ub == ub_pos) lb = ub;
                 else ub = lb;
             }
-            args.blb[(size_t)inst * T.n_bound + j] = (TI)lb;
-            args.bub[(size_t)inst * T.n_bound + j] = (TI)ub;
+            args.blb[(size_t)rinst * T.n_bound + j] = (TI)lb;
+            args.bub[(size_t)rinst * T.n_bound + j] = (TI)ub;
         }
         // ---- phase 2 on this wave: the Jacobian rows of two framed tasks in three (wave 1 takes the others).  The frames are
         //      recomputed here into this wave's own copy of the table: cheaper than waiting for wave 1 to publish them ----------
@@ -555,8 +553,8 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
             const bool colv = lane < nv;
             const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
             // two tasks in three here, one in three on wave 1, which also evaluates the laws
-            jacobian_rows<TI>(T, law3, c, colv, lane, 1, 3, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
-            jacobian_rows<TI>(T, law3, c, colv, lane, 2, 3, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
+            jacobian_rows<TI>(T, law3, c, colv, lane, 1, 3, args.A + (size_t)rinst * T.n_dense * nv, args.Ac + (size_t)rinst * T.nc * 6 * nv, nv);
+            jacobian_rows<TI>(T, law3, c, colv, lane, 2, 3, args.A + (size_t)rinst * T.n_dense * nv, args.Ac + (size_t)rinst * T.nc * 6 * nv, nv);
         }
     }
     else if (wave == 1) {
@@ -613,7 +611,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
             {
                 const bool colv = lane < nv;
                 const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
-                jacobian_rows<TI>(T, law, c, colv, lane, 0, 3, args.A + (size_t)inst * T.n_dense * nv, args.Ac + (size_t)inst * T.nc * 6 * nv, nv);
+                jacobian_rows<TI>(T, law, c, colv, lane, 0, 3, args.A + (size_t)rinst * T.n_dense * nv, args.Ac + (size_t)rinst * T.nc * 6 * nv, nv);
             }
             TSTAMP(4)
         }
@@ -703,9 +701,9 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     const double mass = tot[0], imass = 1.0 / mass;
     const V3 com = imass * ld3(tot + 1);
     const V3 htl = ld3(tots), hta = ld3(tots + 3);
-    if (args.momentum && tid == 0) { // Ag v: total momentum, the angular part taken about the CoM (controller.cpp:245 reads its last three)
+    if (gmom && tid == 0) { // Ag v: total momentum, the angular part taken about the CoM (controller.cpp:245 reads its last three)
         const V3 La = hta - cross(com, htl);
-        TI* mo = args.momentum + (size_t)inst * 6;
+        TI* mo = gmom;
         mo[0] = (TI)htl.x; mo[1] = (TI)htl.y; mo[2] = (TI)htl.z;
         mo[3] = (TI)La.x; mo[4] = (TI)La.y; mo[5] = (TI)La.z;
     }
@@ -718,7 +716,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     TSTAMP(7)
     // M, row by row into the packed lower triangle: M(i, j) = S_j . F_i for j an ancestor dof of i (crba); F_i by readlane
     {
-        TI* Mo = args.M + (size_t)inst * (nv * (nv + 1) / 2);
+        TI* Mo = args.M + (size_t)rinst * (nv * (nv + 1) / 2);
         for (int i = wave; i < nv; i += kWaves) {
             const int b_i = rl(bj, i);
             const V3 fv = {bcast_lane(Fv.x, i), bcast_lane(Fv.y, i), bcast_lane(Fv.z, i)};
@@ -728,7 +726,7 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
         }
     }
     TSTAMP(8)
-    TI* Ao = args.A + (size_t)inst * T.n_dense * nv; // (the Jacobian rows of the framed tasks left in phase 2, from wave 1)
+    TI* Ao = args.A + (size_t)rinst * T.n_dense * nv; // (the Jacobian rows of the framed tasks left in phase 2, from wave 1)
     TSTAMP(9)
     // CoM, momentum and self-collision rows and the CoM / momentum right-hand sides, one block per wave in turn
     {
@@ -794,8 +792,8 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
     }
     TSTAMP(10)
     __syncthreads();
-    for (int i = tid; i < T.r1; i += kTermsThreads) args.b1[(size_t)inst * T.r1 + i] = (TI)b1s[i];
-    for (int i = tid; i < 6 * T.nc; i += kTermsThreads) args.bc[(size_t)inst * 6 * T.nc + i] = (TI)bcs[i];
+    for (int i = tid; i < T.r1; i += kTermsThreads) args.b1[(size_t)rinst * T.r1 + i] = (TI)b1s[i];
+    for (int i = tid; i < 6 * T.nc; i += kTermsThreads) args.bc[(size_t)rinst * 6 * T.nc + i] = (TI)bcs[i];
 #ifdef WBCQP_STAMPS
     TSTAMP(11)
     // every wave accumulates its own phases; wave w writes the slots it owns (0: 0-3,6-11; 1: 4; 2: 5)
@@ -806,6 +804,16 @@ __global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs
         if (wave == 2) D[5] = tacc_[5];
     }
 #endif
+}
+
+template <typename TI>
+__global__ __launch_bounds__(kTermsThreads, 4) void terms_kernel(const TermsArgs<TI> args)
+{
+    extern __shared__ double lds[];
+    if ((int)blockIdx.x >= args.batch) return;
+    const int inst = (int)blockIdx.x;
+    terms_one<TI>(args, args.q + (size_t)inst * args.T.nq, args.v + (size_t)inst * args.T.nv, args.ref + (size_t)inst * args.T.nref,
+                  args.momentum ? args.momentum + (size_t)inst * 6 : nullptr, inst, inst, lds, (int)threadIdx.x);
 }
 
 #endif // __HIPCC__

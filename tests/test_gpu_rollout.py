@@ -262,3 +262,68 @@ def test_tick_keeps_the_state_of_an_instance_whose_qp_fails():
     others = [i for i in range(B) if i != bad]
     assert not torch.equal(qn[others], state["q"][others])
     h.close()
+
+
+@pytest.mark.parametrize("B,K", [(5, 1), (7, 6), (600, 4)])
+def test_rollout_equals_k_ticks_bit_for_bit(B, K):
+    """wbcqp_rollout (K ticks of every instance in ONE launch, persistent workgroups, the record in a per-workgroup slot) against K
+    calls of wbcqp_tick with the state fed back: the same device functions run the three phases, so every output is the same bits --
+    the final state, q_solver, the last tick's x / tau / status / iters, the momentum of the last tick's state, and the iteration
+    total.  600 instances: more than the 512 resident workgroups, so some workgroups run two instances one after the other."""
+    import torch
+    m = mdl.talos_like()
+    st = structure.talos_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    dev = torch.device("cuda", 0)
+    s = mdl.sample_states(m, tm, B, 91_000, q_noise=0.01, v_noise=0.05, ref_noise=0.01)
+    com_blk = next(b for b in tm.blocks if b.kind == mdl.T_COM)
+    pos, vel, acc = trajs.move_com_stream(m.com(m.q0), [[0.0, 0.0, -0.2]], "001", tm.dt, 2.0, loop=True, absolute=False)
+    refs = np.repeat(s["ref"][None], K, axis=0).copy()  # [K, B, nref]: the CoM reference advances, instance i is 37 i ticks ahead
+    for t in range(K):
+        for i in range(B):
+            k = (t + 37 * i) % len(pos)
+            refs[t, i, com_blk.ref:com_blk.ref + 9] = np.concatenate([pos[k], vel[k], acc[k]])
+    L = st.field_lengths()
+    tlb = torch.from_numpy(np.tile(-m.tau_max, (B, 1))).to(dev)
+    tub = torch.from_numpy(np.tile(m.tau_max, (B, 1))).to(dev)
+    w = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def outs():
+        return dict(x=torch.full((B, st.n), float("nan"), dtype=torch.float64, device=dev), tau=torch.full((B, st.na), float("nan"), dtype=torch.float64, device=dev),
+                    status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+
+    h = capi.Handle(0, capi.F64)
+    h.set_structure(0, st)
+    h.set_model(0, m, tm)
+    # ---- K ticks, state fed back
+    q, v = torch.from_numpy(s["q"]).to(dev), torch.from_numpy(s["v"]).to(dev)
+    qn, vn, qs = torch.zeros_like(q), torch.zeros_like(v), torch.zeros_like(v)
+    rows = {k: torch.zeros(B, L[k], dtype=torch.float64, device=dev) for k in capi.ROW_FIELDS}
+    rows.update(tlb=tlb, tub=tub, w=w)
+    o1 = outs()
+    mom1 = torch.zeros(B, 6, dtype=torch.float64, device=dev)
+    it_sum = np.zeros(B, np.int64)
+    for t in range(K):
+        state = dict(q=q, v=v, ref=torch.from_numpy(refs[t]).to(dev), momentum=mom1)
+        h.tick(0, B, state, rows, o1, qn, vn, tm.dt, q_solver=qs, stream=stream)
+        torch.cuda.synchronize()
+        it_sum += o1["iters"].cpu().numpy()
+        q, qn = qn, q
+        v, vn = vn, v
+    # ---- one rollout
+    o2 = outs()
+    q2, v2, qs2 = torch.zeros_like(q), torch.zeros_like(v), torch.zeros_like(v)
+    mom2 = torch.zeros(B, 6, dtype=torch.float64, device=dev)
+    isum = torch.zeros(B, dtype=torch.int32, device=dev)
+    nok = torch.zeros(B, dtype=torch.int32, device=dev)
+    st0 = dict(q=torch.from_numpy(s["q"]).to(dev), v=torch.from_numpy(s["v"]).to(dev), ref=torch.from_numpy(np.ascontiguousarray(refs)).to(dev), momentum=mom2)
+    h.rollout(0, B, K, st0, dict(tlb=tlb, tub=tub, w=w), o2, q2, v2, tm.dt, q_solver=qs2, iters_sum=isum, ticks_ok=nok, stream=stream)
+    torch.cuda.synchronize()
+    assert (o1["status"] == 0).all().item() and (nok == K).all().item()
+    for name, a, b in (("q", q, q2), ("v", v, v2), ("q_solver", qs, qs2), ("x", o1["x"], o2["x"]), ("tau", o1["tau"], o2["tau"]),
+                       ("status", o1["status"], o2["status"]), ("iters", o1["iters"], o2["iters"]), ("momentum", mom1, mom2)):
+        assert torch.equal(a, b), name
+    assert np.array_equal(isum.cpu().numpy(), it_sum)
+    assert np.array_equal(st0["q"].cpu().numpy(), s["q"])  # the caller's state arrays are inputs only
+    h.close()
