@@ -13,6 +13,10 @@ python3 tools/phase_profile.py --out $OUT/phase.json > $OUT/phase.txt 2>&1
 python3 tools/phase_profile.py --model > $OUT/phase_model.txt 2>&1
 python3 tools/terms_profile.py > $OUT/terms_phase.txt 2>&1
 python3 tools/tick_latency.py --reps 100 --out $OUT/tick_latency.json > $OUT/tick_latency.txt 2>&1
+python3 tools/straggler_time.py --stamps > $OUT/straggler.txt 2>&1
+python3 tools/straggler_time.py --out $OUT/straggler_product.json > /dev/null 2>&1
+python3 bench.py --robot franka --batch 8192 --steps 50 --warmup 10 --no-sweep > $OUT/bench_franka_b8192.json 2> /dev/null
+python3 tools/rollout_bench.py > $OUT/rollout_bench.json 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 200 --warmup 20 --headline-only > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 20 --warmup 4 --headline-only > $OUT/fetch.log 2>&1
