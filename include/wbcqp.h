@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WBCQP_VERSION 130 /* 0.1.2: + wbcqp_integrate (0.1.1), wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions (0.1.2); 121: queue + packed launch order, wbcqp_launch_order */
+#define WBCQP_VERSION 140 /* 0.1.4: + wbcqp_rollout, wbcqp_outputs.active_mask (WBCQP_FLAG_WARM_START), wbcqp_state.momentum, wbcqp_layout.wave_per_qp (WBCQP_FLAG_WORKGROUP_PER_QP); 130: wbcqp_integrate, wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions; 121: queue + packed launch order, wbcqp_launch_order */
 #define WBCQP_MAX_STRUCTURES 16
 #define WBCQP_MAX_INEQ_BLOCKS 16
 #define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: every per-QP vector fits one 128-entry LDS slot, n + 2 <= 128 */

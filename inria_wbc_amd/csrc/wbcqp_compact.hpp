@@ -31,6 +31,9 @@
 #ifndef WBCQP_X_JUPD
 #define WBCQP_X_JUPD 0
 #endif
+#ifndef WBCQP_X_QR
+#define WBCQP_X_QR 1 // 1: qr_unified (every vector on a quad of its own), 0: qr_resident (round 2)
+#endif
 
 namespace wbcqp {
 #ifdef __HIPCC__
@@ -644,7 +647,11 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         }
         bsync();
         STAMP(5)
+#if WBCQP_X_QR
+        bool ok = qr_unified(c, Nm, c.s, c.s + 160);
+#else
         bool ok = qr_resident(c, Nm, c.s, c.s + 160);
+#endif
         if (!ok) status = HQP_ERROR; // redundant equalities
         else {
             bsync();

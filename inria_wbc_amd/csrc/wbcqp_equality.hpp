@@ -221,6 +221,179 @@ __device__ __forceinline__ bool qr_resident(Ctx& c, const double* Bm, double* vb
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same factorisation with EVERY vector on a quad of its own.  A column of B and a row of J take the same operation per
+// reflector, x <- x - tau (x . v) v, so qr_resident's two roles are one: m columns + n rows = up to 102 vectors, four lanes
+// each in the (2 kc + 8 t, + 1) pair layout, the reflector read ONCE per step into registers (10 x 16 bytes) and used for
+// both passes.  Round 1: vectors 0..63 on the 64 quads (the columns of B first: the quad of column j + 1 goes on to the next
+// reflector as soon as its own update is done); round 2: the remaining rows of J on the LAST quads (waves 2 and 3), so the waves
+// that carry the columns' critical path have one round only.  Why: in qr_resident wave 1 holds the last two columns of B (lanes
+// 64..71) AND twenty lanes of J rows -- it runs the column path and the row path one after the other in 16 of 18 steps, the J lanes
+// read the reflector twice (40 x 16 bytes) and only 148 of 256 lanes carry the 2 n^2 m flops of J <- J Q: 37 k cycles for
+// 18 reflectors (profiles/r03/v20_phase.txt).  Requires n <= 80, m <= 22, m + n <= 102.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbuf, double* sc)
+{
+    const int n = c.n, m = c.neq, ldb = c.ldb, ldj = c.ldj, tid = c.tid;
+    const int e = tid >> 2, kc = tid & 3;
+    const int nvec = m + n, r2 = max(nvec - 64, 0);
+    const bool col1 = e < m;                 // round 1: a column of B ...
+    const int jr1 = e - m;                   // ... or row jr1 of J
+    const bool row1 = !col1 && jr1 < n;
+    const bool has2 = e >= 64 - r2;          // round 2: row jr2 of J
+    const int jr2 = 64 - m + (e - (64 - r2));
+    double b[10][2], b2[10][2];
+    {
+        const int es = col1 ? e : 0;
+        const double* Jr = c.J + (row1 ? jr1 : 0) * ldj;
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = 2 * kc + 8 * t + i, kk = min(k, n - 1);
+                const double vb = Bm[kk * ldb + es], vj = Jr[kk];
+                b[t][i] = (k < n && (col1 || row1)) ? (col1 ? vb : vj) : 0.0;
+            }
+        const double* Jr2 = c.J + (has2 ? jr2 : 0) * ldj;
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = 2 * kc + 8 * t + i;
+                const double vj = Jr2[min(k, n - 1)];
+                b2[t][i] = (k < n && has2) ? vj : 0.0;
+            }
+    }
+    double my_alpha = 1.0;
+    // reflector of column jn from the registers of its quad (call under e == jn): qr_resident's prepare, verbatim
+    auto prepare_t = [&](auto T0c, int jn) __attribute__((always_inline)) {
+        constexpr int T0 = decltype(T0c)::value;
+        const int row0 = 2 * kc + 8 * T0;
+        const double e0 = (row0 >= jn) ? b[T0][0] : 0.0, e1 = (row0 + 1 >= jn) ? b[T0][1] : 0.0;
+        double sq0 = e0 * e0, sq1 = e1 * e1, sq2 = 0.0, sq3 = 0.0;
+#pragma unroll
+        for (int t = T0 + 1; t + 1 < 10; t += 2) {
+            sq0 = fma(b[t][0], b[t][0], sq0);
+            sq1 = fma(b[t][1], b[t][1], sq1);
+            sq2 = fma(b[t + 1][0], b[t + 1][0], sq2);
+            sq3 = fma(b[t + 1][1], b[t + 1][1], sq3);
+        }
+        if constexpr (((10 - (T0 + 1)) & 1) != 0) {
+            sq0 = fma(b[9][0], b[9][0], sq0);
+            sq1 = fma(b[9][1], b[9][1], sq1);
+        }
+        double x0 = (row0 == jn) ? b[T0][0] : ((row0 + 1 == jn) ? b[T0][1] : 0.0);
+        const double nrm = quad_sum((sq0 + sq1) + (sq2 + sq3));
+        x0 = quad_sum(x0);
+        const double inx = rsqrt(nrm);
+        const double nx = (nrm > 0.0) ? nrm * inx : 0.0; // exactly dependent column: alpha = 0 -> reported as redundant
+        const double alpha = (x0 >= 0.0) ? -nx : nx;
+        const double v0 = x0 - alpha;
+        const double tj = fast_rcp(fma(nx, fabs(x0), nrm)); // 2 / v'v
+        my_alpha = alpha;
+        double* vb = vbuf + (jn & 1) * 80 + 2 * kc;
+        if (row0 == jn) b[T0][0] = v0;
+        if (row0 + 1 == jn) b[T0][1] = v0;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            double2v o;
+            if (t < T0) {
+                o.x = 0.0;
+                o.y = 0.0;
+            }
+            else if (t == T0) {
+                o.x = (row0 >= jn) ? b[T0][0] : 0.0;
+                o.y = (row0 + 1 >= jn) ? b[T0][1] : 0.0;
+            }
+            else {
+                o.x = b[t][0];
+                o.y = b[t][1];
+            }
+            *reinterpret_cast<double2v*>(__builtin_assume_aligned(vb + 8 * t, 16)) = o;
+        }
+        if (kc == 0) {
+            sc[(jn & 1) * 2] = tj;
+            sc[(jn & 1) * 2 + 1] = alpha;
+        }
+    };
+    auto prepare = [&](int jn) __attribute__((always_inline)) {
+        switch (jn >> 3) { // jn < 32
+        case 0: prepare_t(std::integral_constant<int, 0>{}, jn); break;
+        case 1: prepare_t(std::integral_constant<int, 1>{}, jn); break;
+        case 2: prepare_t(std::integral_constant<int, 2>{}, jn); break;
+        default: prepare_t(std::integral_constant<int, 3>{}, jn); break;
+        }
+    };
+    auto apply = [&](double (&x)[10][2], const double2v (&v)[10], double tj) __attribute__((always_inline)) {
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+        for (int t = 0; t < 10; t += 2) {
+            d0 = fma(v[t].x, x[t][0], d0);
+            d1 = fma(v[t].y, x[t][1], d1);
+            d2 = fma(v[t + 1].x, x[t + 1][0], d2);
+            d3 = fma(v[t + 1].y, x[t + 1][1], d3);
+        }
+        const double coef = quad_sum((d0 + d1) + (d2 + d3)) * tj;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            x[t][0] = fma(-coef, v[t].x, x[t][0]);
+            x[t][1] = fma(-coef, v[t].y, x[t][1]);
+        }
+    };
+    if (e == 0) prepare(0);
+    for (int j = 0; j < m; ++j) {
+        bsync();
+        const double tj = sc[(j & 1) * 2], alpha = sc[(j & 1) * 2 + 1];
+        if (!(fabs(alpha) > 2.220446049250313e-16 * c.R_norm)) return false; // also catches a NaN pivot
+        c.R_norm = fmax(c.R_norm, fabs(alpha));
+        const double* vb = vbuf + (j & 1) * 80 + 2 * kc;
+        double2v v[10];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) v[t] = ld2(vb + 8 * t);
+        if ((col1 && e > j) || row1) {
+            apply(b, v, tj);
+            if (e == j + 1 && j + 1 < m) prepare(j + 1);
+        }
+        if (has2) apply(b2, v, tj);
+    }
+    // R packed, 1/R(j,j); J rows back to LDS
+    if (col1) {
+        double* Rc = c.R + roff(e);
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 2 * kc + 8 * t + i;
+                if (row < e) Rc[row] = b[t][i];
+            }
+        if (kc == 0) {
+            Rc[e] = my_alpha;
+            c.rdinv[e] = 1.0 / my_alpha;
+        }
+    }
+    if (row1) {
+        double* Jr = c.J + jr1 * ldj;
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = 2 * kc + 8 * t + i;
+                if (k < n) Jr[k] = b[t][i];
+            }
+    }
+    if (has2) {
+        double* Jr = c.J + jr2 * ldj;
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = 2 * kc + 8 * t + i;
+                if (k < n) Jr[k] = b2[t][i];
+            }
+    }
+    return true;
+}
+
 // y = R'^-1 rhs (forward substitution) on one wave: lane = index.  Column `lane` of the packed R sits in registers
 // (clamped loads, all in flight at once); lanes past m carry zeros, so the loop runs to the compile-time bound MM >= m
 // without guards.  The multipliers u = R^-1 y of the equality rows are not formed: no later decision reads them (the
