@@ -31,6 +31,9 @@
 #ifndef WBCQP_X_JUPD
 #define WBCQP_X_JUPD 0
 #endif
+#ifndef WBCQP_X_DCOL
+#define WBCQP_X_DCOL 1 // 1: d = J'n of an actuation row over the columns from neq on, a quad per column; 0: all columns, a lane pair each
+#endif
 #ifndef WBCQP_X_QR
 #define WBCQP_X_QR 1 // 1: qr_unified (every vector on a quad of its own), 0: qr_resident (round 2)
 #endif
@@ -1030,7 +1033,19 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
                 bsync();
             }
-            else if (kind == INEQ_ACTUATION) { // two lanes per column, halves of the support
+            else if (kind == INEQ_ACTUATION) {
+#if WBCQP_X_DCOL
+                // only the columns from neq on: the first neq columns of J (the equality block) feed r of the equality rows, which
+                // nothing reads.  n - neq <= 64 columns (host check): a quad per column, a quarter of the support per lane
+                const int idx = neq + (tid >> 2), q4 = tid & 3;
+                const int ic = min(idx, n - 1);
+                const int qlen = (n + 3) >> 2;
+                const int ka = q4 * qlen, kb = min(n, ka + qlen);
+                double acc = dot8(c.np, 1, c.J + ic, ldj, ka, kb);
+                acc = quad_sum(acc);
+                if (q4 == 0 && idx < n) c.d[idx] = acc;
+#else
+                // two lanes per column, halves of the support
                 const int idx = tid >> 1, hf = tid & 1;
                 const int ic = min(idx, n - 1);
                 const int mid = (n + 1) >> 1;
@@ -1038,6 +1053,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 double acc = dot8(c.np, 1, c.J + ic, ldj, ka, hf ? n : mid);
                 acc += dpp_get<0xB1>(acc);
                 if (hf == 0 && idx < n) c.d[idx] = acc;
+#endif
                 bsync();
             }
             STAMP(11)
