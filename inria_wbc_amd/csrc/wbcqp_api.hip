@@ -45,6 +45,13 @@ struct Staging {
     void* dev = nullptr;
     size_t bytes = 0;
 };
+// page-locked host memory for the host-pointer entry points at small batches: the eleven input arrays of a QP record (five output
+// arrays) cross PCIe as ONE copy each way instead of eleven (five) -- at batch 1 the copies' fixed cost is most of the call
+struct Pinned {
+    void* host = nullptr;
+    size_t bytes = 0;
+};
+constexpr size_t kPackedBytes = 1u << 20; // above this the arrays go up one by one (the extra host copy would cost more than it saves)
 
 } // namespace
 
@@ -72,6 +79,7 @@ struct wbcqp_handle {
     std::string err;
     Slot slots[WBCQP_MAX_STRUCTURES];
     Staging stage_in, stage_out;
+    Pinned pin_in, pin_out;
     int max_lds[2] = {0, 0};   // per kernel variant (full, compact): largest dynamic LDS size set so far
     long long* dbg = nullptr; // diagnostic builds only (wbcqp_debug_set_stamp_buffer)
     // longest-first schedule (schedule_kernel): launch order for the next solve of the same shape on the same stream
@@ -430,6 +438,17 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
 
 // the small structures of a launch: one wavefront per QP, four per workgroup, in table order (no launch order: the QPs are
 // short and alike, and 32 of them are resident per CU)
+int ensure_pinned(wbcqp_handle* h, Pinned& p, size_t bytes)
+{
+    if (p.bytes >= bytes) return WBCQP_OK;
+    if (p.host) (void)hipHostFree(p.host);
+    p.host = nullptr;
+    p.bytes = 0;
+    HIP_TRY(h, hipHostMalloc(&p.host, bytes, hipHostMallocDefault));
+    p.bytes = bytes;
+    return WBCQP_OK;
+}
+
 template <typename TI>
 int launch_small(wbcqp_handle* h, GroupTable<TI>& tab, int total, hipStream_t stream)
 {
@@ -508,6 +527,8 @@ int wbcqp_destroy(wbcqp_handle* h)
     for (auto& s : h->slots) release(s);
     if (h->stage_in.dev) (void)hipFree(h->stage_in.dev);
     if (h->stage_out.dev) (void)hipFree(h->stage_out.dev);
+    if (h->pin_in.host) (void)hipHostFree(h->pin_in.host);
+    if (h->pin_out.host) (void)hipHostFree(h->pin_out.host);
     if (h->roll_rec.dev) (void)hipFree(h->roll_rec.dev);
     if (h->roll_state.dev) (void)hipFree(h->roll_state.dev);
     for (auto& r : h->roll_subs) {
@@ -711,8 +732,20 @@ int wbcqp_solve_batch_host(wbcqp_handle* h, int slot, int batch, const wbcqp_inp
     if (rc != WBCQP_OK) return rc;
     char* din = static_cast<char*>(h->stage_in.dev);
     char* dout = static_cast<char*>(h->stage_out.dev);
-    for (int f = 0; f < 11; ++f)
-        if (lens[f] > 0) HIP_TRY(h, hipMemcpyAsync(din + offs[f], src[f], (size_t)lens[f] * batch * es, hipMemcpyHostToDevice, nullptr));
+    const bool packed = in_bytes + (size_t)batch * 32 <= kPackedBytes && out_bytes <= kPackedBytes;
+    if (packed) {
+        rc = ensure_pinned(h, h->pin_in, kPackedBytes);
+        if (rc != WBCQP_OK) return rc;
+        rc = ensure_pinned(h, h->pin_out, kPackedBytes);
+        if (rc != WBCQP_OK) return rc;
+        char* pin = static_cast<char*>(h->pin_in.host);
+        for (int f = 0; f < 11; ++f)
+            if (lens[f] > 0) std::memcpy(pin + offs[f], src[f], (size_t)lens[f] * batch * es);
+        HIP_TRY(h, hipMemcpyAsync(din, pin, in_bytes, hipMemcpyHostToDevice, nullptr));
+    }
+    else
+        for (int f = 0; f < 11; ++f)
+            if (lens[f] > 0) HIP_TRY(h, hipMemcpyAsync(din + offs[f], src[f], (size_t)lens[f] * batch * es, hipMemcpyHostToDevice, nullptr));
     wbcqp_inputs di = {din + offs[0], din + offs[1], din + offs[2], din + offs[3], din + offs[4], din + offs[5],
                        din + offs[6], din + offs[7], din + offs[8], din + offs[9], din + offs[10]};
     wbcqp_outputs dso{};
@@ -725,6 +758,19 @@ int wbcqp_solve_batch_host(wbcqp_handle* h, int slot, int batch, const wbcqp_inp
     }
     rc = wbcqp_solve_batch(h, slot, batch, &di, &dso, nullptr);
     if (rc != WBCQP_OK) return rc;
+    if (packed) { // one copy down, then the arrays are taken apart on the host
+        char* po = static_cast<char*>(h->pin_out.host);
+        HIP_TRY(h, hipMemcpyAsync(po, dout, out_bytes, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(h, hipStreamSynchronize(nullptr));
+        std::memcpy(out->x, po + o_x, (size_t)L.n * batch * es);
+        if (s.host.na > 0) std::memcpy(out->tau, po + o_tau, (size_t)s.host.na * batch * es);
+        std::memcpy(out->status, po + o_st, (size_t)batch * 4);
+        std::memcpy(out->iters, po + o_it, (size_t)batch * 4);
+        if (out->objective) std::memcpy(out->objective, po + o_obj, (size_t)batch * es);
+        if (out->n_active) std::memcpy(out->n_active, po + o_na, (size_t)batch * 4);
+        if (out->active_mask) std::memcpy(out->active_mask, po + o_am, (size_t)batch * 32);
+        return WBCQP_OK;
+    }
     if (out->active_mask) HIP_TRY(h, hipMemcpyAsync(out->active_mask, dso.active_mask, (size_t)batch * 32, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipMemcpyAsync(out->x, dso.x, (size_t)L.n * batch * es, hipMemcpyDeviceToHost, nullptr));
     if (s.host.na > 0) HIP_TRY(h, hipMemcpyAsync(out->tau, dso.tau, (size_t)s.host.na * batch * es, hipMemcpyDeviceToHost, nullptr));
@@ -1424,8 +1470,21 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     if (rc != WBCQP_OK) return rc;
     char* din = static_cast<char*>(h->stage_in.dev);
     char* dout = static_cast<char*>(h->stage_out.dev);
-    for (int f = 0; f < 6; ++f)
-        if (ilen[f] > 0) HIP_TRY(h, hipMemcpyAsync(din + ioff[f], isrc[f], (size_t)ilen[f] * B * es, hipMemcpyHostToDevice, nullptr));
+    const size_t in_only = roff[0]; // the inputs lie in front of the record: [0, roff[0])
+    const bool packed = in_only <= kPackedBytes && out_bytes <= kPackedBytes;
+    if (packed) {
+        rc = ensure_pinned(h, h->pin_in, kPackedBytes);
+        if (rc != WBCQP_OK) return rc;
+        rc = ensure_pinned(h, h->pin_out, kPackedBytes);
+        if (rc != WBCQP_OK) return rc;
+        char* pin = static_cast<char*>(h->pin_in.host);
+        for (int f = 0; f < 6; ++f)
+            if (ilen[f] > 0) std::memcpy(pin + ioff[f], isrc[f], (size_t)ilen[f] * B * es);
+        HIP_TRY(h, hipMemcpyAsync(din, pin, in_only, hipMemcpyHostToDevice, nullptr));
+    }
+    else
+        for (int f = 0; f < 6; ++f)
+            if (ilen[f] > 0) HIP_TRY(h, hipMemcpyAsync(din + ioff[f], isrc[f], (size_t)ilen[f] * B * es, hipMemcpyHostToDevice, nullptr));
     wbcqp_tick_io d{};
     d.state = {din + ioff[0], din + ioff[1], din + ioff[2], io->state.momentum ? dout + o_mom : nullptr};
     d.rows.M = din + roff[0]; d.rows.h = din + roff[1]; d.rows.A = din + roff[2]; d.rows.b1 = din + roff[3]; d.rows.Ac = din + roff[4];
@@ -1438,6 +1497,24 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     d.dt = io->dt;
     rc = wbcqp_tick(h, slot, batch, &d, nullptr);
     if (rc != WBCQP_OK) return rc;
+    if (packed) { // one copy down (the rows, when asked for, follow one by one), then taken apart on the host
+        char* po = static_cast<char*>(h->pin_out.host);
+        HIP_TRY(h, hipMemcpyAsync(po, dout, out_bytes, hipMemcpyDeviceToHost, nullptr));
+        for (int f = 0; f < 8; ++f)
+            if (rlen[f] > 0 && rdst[f]) HIP_TRY(h, hipMemcpyAsync(rdst[f], din + roff[f], (size_t)rlen[f] * B * es, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(h, hipStreamSynchronize(nullptr));
+        std::memcpy(io->out.x, po + o_x, (size_t)L.n * B * es);
+        if (s.host.na > 0) std::memcpy(io->out.tau, po + o_tau, (size_t)s.host.na * B * es);
+        std::memcpy(io->out.status, po + o_st, B * 4);
+        std::memcpy(io->out.iters, po + o_it, B * 4);
+        if (io->out.objective) std::memcpy(io->out.objective, po + o_obj, B * es);
+        if (io->out.n_active) std::memcpy(io->out.n_active, po + o_na, B * 4);
+        std::memcpy(io->q_next, po + o_qn, (size_t)T.nq * B * es);
+        std::memcpy(io->v_next, po + o_vn, (size_t)T.nv * B * es);
+        if (io->q_solver) std::memcpy(io->q_solver, po + o_qs, (size_t)T.nv * B * es);
+        if (io->state.momentum) std::memcpy(io->state.momentum, po + o_mom, (size_t)6 * B * es);
+        return WBCQP_OK;
+    }
     HIP_TRY(h, hipMemcpyAsync(io->out.x, d.out.x, (size_t)L.n * B * es, hipMemcpyDeviceToHost, nullptr));
     if (s.host.na > 0) HIP_TRY(h, hipMemcpyAsync(io->out.tau, d.out.tau, (size_t)s.host.na * B * es, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipMemcpyAsync(io->out.status, d.out.status, B * 4, hipMemcpyDeviceToHost, nullptr));
