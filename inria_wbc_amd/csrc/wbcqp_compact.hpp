@@ -38,6 +38,12 @@
 #define WBCQP_X_QR 1 // 1: qr_unified (every vector on a quad of its own), 0: qr_resident (round 2)
 #endif
 
+#if defined(WBCQP_X_STOP) && !defined(WBCQP_STAMPS)
+// instruction accounting (tools/phase_insts.sh): the QP ends at stamp WBCQP_X_STOP, so the SQ counters of two such builds differ by one phase
+#undef STAMP
+#define STAMP(i) { if ((i) == WBCQP_X_STOP) return; }
+#endif
+
 namespace wbcqp {
 #ifdef __HIPCC__
 
@@ -1412,3 +1418,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
 
 #endif // __HIPCC__
 } // namespace wbcqp
+
+#if defined(WBCQP_X_STOP) && !defined(WBCQP_STAMPS)
+#undef STAMP
+#define STAMP(i)
+#endif
