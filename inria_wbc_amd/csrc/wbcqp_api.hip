@@ -1154,10 +1154,9 @@ static int derive_terms(wbcqp_handle* h, const DevStruct& D, const wbcqp_model* 
     T.o_state = take(nq + nv + tm->nref);
     T.o_kin = take(nb * kKinStride);
     T.o_scan = take((nb + 1) * kScanStride);
-    T.o_tot = take(8); // momentum totals
+    T.o_tot = take(8); // momentum totals (6), the frames-published flag
     T.o_sf = take(nv * kSFStride);
     T.o_law = take(T.nlaw * kLawStride);
-    T.o_law3 = take(T.nlaw * kLawStride); // wave 3's own copy of the task frames
     T.o_pair = take(T.npair * kPairStride);
     T.o_scf = take(T.nscf * kScfStride);
     T.o_b1 = take(D.r1);

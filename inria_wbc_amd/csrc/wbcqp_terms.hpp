@@ -62,7 +62,7 @@ struct TermsDev {
     int d_blk_kp, d_blk_kd;                                  // [nblock]
     int d_qlb, d_qub, d_dqmax;                               // [na]
     // LDS layout (doubles)
-    int o_state, o_kin, o_scan, o_tot, o_sf, o_law, o_law3, o_pair, o_scf, o_b1, o_bc;
+    int o_state, o_kin, o_scan, o_tot, o_sf, o_law, o_pair, o_scf, o_b1, o_bc;
     int lds_doubles;
 };
 
@@ -118,6 +118,37 @@ __device__ __forceinline__ double scan_incl(double v, int lane)
     return v;
 }
 
+// sin and cos of a joint angle: Cody-Waite reduction by pi/2 in two fused steps and the fdlibm kernel polynomials on
+// [-pi/4, pi/4] -- some 35 instructions where the library's sincos() is over a hundred (it carries the reduction for
+// arguments of any size).  Under one ulp up to |x| = 1e5, which no joint angle reaches; beyond that the library's.
+__device__ __forceinline__ void sincos_joint(double x, double* sn, double* cs)
+{
+    if (!(fabs(x) < 1.0e5)) {
+        sincos(x, sn, cs);
+        return;
+    }
+    const double k = rint(x * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632679489655800e+00, x);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double S = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double C = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double s0 = (q & 1) ? C : S, c0 = (q & 1) ? S : C;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 // pinocchio log3 [UPSTREAM-RECALL, as oracle/rbd_oracle.c wbco_log3]
 __device__ __forceinline__ V3 log3(const double* R)
 {
@@ -133,8 +164,11 @@ __device__ __forceinline__ V3 log3(const double* R)
         return {(R[7] > R[5] ? 1.0 : -1.0) * (t0 > 0.0 ? sqrt(t0) : 0.0), (R[2] > R[6] ? 1.0 : -1.0) * (t1 > 0.0 ? sqrt(t1) : 0.0),
                 (R[3] > R[1] ? 1.0 : -1.0) * (t2 > 0.0 ? sqrt(t2) : 0.0)};
     }
-    const double t = ((theta > 1.220703125e-4) ? theta / sin(theta) : 1.0) / 2.0;
-    return {t * (R[7] - R[5]), t * (R[2] - R[6]), t * (R[3] - R[1])};
+    // theta / (2 sin theta): 2 sin(theta) is the length of the antisymmetric part itself (one square root where sin() is ~150
+    // instructions; the two agree to rounding on (1.2e-4, pi - 1e-2))
+    const V3 w = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+    const double t = (theta > 1.220703125e-4) ? theta / sqrt(dot(w, w)) : 0.5;
+    return {t * w.x, t * w.y, t * w.z};
 }
 
 // Frame placement, velocity and classical acceleration in the frame's own axes (tsid RobotWrapper::framePosition /
@@ -161,15 +195,14 @@ __device__ __forceinline__ int rl(int v, int src) { return __builtin_amdgcn_read
 
 // Column j of the world-aligned joint Jacobian: the joint's motion subspace column in its own axes, moved by oMi.act(.)
 struct ColumnAxis { int body, last; V3 Sv, Sw; };
-__device__ __forceinline__ ColumnAxis column_axis(const TermsDev& T, const double* kin, int cj)
+// (body, last, kj, jtj: the column's constants -- its body, the last body of that body's subtree, the index of the dof inside its
+// joint, the joint type -- fetched once per thread at the top of the kernel)
+__device__ __forceinline__ ColumnAxis column_axis(const double* kin, int body, int last, int kj, int jtj)
 {
-    const int* ip = T.ipool;
     ColumnAxis c;
-    c.body = ip[T.i_bodyof + cj];
-    const int kj = ip[T.i_kof + cj];
-    c.last = ip[T.i_last + c.body];
+    c.body = body;
+    c.last = last;
     const double* K = kin + kKinStride * c.body;
-    const int jtj = ip[T.i_jtype + c.body];
     const int a = (jtj == J_FREEFLYER) ? (kj % 3) : (jtj <= J_RZ) ? jtj - J_RX : jtj - J_PX;
     const bool ang = (jtj == J_FREEFLYER) ? (kj >= 3) : (jtj <= J_RZ);
     const V3 ax = col(K, 0), ay = col(K, 1), az = col(K, 2);
@@ -211,8 +244,8 @@ constexpr int kTermsThreads = 256; // four wavefronts per instance: one runs the
 
 // One workgroup of four wavefronts per instance.
 //   phase 1  wave 0: joint transforms and the sweep down the tree;  wave 3 meanwhile: posture right-hand side, joint bounds
-//   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames, their laws, a third of their Jacobian
-//            rows;  wave 2: self-collision frames and pairs;  wave 3: the other two thirds of the Jacobian rows
+//   phase 2  wave 0: world inertias, bias forces, prefix sums;  wave 1: task frames (published at once, with a flag), their laws, a
+//            third of their Jacobian rows;  wave 2: self-collision frames and pairs;  wave 3: the other two thirds of the Jacobian rows
 //   phase 3  every wave: S_j and F_j of its lanes' columns (from wave 0, through LDS), then a quarter of the remaining rows each -- rows of M,
 //            CoM / momentum / self-collision rows
 // inst: which instance's state and references are read; rinst: where the record goes in the row arrays (the same index for the
@@ -243,7 +276,13 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
     double* b1s = lds + T.o_b1;
     double* bcs = lds + T.o_bc;
     double* tots = lds + T.o_tot; // total momentum of the robot (6 doubles)
+    int* frames_ready = reinterpret_cast<int*>(tots + 6); // wave 1 has published the task frames (wave 3 waits for it, nobody else)
 
+    // the constants of this lane's column (two dependent global reads): asked for here, they arrive behind the state; phases 2 and 3
+    // used to fetch them again on every wave, the second time right after a barrier
+    const int cj = min(lane, nv - 1);
+    const int bj = ip[T.i_bodyof + cj], kofj = ip[T.i_kof + cj];
+    const int lastj = ip[T.i_last + bj], jtypej = ip[T.i_jtype + bj];
     // ---- state and references into LDS ----------------------------------------------------------------------------
     {
         // one pass: every thread fetches its elements of the three arrays before any of them is stored
@@ -263,6 +302,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         for (int e = tid + 2 * kTermsThreads; e < n3; e += kTermsThreads)
             q[e] = (double)((e < n1) ? gq[e] : (e < n2) ? gv[e - n1] : gr[e - n2]);
         for (int i = tid; i < T.r1; i += kTermsThreads) b1s[i] = 0.0;
+        if (tid == 0) __hip_atomic_store(frames_ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     TSTAMP(0)
@@ -298,7 +338,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
                 const V3 e = {a == 0 ? qd : 0.0, a == 1 ? qd : 0.0, a == 2 ? qd : 0.0};
                 if (jt <= J_RZ) {
                     double sn, cs;
-                    sincos(q[iq], &sn, &cs);
+                    sincos_joint(q[iq], &sn, &cs);
                     // P.R * Rot(axis): the axis column stays, the other two mix
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
@@ -466,7 +506,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         // the four waves of phase 3 (this wave has time to spare here: the task-law wave is the long one in phase 2)
         {
             const bool colv = lane < nv;
-            const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
+            const ColumnAxis c = column_axis(kin, bj, lastj, kofj, jtypej);
             const double* hi = scan + kScanStride * (c.last + 1); // prefix(last + 1) - prefix(body)
             const double* lo = scan + kScanStride * c.body;
             double Y[16];
@@ -496,9 +536,10 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         }
         // joint bounds: tsid TaskJointPosVelAccBounds::computeAccLimits [UPSTREAM-RECALL, as oracle/rbd_oracle.c]
         for (int j = lane; j < T.n_bound; j += kWave) {
-            const double dt = T.dt, qj = q[nq - na + j], dq = v[nv - na + j];
-            const double qmin = dp[T.d_qlb + j], qmax = dp[T.d_qub + j], dqmax = dp[T.d_dqmax + j], ddqmax = dqmax / dt;
-            const double two_dt_sq = 2.0 / (dt * dt), mdq_dt = -dq / dt;
+            // (the divisions by dt and by 2 dt^2 are multiplications by reciprocals formed once: a double division is ~30 instructions)
+            const double dt = T.dt, idt = 1.0 / dt, qj = q[nq - na + j], dq = v[nv - na + j];
+            const double qmin = dp[T.d_qlb + j], qmax = dp[T.d_qub + j], dqmax = dp[T.d_dqmax + j], ddqmax = dqmax * idt;
+            const double two_dt_sq = 2.0 * idt * idt, mdq_dt = -dq * idt;
             const double max_q3 = two_dt_sq * (qmax - qj - dt * dq), min_q3 = two_dt_sq * (qmin - qj - dt * dq);
             double lb_pos, ub_pos;
             if (dq <= 0.0) {
@@ -513,13 +554,13 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
                 else if (qj != qmax) ub_pos = fmin(-dq * dq / (2.0 * (qmax - qj)), mdq_dt);
                 else ub_pos = -1e6;
             }
-            const double lb_vel = (-dqmax - dq) / dt, ub_vel = (dqmax - dq) / dt;
-            const double dt_dq = dt * dq, two_a = 2.0 * dt * dt, dt_ddq_dt = ddqmax * dt * dt;
+            const double lb_vel = (-dqmax - dq) * idt, ub_vel = (dqmax - dq) * idt;
+            const double dt_dq = dt * dq, two_a = 2.0 * dt * dt, i_two_a = 0.5 * idt * idt, dt_ddq_dt = ddqmax * dt * dt;
             const double b_1 = 2.0 * dt_dq + dt_ddq_dt, b_2 = 2.0 * dt_dq - dt_ddq_dt;
             const double c_1 = dq * dq - 2.0 * ddqmax * (qmax - (qj + dt_dq)), c_2 = dq * dq - 2.0 * ddqmax * ((qj + dt_dq) - qmin);
             const double delta_1 = b_1 * b_1 - 2.0 * two_a * c_1, delta_2 = b_2 * b_2 - 2.0 * two_a * c_2;
-            const double ub_via = delta_1 >= 0.0 ? (-b_1 + sqrt(delta_1)) / two_a : mdq_dt;
-            const double lb_via = delta_2 >= 0.0 ? (-b_2 - sqrt(delta_2)) / two_a : mdq_dt;
+            const double ub_via = delta_1 >= 0.0 ? (-b_1 + sqrt(delta_1)) * i_two_a : mdq_dt;
+            const double lb_via = delta_2 >= 0.0 ? (-b_2 - sqrt(delta_2)) * i_two_a : mdq_dt;
             double lb = fmax(fmax(lb_pos, lb_via), fmax(lb_vel, -ddqmax));
             double ub = fmin(fmin(ub_pos, ub_via), fmin(ub_vel, ddqmax));
             if (ub < lb) {
@@ -529,32 +570,18 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
             args.blb[(size_t)rinst * T.n_bound + j] = (TI)lb;
             args.bub[(size_t)rinst * T.n_bound + j] = (TI)ub;
         }
-        // ---- phase 2 on this wave: the Jacobian rows of two framed tasks in three (wave 1 takes the others).  The frames are
-        //      recomputed here into this wave's own copy of the table: cheaper than waiting for wave 1 to publish them ----------
-        const int ll = min(lane, max(T.nlaw - 1, 0));
-        const int l_body = ip[T.i_law_body + ll];
-        double l_place[12];
-#pragma unroll
-        for (int r = 0; r < 12; ++r) l_place[r] = dp[T.d_law_place + 12 * ll + r];
+        // ---- phase 2 on this wave: the Jacobian rows of two framed tasks in three (wave 1 takes the others).  The frames come
+        //      from wave 1 (round 2 recomputed them here, ~200 instructions on the vector port this kernel saturates): wave 1
+        //      publishes them first thing after the barrier and raises a flag; this wave sleeps on the flag, which costs no issue slot
         __syncthreads(); // barrier 1: kin is complete
-        double* law3 = lds + T.o_law3;
-        if (lane < T.nlaw) {
-            FrameKin f;
-            frame_kin(kin + kKinStride * l_body, l_place, f);
-            double* Lw = law3 + kLawStride * lane;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) Lw[r] = f.R[r];
-            st3(Lw + 9, f.p);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
             const bool colv = lane < nv;
-            const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
+            const ColumnAxis c = column_axis(kin, bj, lastj, kofj, jtypej);
+            while (__hip_atomic_load(frames_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             // two tasks in three here, one in three on wave 1, which also evaluates the laws
-            jacobian_rows<TI>(T, law3, c, colv, lane, 1, 3, args.A + (size_t)rinst * T.n_dense * nv, args.Ac + (size_t)rinst * T.nc * 6 * nv, nv);
-            jacobian_rows<TI>(T, law3, c, colv, lane, 2, 3, args.A + (size_t)rinst * T.n_dense * nv, args.Ac + (size_t)rinst * T.nc * 6 * nv, nv);
+            jacobian_rows<TI>(T, law, c, colv, lane, 1, 3, args.A + (size_t)rinst * T.n_dense * nv, args.Ac + (size_t)rinst * T.nc * 6 * nv, nv);
+            jacobian_rows<TI>(T, law, c, colv, lane, 2, 3, args.A + (size_t)rinst * T.n_dense * nv, args.Ac + (size_t)rinst * T.nc * 6 * nv, nv);
         }
     }
     else if (wave == 1) {
@@ -569,13 +596,17 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         for (int r = 0; r < 12; ++r) l_place[r] = dp[T.d_law_place + 12 * ll + r];
         __syncthreads(); // barrier 1: kin is complete
         {
+            FrameKin f;
             if (lane < T.nlaw) {
-                FrameKin f;
                 frame_kin(kin + kKinStride * l_body, l_place, f);
                 double* Lw = law + kLawStride * lane;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) Lw[r] = f.R[r];
                 st3(Lw + 9, f.p);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(frames_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane < T.nlaw) {
                 const double* rf = ref + l_ref;
                 // errorInSE3: M_err = oMf^-1 M_ref -> (translation, log3(rotation)); the reference rotation is column-major
                 const V3 pe = mtv(f.R, (ld3(rf) - p0) - f.p);
@@ -610,7 +641,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             {
                 const bool colv = lane < nv;
-                const ColumnAxis c = column_axis(T, kin, colv ? lane : 0);
+                const ColumnAxis c = column_axis(kin, bj, lastj, kofj, jtypej);
                 jacobian_rows<TI>(T, law, c, colv, lane, 0, 3, args.A + (size_t)rinst * T.n_dense * nv, args.Ac + (size_t)rinst * T.nc * 6 * nv, nv);
             }
             TSTAMP(4)
@@ -666,9 +697,11 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
                     const double e_p = exp(-x), e1 = e_p + 1.0;
                     const double pw1 = exp((-mm_ - 1.0) * log(e1)); // (1 + e)^(-m-1), e1 >= 1; the two neighbouring powers follow from it
                     const double C = 1.0 - pw1 * e1;
-                    const double gscale = -1.0 / norm * k5 * mm_ * e_p * pw1;
-                    const double hh = 1.0 / sn * k5 * k5 * (-mm_ - 1.0) * mm_ * (e_p * e_p) * (pw1 / e1)
-                        + 1.0 / sn * k5 * k5 * mm_ * e_p * pw1 + 1.0 / (norm * sqrt(norm)) * k5 * mm_ * e_p * pw1;
+                    // (1 / norm once; 1 / sn and 1 / (norm sqrt(norm)) follow from it -- the reference's expression has five divisions)
+                    const double inorm = 1.0 / norm, isn = inorm * inorm, ie1 = 1.0 / e1;
+                    const double kme = k5 * mm_ * e_p * pw1;
+                    const double gscale = -inorm * kme;
+                    const double hh = isn * k5 * (-mm_ - 1.0) * e_p * ie1 * kme + isn * k5 * kme + inorm * sqrt(inorm) * kme;
                     const double dJv = dot(diff, Jv);
                     const double quad = hh * dJv * dJv + gscale * dot(Jv, Jv); // Hess = hh diff diff' + gscale I (:156)
                     const V3 gd = gscale * diff;
@@ -708,21 +741,33 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         mo[3] = (TI)La.x; mo[4] = (TI)La.y; mo[5] = (TI)La.z;
     }
     const bool colv = lane < nv;
-    const int cj = colv ? lane : 0;
-    const int bj = ip[T.i_bodyof + cj], lastj = ip[T.i_last + bj];
     // S_j and F_j = Y_subtree(j) S_j of this lane's column: formed once, by wave 0 at the end of phase 2
     const double* SF = lds + T.o_sf + kSFStride * cj;
     const V3 Sv = ld3(SF), Sw = ld3(SF + 3), Fv = ld3(SF + 6), Fw = ld3(SF + 9);
     TSTAMP(7)
-    // M, row by row into the packed lower triangle: M(i, j) = S_j . F_i for j an ancestor dof of i (crba); F_i by readlane
+    // M, row by row into the packed lower triangle: M(i, j) = S_j . F_i for j an ancestor dof of i (crba)
     {
         TI* Mo = args.M + (size_t)rinst * (nv * (nv + 1) / 2);
-        for (int i = wave; i < nv; i += kWaves) {
-            const int b_i = rl(bj, i);
-            const V3 fv = {bcast_lane(Fv.x, i), bcast_lane(Fv.y, i), bcast_lane(Fv.z, i)};
-            const V3 fw = {bcast_lane(Fw.x, i), bcast_lane(Fw.y, i), bcast_lane(Fw.z, i)};
-            const double val = dot(Sv, fv) + dot(Sw, fw);
-            if (lane <= i) Mo[i * (i + 1) / 2 + lane] = (TI)((bj <= b_i && b_i <= lastj) ? val : 0.0);
+        // four rows in flight: the reads of F_i (LDS) and the stores of one row do not wait for the row before
+        for (int i0 = wave; i0 < nv; i0 += 4 * kWaves) {
+            V3 fv[4], fw[4];
+            int b_i[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * kWaves, nv - 1);
+                // F_i from the table (one address for the whole wave: a broadcast read on the LDS port; six readlane pairs would
+                // sit on the vector port, which is the one this kernel saturates)
+                const double* SFi = lds + T.o_sf + kSFStride * i + 6;
+                fv[u] = ld3(SFi);
+                fw[u] = ld3(SFi + 3);
+                b_i[u] = rl(bj, i);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kWaves;
+                const double val = dot(Sv, fv[u]) + dot(Sw, fw[u]);
+                if (i < nv && lane <= i) Mo[i * (i + 1) / 2 + lane] = (TI)((bj <= b_i[u] && b_i[u] <= lastj) ? val : 0.0);
+            }
         }
     }
     TSTAMP(8)

@@ -17,11 +17,12 @@ NAMES = ["load state", "joint transform", "tree sweep", "inertia+scan", "task la
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--time", default=None, metavar="LIB", help="no stamps: microseconds per launch of the rows kernel of this library (product build)")
     args = ap.parse_args()
     import torch
     from inria_wbc_amd import capi, structure
     from inria_wbc_amd import model as mdl
-    capi.LIB_PATH = os.path.join(ROOT, "inria_wbc_amd", "lib", "libwbcqp_stamps.so")
+    capi.LIB_PATH = os.path.abspath(args.time) if args.time else os.path.join(ROOT, "inria_wbc_amd", "lib", "libwbcqp_stamps.so")
     lib = capi.load_library(capi.LIB_PATH)
     m = mdl.talos_like()
     st = structure.talos_structure()
@@ -35,6 +36,20 @@ def main():
     L = st.field_lengths()
     state = {k: torch.from_numpy(s[k]).to(dev) for k in ("q", "v", "ref")}
     rows = {k: torch.zeros(B, L[k], dtype=torch.float64, device=dev) for k in capi.ROW_FIELDS}
+    if args.time:
+        sp = torch.cuda.current_stream().cuda_stream
+        for _ in range(5):
+            h.problem_data(0, B, state, rows, stream=sp)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            h.problem_data(0, B, state, rows, stream=sp)
+        e1.record()
+        torch.cuda.synchronize()
+        print("%s: batch %d, %.2f us per launch (200 back to back)" % (os.path.basename(capi.LIB_PATH), B, e0.elapsed_time(e1) / 200 * 1e3))
+        h.close()
+        return
     dbg = torch.zeros(B, 24, dtype=torch.int64, device=dev)
     lib.wbcqp_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
     assert lib.wbcqp_debug_set_stamp_buffer(h._h, C.c_void_p(dbg.data_ptr())) == 0
