@@ -24,20 +24,6 @@
 #include "wbcqp_equality.hpp"
 #include "wbcqp_activeset.hpp"
 
-// experiment switches (tools/variants.sh builds the combinations side by side; the defaults are what measured best)
-#ifndef WBCQP_X_ZDOT
-#define WBCQP_X_ZDOT 0
-#endif
-#ifndef WBCQP_X_JUPD
-#define WBCQP_X_JUPD 0
-#endif
-#ifndef WBCQP_X_DCOL
-#define WBCQP_X_DCOL 1 // 1: d = J'n of an actuation row over the columns from neq on, a quad per column; 0: all columns, a lane pair each
-#endif
-#ifndef WBCQP_X_QR
-#define WBCQP_X_QR 1 // 1: qr_unified (every vector on a quad of its own), 0: qr_resident (round 2)
-#endif
-
 #if defined(WBCQP_X_STOP) && !defined(WBCQP_STAMPS)
 // instruction accounting (tools/phase_insts.sh): the QP ends at stamp WBCQP_X_STOP, so the SQ counters of two such builds differ by one phase
 #undef STAMP
@@ -656,11 +642,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         }
         bsync();
         STAMP(5)
-#if WBCQP_X_QR
         bool ok = qr_unified(c, Nm, c.s, c.s + 160);
-#else
-        bool ok = qr_resident(c, Nm, c.s, c.s + 160);
-#endif
         if (!ok) status = HQP_ERROR; // redundant equalities
         else {
             bsync();
@@ -1040,7 +1022,6 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 bsync();
             }
             else if (kind == INEQ_ACTUATION) {
-#if WBCQP_X_DCOL
                 // only the columns from neq on: the first neq columns of J (the equality block) feed r of the equality rows, which
                 // nothing reads.  n - neq <= 64 columns (host check): a quad per column, a quarter of the support per lane
                 const int idx = neq + (tid >> 2), q4 = tid & 3;
@@ -1050,16 +1031,6 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 double acc = dot8(c.np, 1, c.J + ic, ldj, ka, kb);
                 acc = quad_sum(acc);
                 if (q4 == 0 && idx < n) c.d[idx] = acc;
-#else
-                // two lanes per column, halves of the support
-                const int idx = tid >> 1, hf = tid & 1;
-                const int ic = min(idx, n - 1);
-                const int mid = (n + 1) >> 1;
-                const int ka = hf ? mid : 0;
-                double acc = dot8(c.np, 1, c.J + ic, ldj, ka, hf ? n : mid);
-                acc += dpp_get<0xB1>(acc);
-                if (hf == 0 && idx < n) c.d[idx] = acc;
-#endif
                 bsync();
             }
             STAMP(11)
@@ -1075,11 +1046,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     const int span = n - iq, hlen = (span + 1) >> 1;
                     const int ca = iq + hf * hlen;
                     const double* Jr = c.J + ir * ldj;
-#if WBCQP_X_ZDOT
-                    double zv = dsg * dotp(Jr + ca, 1, dsrc + ca, 1, hlen, hf ? span - hlen : hlen);
-#else
                     double zv = dsg * dot8(Jr, 1, dsrc, 1, ca, min(n, ca + hlen));
-#endif
                     zv += dpp_get<0xB1>(zv);
                     STAMP(18)
                     double zz = 0.0, dn2 = 0.0;
@@ -1181,22 +1148,19 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                             double* Jk = c.J + kr * ldj;
                             const double wk = tau * (c.z[kr] - alpha * c.part[kr]);
                             // eight columns' operands in flight from ONE address + immediates (reads past cb stay inside LDS and
-                            // are not used), the next block's loads issued before this block's stores (the compiler cannot move
-                            // them there itself: it must assume the stores alias); only the last block's stores are masked, by
-                            // wave-uniform branches.  (A scalar tail costs an LDS round trip per element.)
-                            double dd0[8], jj0[8], dd1[8], jj1[8];
-                            auto ldb = [&](int cc, double (&dd)[8], double (&jj)[8]) __attribute__((always_inline)) {
+                            // are not used); only the last block's stores are masked, by wave-uniform branches.  (A scalar tail costs
+                            // an LDS round trip per element.  Measured and not kept: the next block's loads issued before this
+                            // block's stores -- slower, 256 registers; the columns by quarters on all four waves -- no change.)
+                            for (int cc = ca; cc < cb; cc += 8) {
                                 const double* dq = c.d + cc;
-                                const double* Jq = Jk + cc;
+                                double* Jq = Jk + cc;
+                                double dd[8], jj[8];
 #pragma unroll
                                 for (int u = 0; u < 8; ++u) {
                                     dd[u] = dq[u];
                                     jj[u] = Jq[u];
                                 }
                                 if (cc == iq) dd[0] = v0; // v = d[iq:] - alpha e_0
-                            };
-                            auto stb = [&](int cc, const double (&dd)[8], const double (&jj)[8]) __attribute__((always_inline)) {
-                                double* Jq = Jk + cc;
                                 if (cc + 8 <= cb) {
 #pragma unroll
                                     for (int u = 0; u < 8; ++u) Jq[u] = fma(-wk, dd[u], jj[u]);
@@ -1206,28 +1170,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                                     for (int u = 0; u < 7; ++u)
                                         if (cc + u < cb) Jq[u] = fma(-wk, dd[u], jj[u]);
                                 }
-                            };
-#if !WBCQP_X_JUPD
-                            for (int cc = ca; cc < cb; cc += 8) {
-                                ldb(cc, dd0, jj0);
-                                stb(cc, dd0, jj0);
                             }
-#else
-                            if (ca < cb) {
-                                ldb(ca, dd0, jj0);
-                                int cc = ca;
-                                while (true) {
-                                    if (cc + 8 < cb) ldb(cc + 8, dd1, jj1);
-                                    stb(cc, dd0, jj0);
-                                    cc += 8;
-                                    if (cc >= cb) break;
-                                    if (cc + 8 < cb) ldb(cc + 8, dd0, jj0);
-                                    stb(cc, dd1, jj1);
-                                    cc += 8;
-                                    if (cc >= cb) break;
-                                }
-                            }
-#endif
                         }
                     }
                     STAMP(21)

@@ -8,229 +8,22 @@ namespace wbcqp {
 #ifdef __HIPCC__
 
 // ------------------------------------------------------------------------------------------------
-// Householder QR of B (n x m, n <= 80, m <= 22: 4 m + 2 n <= 256) with J <- J Q in its shadow.
-// QR: columns resident in registers, 4 lanes per column (the first 4 m lanes), lane kc of a column keeps the row pairs
-// (2 kc + 8 t, + 1), t < 10.  Per step only the reflector travels: the owner of column j leaves v_j (zeros above row j,
-// v0 on it) and (tau_j, alpha_j) in LDS, every later column reads it once (10 x 16 bytes per lane), reduces its dot
-// product over its quad by DPP and updates its registers; the lanes of column j + 1 go on to the next reflector.  One
-// barrier per column, no reloads or stores of the trailing matrix.
-// J Q: the last 2 n lanes are not part of the QR.  A lane pair keeps ROW r of J (40 + 40 doubles) in registers and
-// applies every reflector as it appears: row <- row - tau (row . v_j) v_j' -- row-local, the two halves of the dot
-// product meet by DPP, no barrier of its own, and it fits in the time the QR needs for its step.  This replaces the
-// compact-WY route (W = J V, W T, J - W T V': three LDS GEMM phases, 20 k cycles) by work nobody waits for.
-// (One lane per row needs 160 VGPRs for the row: the allocator then parks it in AGPRs, 4 k cycles per step.)
+// Householder QR of B (n x m) with J <- J Q in its shadow; every vector on a quad of its own.  A column of B and a row of J
+// take the same operation per reflector, x <- x - tau (x . v) v: m columns + n rows = up to 102 vectors, four lanes each, lane
+// kc of a vector keeps the row pairs (2 kc + 8 t, + 1), t < 10, in registers for the whole factorisation.  Per step only the
+// reflector travels: the quad of column j leaves v_j (zeros above row j, v0 on it) and (tau_j, alpha_j) in LDS, every other
+// vector reads it ONCE (10 x 16 bytes per lane), reduces its dot product over its quad by DPP and updates its registers; the
+// quad of column j + 1 goes on to the next reflector.  One barrier per column, no reloads or stores of the trailing matrix, and
+// J <- J Q costs no phase of its own (the compact-WY route -- W = J V, W T, J - W T V' -- is three LDS GEMM phases, 20 k cycles).
+// Round 1: vectors 0..63 on the 64 quads (the columns of B first); round 2: the remaining rows of J on the LAST quads (waves 2
+// and 3), so the waves that carry the columns' critical path have one round only.  (Round 2's form, qr_resident, kept a lane
+// pair per row of J and the columns on the first lanes: wave 1 ran the column path and the row path one after the other in 16
+// of 18 steps and the J lanes read the reflector twice; this form returned 36 registers, not time: a step is as long as the
+// chain of the next reflector on ONE wave -- measured with stamps inside a step: 1.5 k of its 2.1 k cycles, the rest is the
+// drain of its stores and the barrier; the other waves need 0.7 k.  Measured and not kept: the barrier replaced by a counter
+// of published reflectors with a slot per reflector, so that the rows of J trail the columns -- same time, the chain does not
+// wait for the other waves.)  Requires n <= 80, m <= 22, m + n <= 102.
 // On return: J = J0 Q in LDS, the packed R and 1/R(j,j).  Returns false when a column is (numerically) dependent.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool qr_resident(Ctx& c, const double* Bm, double* vbuf, double* sc)
-{
-    const int n = c.n, m = c.neq, ldb = c.ldb, ldj = c.ldj, tid = c.tid;
-    const int e = tid >> 2, kc = tid & 3;
-    const bool colv = e < m;
-    const int es = colv ? e : 0;
-    const int jl = tid - (kThreads - 2 * n); // lane pair of a row of J (the last 2 n lanes), < 0: none
-    const int jr = jl >> 1, jh = jl & 1;
-    double b[10][2];
-#pragma unroll
-    for (int t = 0; t < 10; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = 2 * kc + 8 * t + i;
-            const double v = Bm[min(row, n - 1) * ldb + es];
-            b[t][i] = (row < n) ? v : 0.0;
-        }
-    double jrow[40];
-    if (jl >= 0) {
-        const double* Jr = c.J + jr * ldj;
-#pragma unroll
-        for (int q = 0; q < 40; ++q) {
-            const int cc = 40 * jh + q;
-            const double v = Jr[min(cc, n - 1)];
-            jrow[q] = (cc < n) ? v : 0.0;
-        }
-    }
-    double my_alpha = 1.0;
-    // reflector of column jn from the registers of its 4 lanes (call under e == jn).  T0 = jn >> 3 is a compile-time
-    // constant per instance: row pairs below T0 lie above the diagonal, pairs past it below -- only pair T0 needs masks
-    auto prepare_t = [&](auto T0c, int jn) __attribute__((always_inline)) {
-        constexpr int T0 = decltype(T0c)::value;
-        const int row0 = 2 * kc + 8 * T0;
-        const double e0 = (row0 >= jn) ? b[T0][0] : 0.0, e1 = (row0 + 1 >= jn) ? b[T0][1] : 0.0;
-        double sq0 = e0 * e0, sq1 = e1 * e1, sq2 = 0.0, sq3 = 0.0;
-#pragma unroll
-        for (int t = T0 + 1; t + 1 < 10; t += 2) {
-            sq0 = fma(b[t][0], b[t][0], sq0);
-            sq1 = fma(b[t][1], b[t][1], sq1);
-            sq2 = fma(b[t + 1][0], b[t + 1][0], sq2);
-            sq3 = fma(b[t + 1][1], b[t + 1][1], sq3);
-        }
-        if constexpr (((10 - (T0 + 1)) & 1) != 0) {
-            sq0 = fma(b[9][0], b[9][0], sq0);
-            sq1 = fma(b[9][1], b[9][1], sq1);
-        }
-        double x0 = (row0 == jn) ? b[T0][0] : ((row0 + 1 == jn) ? b[T0][1] : 0.0);
-        const double nrm = quad_sum((sq0 + sq1) + (sq2 + sq3));
-        x0 = quad_sum(x0);
-        const double inx = rsqrt(nrm);
-        const double nx = (nrm > 0.0) ? nrm * inx : 0.0; // exactly dependent column: alpha = 0 -> reported as redundant
-        const double alpha = (x0 >= 0.0) ? -nx : nx;
-        const double v0 = x0 - alpha;
-        const double tj = fast_rcp(fma(nx, fabs(x0), nrm)); // 2 / v'v
-        my_alpha = alpha;
-        double* vb = vbuf + (jn & 1) * 80 + 2 * kc;
-        if (row0 == jn) b[T0][0] = v0;
-        if (row0 + 1 == jn) b[T0][1] = v0;
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            double2v o;
-            if (t < T0) {
-                o.x = 0.0;
-                o.y = 0.0;
-            }
-            else if (t == T0) {
-                o.x = (row0 >= jn) ? b[T0][0] : 0.0;
-                o.y = (row0 + 1 >= jn) ? b[T0][1] : 0.0;
-            }
-            else {
-                o.x = b[t][0];
-                o.y = b[t][1];
-            }
-            *reinterpret_cast<double2v*>(__builtin_assume_aligned(vb + 8 * t, 16)) = o;
-        }
-        if (kc == 0) {
-            sc[(jn & 1) * 2] = tj;
-            sc[(jn & 1) * 2 + 1] = alpha;
-        }
-    };
-    auto prepare = [&](int jn) __attribute__((always_inline)) {
-        switch (jn >> 3) { // jn < 32
-        case 0: prepare_t(std::integral_constant<int, 0>{}, jn); break;
-        case 1: prepare_t(std::integral_constant<int, 1>{}, jn); break;
-        case 2: prepare_t(std::integral_constant<int, 2>{}, jn); break;
-        default: prepare_t(std::integral_constant<int, 3>{}, jn); break;
-        }
-    };
-    if (e == 0) prepare(0);
-    for (int j = 0; j < m; ++j) {
-        bsync();
-        const double tj = sc[(j & 1) * 2], alpha = sc[(j & 1) * 2 + 1];
-        if (!(fabs(alpha) > 2.220446049250313e-16 * c.R_norm)) return false; // also catches a NaN pivot
-        c.R_norm = fmax(c.R_norm, fabs(alpha));
-        const double* vbj = vbuf + (j & 1) * 80;
-        if (colv && e > j) {
-            const double* vb = vbj + 2 * kc;
-            double2v v[10];
-#pragma unroll
-            for (int t = 0; t < 10; ++t) v[t] = ld2(vb + 8 * t);
-            double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll
-            for (int t = 0; t < 10; t += 2) {
-                d0 = fma(v[t].x, b[t][0], d0);
-                d1 = fma(v[t].y, b[t][1], d1);
-                d2 = fma(v[t + 1].x, b[t + 1][0], d2);
-                d3 = fma(v[t + 1].y, b[t + 1][1], d3);
-            }
-            const double coef = quad_sum((d0 + d1) + (d2 + d3)) * tj;
-#pragma unroll
-            for (int t = 0; t < 10; ++t) {
-                b[t][0] = fma(-coef, v[t].x, b[t][0]);
-                b[t][1] = fma(-coef, v[t].y, b[t][1]);
-            }
-            if (e == j + 1) prepare(j + 1);
-        }
-        else if (jl >= 0) {
-            const double* vh = vbj + 40 * jh;
-            double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-            // Left alone the scheduler hoists all forty 16-byte reads of the unrolled loops (160 VGPRs on top of the 120 the
-            // rows and columns hold) and the allocator then parks live values in AGPRs (see build.py).  Explicit software
-            // pipeline instead: groups of five reads, the next group in flight while this one multiplies.
-            double2v g0[5], g1[5];
-            auto ldg = [&](int grp, double2v (&g)[5]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) g[i] = ld2(vh + 10 * grp + 2 * i);
-            };
-            auto dotg = [&](int grp, const double2v (&g)[5]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    if (i & 1) {
-                        d2 = fma(g[i].x, jrow[10 * grp + 2 * i], d2);
-                        d3 = fma(g[i].y, jrow[10 * grp + 2 * i + 1], d3);
-                    }
-                    else {
-                        d0 = fma(g[i].x, jrow[10 * grp + 2 * i], d0);
-                        d1 = fma(g[i].y, jrow[10 * grp + 2 * i + 1], d1);
-                    }
-                }
-            };
-            ldg(0, g0);
-            __builtin_amdgcn_sched_barrier(0);
-            ldg(1, g1);
-            dotg(0, g0);
-            __builtin_amdgcn_sched_barrier(0);
-            ldg(2, g0);
-            dotg(1, g1);
-            __builtin_amdgcn_sched_barrier(0);
-            ldg(3, g1);
-            dotg(2, g0);
-            __builtin_amdgcn_sched_barrier(0);
-            ldg(0, g0); // first group of the update pass
-            dotg(3, g1);
-            double dot = (d0 + d1) + (d2 + d3);
-            dot += dpp_get<0xB1>(dot); // the other half of the row
-            const double coef = dot * tj;
-            auto updg = [&](int grp, const double2v (&g)[5]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    jrow[10 * grp + 2 * i] = fma(-coef, g[i].x, jrow[10 * grp + 2 * i]);
-                    jrow[10 * grp + 2 * i + 1] = fma(-coef, g[i].y, jrow[10 * grp + 2 * i + 1]);
-                }
-            };
-            __builtin_amdgcn_sched_barrier(0);
-            ldg(1, g1);
-            updg(0, g0);
-            __builtin_amdgcn_sched_barrier(0);
-            ldg(2, g0);
-            updg(1, g1);
-            __builtin_amdgcn_sched_barrier(0);
-            ldg(3, g1);
-            updg(2, g0);
-            __builtin_amdgcn_sched_barrier(0);
-            updg(3, g1);
-        }
-    }
-    // R packed, 1/R(j,j); J rows back to LDS
-    if (colv) {
-        double* Rc = c.R + roff(e);
-#pragma unroll
-        for (int t = 0; t < 10; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = 2 * kc + 8 * t + i;
-                if (row < e) Rc[row] = b[t][i];
-            }
-        if (kc == 0) {
-            Rc[e] = my_alpha;
-            c.rdinv[e] = 1.0 / my_alpha;
-        }
-    }
-    if (jl >= 0) {
-        double* Jr = c.J + jr * ldj + 40 * jh;
-#pragma unroll
-        for (int q = 0; q < 40; ++q)
-            if (40 * jh + q < n) Jr[q] = jrow[q];
-    }
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same factorisation with EVERY vector on a quad of its own.  A column of B and a row of J take the same operation per
-// reflector, x <- x - tau (x . v) v, so qr_resident's two roles are one: m columns + n rows = up to 102 vectors, four lanes
-// each in the (2 kc + 8 t, + 1) pair layout, the reflector read ONCE per step into registers (10 x 16 bytes) and used for
-// both passes.  Round 1: vectors 0..63 on the 64 quads (the columns of B first: the quad of column j + 1 goes on to the next
-// reflector as soon as its own update is done); round 2: the remaining rows of J on the LAST quads (waves 2 and 3), so the waves
-// that carry the columns' critical path have one round only.  Why: in qr_resident wave 1 holds the last two columns of B (lanes
-// 64..71) AND twenty lanes of J rows -- it runs the column path and the row path one after the other in 16 of 18 steps, the J lanes
-// read the reflector twice (40 x 16 bytes) and only 148 of 256 lanes carry the 2 n^2 m flops of J <- J Q: 37 k cycles for
-// 18 reflectors (profiles/r03/v20_phase.txt).  Requires n <= 80, m <= 22, m + n <= 102.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbuf, double* sc)
 {
@@ -265,7 +58,7 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
             }
     }
     double my_alpha = 1.0;
-    // reflector of column jn from the registers of its quad (call under e == jn): qr_resident's prepare, verbatim
+    // reflector of column jn from the registers of its quad (call under e == jn)
     auto prepare_t = [&](auto T0c, int jn) __attribute__((always_inline)) {
         constexpr int T0 = decltype(T0c)::value;
         const int row0 = 2 * kc + 8 * T0;
@@ -518,7 +311,7 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     bsync();
     STAMP(5)
     // ---- Householder QR of B (columns in registers, one barrier per column) and J <- J Q in its shadow (rows in registers)
-    if (!qr_resident(c, Bm, c.s, c.s + 160)) return false; // redundant equalities
+    if (!qr_unified(c, Bm, c.s, c.s + 160)) return false; // redundant equalities
     bsync();
     STAMP(6)
     // ---- y = R'^-1 rhs on one wave

@@ -314,54 +314,6 @@ __device__ __forceinline__ double dot8(const double* a, int sa, const double* b,
     return (s0 + s1) + (s2 + s3);
 }
 
-// sum_{e < mine} a[e sa] b[e sb] for a wave-uniform trip count cnt >= mine >= cnt - 1 (per-lane base pointers: the two lanes of a
-// pair take halves that differ by at most one term).  Groups of eight; the operands of group g + 1 are in flight while group g
-// multiplies (a lone wave per SIMD has nothing else to hide the LDS round trip behind, and a round trip per group is what the
-// matvec phases of the active-set loop were made of).  Reads past cnt stay inside LDS and are never used.
-__device__ __forceinline__ double dotp(const double* a, int sa, const double* b, int sb, int cnt, int mine)
-{
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (cnt <= 0) return 0.0;
-    double x0[8], y0[8], x1[8], y1[8];
-    auto ld = [&](int e0, double (&x)[8], double (&y)[8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            x[u] = a[(e0 + u) * sa];
-            y[u] = b[(e0 + u) * sb];
-        }
-    };
-    auto mac = [&](int e0, const double (&x)[8], const double (&y)[8]) __attribute__((always_inline)) {
-        if (e0 + 8 < cnt) { // not the last group: every term is everybody's
-            s0 = fma(x[0], y[0], s0); s1 = fma(x[1], y[1], s1); s2 = fma(x[2], y[2], s2); s3 = fma(x[3], y[3], s3);
-            s0 = fma(x[4], y[4], s0); s1 = fma(x[5], y[5], s1); s2 = fma(x[6], y[6], s2); s3 = fma(x[7], y[7], s3);
-        }
-        else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (e0 + u < cnt) {
-                    const double yv = (e0 + u < mine) ? y[u] : 0.0;
-                    if ((u & 3) == 0) s0 = fma(x[u], yv, s0);
-                    else if ((u & 3) == 1) s1 = fma(x[u], yv, s1);
-                    else if ((u & 3) == 2) s2 = fma(x[u], yv, s2);
-                    else s3 = fma(x[u], yv, s3);
-                }
-        }
-    };
-    ld(0, x0, y0);
-    int e = 0;
-    while (true) {
-        if (e + 8 < cnt) ld(e + 8, x1, y1);
-        mac(e, x0, y0);
-        e += 8;
-        if (e >= cnt) break;
-        if (e + 8 < cnt) ld(e + 8, x0, y0);
-        mac(e, x1, y1);
-        e += 8;
-        if (e >= cnt) break;
-    }
-    return (s0 + s1) + (s2 + s3);
-}
-
 // packed upper-triangular R with one spare slot per column (column j holds rows 0..j+1):
 __device__ __forceinline__ int roff(int j) { return (j * (j + 3)) >> 1; }
 // first structurally non-zero column / one past the last of row i: H is block diagonal (dv block, one 12x12 block per contact)
