@@ -132,6 +132,29 @@ def test_problem_data_far_from_the_origin(handle, rbd):
     _compare(dev, ora, tol=1e-7)  # the oracle's own cancellation at |p| = 1e3 (M, h through 1e6-sized intermediate moments)
 
 
+def test_problem_data_wound_up_joint_angles(handle, rbd):
+    """The kernel's own sin / cos of a joint angle (Cody-Waite reduction by pi/2 + the fdlibm kernels, wbcqp_terms.hpp sincos_joint)
+    against the oracle's libm: angles many turns from zero, exact multiples of pi/2, and beyond 1e5 where the kernel hands the
+    argument to the library's sincos().  Only the kinematics matter here: the joint-limit rows see the same q on both sides."""
+    m, st, tm = CASES["franka"]()
+    handle.set_structure(3, st)
+    handle.set_model(3, m, tm)
+    s = mdl.sample_states(m, tm, 32, 36_000)
+    rng = np.random.default_rng(7)
+    rev = np.where(np.asarray(m.jtype) <= 3)[0]  # the revolute joints (J_RX .. J_RZ); fixed base: idx_q = joint index
+    nj = rev.size
+    s["q"][0:8, rev] += rng.uniform(-60.0, 60.0, (8, nj))                        # tens of turns
+    s["q"][8:16, rev] = np.round(s["q"][8:16, rev] / (np.pi / 2)) * (np.pi / 2)  # on the quadrant boundaries
+    s["q"][16:24, rev] += rng.uniform(-9.0e4, 9.0e4, (8, nj))                    # the top of the polynomial path
+    s["q"][24:32, rev] += rng.choice([-1.0, 1.0], (8, nj)) * rng.uniform(1.0e5, 1.0e7, (8, nj))  # the library path
+    dev = handle.problem_data_host(3, s["q"], s["v"], s["ref"])
+    ora = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"])
+    for k in ("M", "h", "A", "b1"):
+        scale = max(1.0, np.abs(ora[k]).max())
+        # an angle of 1e7 carries an absolute error of 1e-9 in double: the two sides see the same q, so only the reduction differs
+        assert np.abs(dev[k] - ora[k]).max() <= 1e-9 * scale, k
+
+
 def test_problem_data_then_solve_matches_oracle_pipeline(handle, rbd):
     """State -> rows -> QP -> torques, all on the device, against oracle rows -> oracle tick."""
     import torch
