@@ -15,7 +15,8 @@ from tools import gi_rinv_proto as proto
     ("icub", 0, 6, dict(task_noise=2.0)),
     ("talos_single_support", 0, 4, dict(task_noise=2.0)),
 ])
-def test_proto_matches_oracle(name, first, count, kw):
+@pytest.mark.parametrize("projector", [False, True])
+def test_proto_matches_oracle(name, first, count, kw, projector):
     st = structure.STRUCTURES[name]()
     seed = synth.SEED_BASE["talos_squat" if kw.get("squat") else name]
     inp = synth.generate(st, count, seed, first=first, **kw)
@@ -24,7 +25,7 @@ def test_proto_matches_oracle(name, first, count, kw):
     for i in range(count):
         H, g, CE, ce0, CI, ci0 = oracle.assemble(st, inp, i)
         tr = {}
-        out = proto.solve(H, g, CE, ce0, CI, ci0, trace=tr)
+        out = proto.solve(H, g, CE, ce0, CI, ci0, trace=tr, projector=projector)
         assert out["status"] == ref["status"][i]
         scale = max(1.0, float(np.abs(ref["x"][i]).max()))
         assert np.abs(out["x"] - ref["x"][i]).max() <= 1e-8 * scale

@@ -20,7 +20,7 @@ EPS = np.finfo(float).eps
 OPTIMAL, INFEASIBLE, MAX_ITER, ERROR = 0, 1, 3, 4
 
 
-def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None):
+def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False):
     n = g.size
     neq, m = CE.shape[0], CI.shape[0]
     U = np.linalg.cholesky(H).T
@@ -40,6 +40,10 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None):
         iq = neq
         R_norm = max(1.0, np.abs(np.diag(Rq[:neq])).max())
     Ri = np.zeros((n, n))  # inverse of the inequality block of R, position space (0 .. iq - neq)
+    # projector=True: the null-space block J2 = J(:, iq:) is never touched again; the symmetric G = J2 J2' is carried instead
+    # (Goldfarb-Idnani's H* operator): z = G n, adding a constraint is G -= z z' / (z'n) with the new column z / sqrt(z'n) of J1,
+    # dropping one returns the leaving column q of J1: G += q q'.
+    G = J[:, iq:] @ J[:, iq:].T if projector else None
     A = [-(i + 1) for i in range(neq)]
     u = np.zeros(n + 2)
     act = np.zeros(m, bool)
@@ -69,10 +73,16 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None):
             u[iq] = 0.0
             A = A[:iq] + [ip]
             d = J.T @ npv
-            z = J[:, iq:] @ d[iq:]
+            if projector:
+                d[iq:] = 0.0
+                z = G @ npv
+            else:
+                z = J[:, iq:] @ d[iq:]
             mi = iq - neq
             r = Ri[:mi, :mi] @ d[neq:iq]
             zz, znp, dn2 = z @ z, z @ npv, d[iq:] @ d[iq:]
+            if projector:
+                dn2 = znp
             rejected = False
             while True:  # l2a with everything carried across drops
                 mi = iq - neq
@@ -123,6 +133,8 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None):
                 u[iq] = 0.0
                 A = A[:neq + p] + A[neq + p + 1:]
                 iq -= 1
+                if projector:
+                    G += np.outer(J[:, iq], J[:, iq])
                 z = z + delta * J[:, iq]
                 znp += delta * delta
                 dn2 += delta * delta
@@ -130,7 +142,12 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None):
             # ---- full step: add ip with one reflector (v = d[iq:] - alpha e0)
             diq = d[iq]
             alpha = diq
-            if iq + 1 < n and dn2 > 0.0:
+            if projector:
+                alpha = np.sqrt(znp) if znp > 0.0 else 0.0
+                if abs(alpha) > EPS * R_norm:
+                    J[:, iq] = z / alpha
+                    G -= np.outer(z, z) / znp
+            elif iq + 1 < n and dn2 > 0.0:
                 nx = np.sqrt(dn2)
                 alpha = -nx if diq >= 0.0 else nx
                 v = d[iq:].copy()
