@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds libwbcqp.so variants side by side (inria_wbc_amd/lib/libwbcqp_<tag>.so) from -D switches, four compiles at a time:
-#   tools/variants.sh base "" zd "-DWBCQP_X_ZDOT=1" ...
-# tools/straggler_time.py --lib <path> / bench.py (WBCQP_LIB=<path>) then measure them in one GPU call.
+#   tools/variants.sh base "" stop3 "-DWBCQP_X_STOP=3" ...
+# tools/run_variants.sh <tag> ... (tools/straggler_time.py --lib <path>) then measures them in one GPU call.
 cd "$(dirname "$0")/.."
 mkdir -p inria_wbc_amd/lib
 n=0
