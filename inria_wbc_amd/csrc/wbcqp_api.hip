@@ -845,9 +845,24 @@ int wbcqp_solve_dense_host(wbcqp_handle* h, int batch, int n, int neq, int nin, 
     char* din = static_cast<char*>(h->stage_in.dev);
     char* dout = static_cast<char*>(h->stage_out.dev);
     std::vector<float> tmp;
-    for (int f = 0; f < 6; ++f) {
+    for (int f = 0; f < 6; ++f)
+        if (lens[f] != 0 && !src[f]) return fail(h, WBCQP_ERR_INVALID, "dense QP: a required input array is NULL");
+    // a small batch (the reference's own use: one QP per call) crosses PCIe as ONE page-locked copy each way, as in
+    // wbcqp_solve_batch_host: six pageable copies up and five synchronous ones down were a quarter of a single QP's wall time
+    const size_t out_total = o_na + al(B * 4);
+    const bool packed = !f32 && in_bytes <= kPackedBytes && out_total <= kPackedBytes;
+    if (packed) {
+        rc = ensure_pinned(h, h->pin_in, kPackedBytes);
+        if (rc != WBCQP_OK) return rc;
+        rc = ensure_pinned(h, h->pin_out, kPackedBytes);
+        if (rc != WBCQP_OK) return rc;
+        char* pin = static_cast<char*>(h->pin_in.host);
+        for (int f = 0; f < 6; ++f)
+            if (lens[f] != 0) std::memcpy(pin + offs[f], src[f], lens[f] * B * 8);
+        HIP_TRY(h, hipMemcpyAsync(din, pin, in_bytes, hipMemcpyHostToDevice, nullptr));
+    }
+    for (int f = 0; f < 6 && !packed; ++f) {
         if (lens[f] == 0) continue;
-        if (!src[f]) return fail(h, WBCQP_ERR_INVALID, "dense QP: a required input array is NULL");
         if (f32) { // the caller's arrays are double (Eigen); an F32 handle carries float at the device boundary
             tmp.resize(lens[f] * B);
             const double* sd = static_cast<const double*>(src[f]);
@@ -869,6 +884,19 @@ int wbcqp_solve_dense_host(wbcqp_handle* h, int batch, int n, int neq, int nin, 
     h->dense_status.assign(B, WBCQP_HQP_UNKNOWN);
     h->dense_iters.assign(B, 0);
     h->dense_nact.assign(B, 0);
+    if (packed) {
+        char* po = static_cast<char*>(h->pin_out.host);
+        HIP_TRY(h, hipMemcpyAsync(po, dout, out_total, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(h, hipStreamSynchronize(nullptr));
+        std::memcpy(h->dense_x.data(), po + o_x, (size_t)n * B * 8);
+        std::memcpy(h->dense_obj.data(), po + o_obj, B * 8);
+        std::memcpy(h->dense_status.data(), po + o_st, B * 4);
+        std::memcpy(h->dense_iters.data(), po + o_it, B * 4);
+        std::memcpy(h->dense_nact.data(), po + o_na, B * 4);
+        h->dense_out = {batch, n, h->dense_x.data(), h->dense_status.data(), h->dense_iters.data(), h->dense_obj.data(), h->dense_nact.data()};
+        *result = &h->dense_out;
+        return WBCQP_OK;
+    }
     if (f32) {
         std::vector<float> xf((size_t)n * B), of(B);
         HIP_TRY(h, hipMemcpy(xf.data(), dso.x, xf.size() * 4, hipMemcpyDeviceToHost));
