@@ -71,26 +71,41 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
 
     // ---- H (lower triangle is read) into the J region, g; c1 = tr H
     double tr = 0.0;
-    for (int e = tid; e < n * n; e += kThreads) {
-        const int i = e / n, j = e - i * n;
-        const double v = (double)H[e];
-        if (j <= i) c.J[i * ldj + j] = v;
-        if (i == j) tr += v;
+    {
+        int i = tid / n, j = tid - i * n; // (one division per thread; the running (row, column) follows the flat index from there)
+        for (int e = tid; e < n * n; e += kThreads) {
+            const double v = (double)H[e];
+            if (j <= i) c.J[i * ldj + j] = v;
+            if (i == j) tr += v;
+            j += kThreads;
+            while (j >= n) {
+                j -= n;
+                ++i;
+            }
+        }
     }
     for (int i = tid; i < n; i += kThreads) c.g[i] = (double)g[i];
     const double c1 = block_sum(c, tr);
-    // ---- Cholesky H = L L' in place (right-looking, one column per step; Eigen LLT).  A non-positive pivot gives NaN,
-    //      which propagates like Eigen's LLT on a matrix that is not SPD
-    for (int j = 0; j < n; ++j) {
-        const double ljj = sqrt(c.J[j * ldj + j]);
+    // ---- Cholesky H = L L' in place, right-looking, ONE barrier per column: the trailing update uses the unscaled pivot column,
+    //      A(i, k) -= A(i, j) A(k, j) / A(j, j), on a 16 x 16 thread grid (no index divisions), and the columns are scaled by
+    //      1 / sqrt(pivot) in one pass at the end (the first form scaled the column first: three barriers per column and an integer
+    //      division per element).  A non-positive pivot ends in a NaN, which propagates like Eigen's LLT on a matrix that is not SPD
+    {
+        const int ta = tid >> 4, te = tid & 15;
         bsync();
-        for (int i = j + tid; i < n; i += kThreads) c.J[i * ldj + j] = (i == j) ? ljj : c.J[i * ldj + j] / ljj;
-        bsync();
-        // trailing update: A(i, k) -= L(i, j) L(k, j), j < k <= i
-        const int m = n - j - 1;
-        for (int e = tid; e < m * m; e += kThreads) {
-            const int i = j + 1 + e / m, k = j + 1 + e % m;
-            if (k <= i) c.J[i * ldj + k] = fma(-c.J[i * ldj + j], c.J[k * ldj + j], c.J[i * ldj + k]);
+        for (int j = 0; j < n; ++j) {
+            const double inv = 1.0 / c.J[j * ldj + j];
+            for (int i = j + 1 + ta; i < n; i += 16) {
+                const double lij = c.J[i * ldj + j] * inv;
+                for (int k = j + 1 + te; k <= i; k += 16) c.J[i * ldj + k] = fma(-lij, c.J[k * ldj + j], c.J[i * ldj + k]);
+            }
+            bsync();
+        }
+        for (int j = c.wave; j < n; j += kWaves) { // a wave per column
+            const double ljj = sqrt(c.J[j * ldj + j]);
+            const double il = 1.0 / ljj;
+            __builtin_amdgcn_wave_barrier();
+            for (int i = j + c.lane; i < n; i += kWave) c.J[i * ldj + j] = (i == j) ? ljj : c.J[i * ldj + j] * il;
         }
         bsync();
     }
@@ -124,24 +139,31 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
     //      too, so the inverse is formed into the UPPER triangle while L stays in the lower one; the diagonal of L moves to dinv.
     if (tid < n) c.dinv[tid] = 1.0 / c.J[tid * ldj + tid];
     bsync();
-    if (tid < n) {
-        // U = L' is upper triangular; X = U^-1 is upper triangular with X(q,q) = 1 / L(q,q) and, for i < q,
-        // X(i,q) = -(sum_{p=i+1..q} U(i,p) X(p,q)) / U(i,i) = -(sum_p L(p,i) X(p,q)) dinv[i].  Column q belongs to thread q: it
-        // reads L from the lower triangle (never written here) and writes only its own column above the diagonal.
-        const int q = tid;
-        for (int i = q - 1; i >= 0; --i) {
-            double acc = c.J[q * ldj + i] * c.dinv[q]; // p = q: L(q,i) X(q,q)
-            for (int p = i + 1; p < q; ++p) acc = fma(c.J[p * ldj + i], c.J[p * ldj + q], acc);
-            c.J[i * ldj + q] = -acc * c.dinv[i];
+    // U = L' is upper triangular; X = U^-1 is upper triangular with X(q,q) = 1 / L(q,q) and, for i < q,
+    // X(i,q) = -(sum_{p=i+1..q} U(i,p) X(p,q)) / U(i,i) = -(sum_p L(p,i) X(p,q)) dinv[i].  Column q belongs to a quad of lanes (the
+    // sum over p in four strided parts, met by DPP), columns q and q + 64 in two rounds: L is read from the lower triangle (never
+    // written here) and a quad writes only its own column above the diagonal -- read back by itself alone.
+    for (int q0 = 0; q0 < n; q0 += kThreads / 4) {
+        const int q = q0 + (tid >> 2), kc = tid & 3;
+        const int qs = min(q, n - 1);
+        if (uni(q0 + ((tid >> 6) << 4)) >= n) continue;                      // (a wave without a column in this round)
+        const int imax = uni(min(q0 + (((tid >> 6) + 1) << 4) - 1, n - 1)); // the wave's longest column
+        for (int i = imax - 1; i >= 0; --i) {
+            double acc = 0.0;
+            if (i < qs) {
+                for (int p = i + 1 + kc; p < qs; p += 4) acc = fma(c.J[p * ldj + i], c.J[p * ldj + qs], acc);
+                if (kc == 0) acc = fma(c.J[qs * ldj + i], c.dinv[qs], acc); // p = q: L(q,i) X(q,q)
+            }
+            acc = quad_sum(acc);
+            if (kc == 0 && i < q && q < n) c.J[i * ldj + q] = -acc * c.dinv[i];
         }
     }
     bsync();
     // lower triangle := 0, diagonal := 1 / L(q,q): J = L^-T complete
     double tr2 = 0.0;
-    for (int e = tid; e < n * n; e += kThreads) {
-        const int i = e / n, j = e - i * n;
-        if (j < i) c.J[i * ldj + j] = 0.0;
-        else if (i == j) {
+    for (int i = tid >> 4; i < n; i += 16) {
+        for (int j = tid & 15; j < i; j += 16) c.J[i * ldj + j] = 0.0;
+        if ((tid & 15) == 0) {
             c.J[i * ldj + i] = c.dinv[i];
             tr2 += c.dinv[i];
         }
@@ -202,20 +224,26 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
                 }
                 for (int i = tid; i < n; i += kThreads) c.xold[i] = c.x[i];
                 double psi = 0.0;
-                for (int i = tid; i < nin; i += kThreads) {
-                    const TI* row = CI + (size_t)i * n;
+                // eight lanes per row, consecutive columns across them: a load instruction touches one cache line per row (a lane per
+                // row walked its own row: 64 lines per instruction)
+                for (int i0 = 0; i0 < nin; i0 += kThreads / 8) {
+                    const int i = i0 + (tid >> 3), l8 = tid & 7;
+                    const TI* row = CI + (size_t)min(i, nin - 1) * n;
                     double s0 = 0.0, s1 = 0.0;
-                    int j = 0;
-                    for (; j + 2 <= n; j += 2) {
+                    int j = l8;
+                    for (; j + 8 < n; j += 16) {
                         s0 = fma((double)row[j], c.x[j], s0);
-                        s1 = fma((double)row[j + 1], c.x[j + 1], s1);
+                        s1 = fma((double)row[j + 8], c.x[j + 8], s1);
                     }
                     if (j < n) s0 = fma((double)row[j], c.x[j], s0);
-                    const double v = (s0 + s1) + (double)ci0[i];
-                    c.s[i] = v;
-                    c.iaexcl[i] = 1;
-                    psi += fmin(0.0, v);
-                    if (v < 0.0 && c.iai[i] != -1) best = vi_min(best, ValIdx{v, i});
+                    const double sum = grp8_sum(s0 + s1);
+                    if (l8 == 0 && i < nin) {
+                        const double v = sum + (double)ci0[i];
+                        c.s[i] = v;
+                        c.iaexcl[i] = 1;
+                        psi += fmin(0.0, v);
+                        if (v < 0.0 && c.iai[i] != -1) best = vi_min(best, ValIdx{v, i});
+                    }
                 }
                 psi = block_sum(c, psi);
                 best = block_argmin(c, best);
