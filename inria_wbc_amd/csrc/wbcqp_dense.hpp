@@ -12,6 +12,9 @@
 #include "wbcqp_prims.hpp"
 #include "wbcqp_activeset.hpp"
 
+#ifndef WBCQP_DENSE_STOP
+#define WBCQP_DENSE_STOP 0
+#endif
 namespace wbcqp {
 #ifdef __HIPCC__
 
@@ -93,12 +96,42 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
     {
         const int ta = tid >> 4, te = tid & 15;
         bsync();
-        for (int j = 0; j < n; ++j) {
+        // a thread's tile of the trailing matrix, rows j + 1 + ta + 16 u, columns j + 1 + te + 16 w: every operand of the step in flight
+        // before the first product (an element at a time is three dependent LDS round trips per element)
+        auto step = [&](auto NUc, int j) __attribute__((always_inline)) {
+            constexpr int NU = decltype(NUc)::value;
             const double inv = 1.0 / c.J[j * ldj + j];
-            for (int i = j + 1 + ta; i < n; i += 16) {
-                const double lij = c.J[i * ldj + j] * inv;
-                for (int k = j + 1 + te; k <= i; k += 16) c.J[i * ldj + k] = fma(-lij, c.J[k * ldj + j], c.J[i * ldj + k]);
+            double li[NU], lk[NU], av[NU][NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = min(j + 1 + ta + 16 * u, n - 1), k = min(j + 1 + te + 16 * u, n - 1);
+                li[u] = c.J[i * ldj + j];
+                lk[u] = c.J[k * ldj + j];
             }
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int w = 0; w < NU; ++w) {
+                    const int i = min(j + 1 + ta + 16 * u, n - 1), k = min(j + 1 + te + 16 * w, n - 1);
+                    av[u][w] = c.J[i * ldj + min(k, i)];
+                }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = j + 1 + ta + 16 * u;
+                const double lij = li[u] * inv;
+#pragma unroll
+                for (int w = 0; w < NU; ++w) {
+                    const int k = j + 1 + te + 16 * w;
+                    if (i < n && k <= i) c.J[i * ldj + k] = fma(-lij, lk[w], av[u][w]);
+                }
+            }
+        };
+        for (int j = 0; j < n; ++j) {
+            const int m = n - j - 1;
+            if (m > 80) step(std::integral_constant<int, 8>{}, j);
+            else if (m > 48) step(std::integral_constant<int, 5>{}, j);
+            else if (m > 16) step(std::integral_constant<int, 3>{}, j);
+            else step(std::integral_constant<int, 1>{}, j);
             bsync();
         }
         for (int j = c.wave; j < n; j += kWaves) { // a wave per column
@@ -109,30 +142,9 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
         }
         bsync();
     }
-    // ---- x = -H^-1 g through L: L y = g (forward), L' x = y (backward); one wave, lanes hold y / x entries
-    if (c.wave == 0) {
-        double y0 = (c.lane < n) ? c.g[c.lane] : 0.0, y1 = (c.lane + kWave < n) ? c.g[c.lane + kWave] : 0.0;
-        for (int j = 0; j < n; ++j) {
-            const double yj = ((j < kWave) ? bcast_lane(y0, j) : bcast_lane(y1, j - kWave)) / c.J[j * ldj + j];
-            if (c.lane == j) y0 = yj;
-            if (c.lane + kWave == j) y1 = yj;
-            if (c.lane > j && c.lane < n) y0 = fma(-yj, c.J[c.lane * ldj + j], y0);
-            if (c.lane + kWave > j && c.lane + kWave < n) y1 = fma(-yj, c.J[(c.lane + kWave) * ldj + j], y1);
-        }
-        for (int j = n - 1; j >= 0; --j) {
-            const double xj = ((j < kWave) ? bcast_lane(y0, j) : bcast_lane(y1, j - kWave)) / c.J[j * ldj + j];
-            if (c.lane == j) y0 = xj;
-            if (c.lane + kWave == j) y1 = xj;
-            if (c.lane < j) y0 = fma(-xj, c.J[j * ldj + c.lane], y0);
-            if (c.lane + kWave < j) y1 = fma(-xj, c.J[j * ldj + c.lane + kWave], y1);
-        }
-        if (c.lane < n) c.x[c.lane] = -y0;
-        if (c.lane + kWave < n) c.x[c.lane + kWave] = -y1;
-    }
-    bsync();
-    double part = 0.0;
-    if (tid < n) part = 0.5 * c.g[tid] * c.x[tid];
-    double f_value = block_sum(c, part);
+#if WBCQP_DENSE_STOP == 1
+    return;
+#endif
     // ---- J = L^-T (upper triangular): column q of J solves L' J(:, q) = e_q; thread per column, rows q .. 0.
     //      L is read from the lower triangle, J lands in a second array (the R region is too small: use part of it plus ...)
     //      -> done in place column by column is impossible (J overwrites L): stage L^-T through the vector area is too small
@@ -143,11 +155,14 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
     // X(i,q) = -(sum_{p=i+1..q} U(i,p) X(p,q)) / U(i,i) = -(sum_p L(p,i) X(p,q)) dinv[i].  Column q belongs to a quad of lanes (the
     // sum over p in four strided parts, met by DPP), columns q and q + 64 in two rounds: L is read from the lower triangle (never
     // written here) and a quad writes only its own column above the diagonal -- read back by itself alone.
-    for (int q0 = 0; q0 < n; q0 += kThreads / 4) {
-        const int q = q0 + (tid >> 2), kc = tid & 3;
-        const int qs = min(q, n - 1);
-        if (uni(q0 + ((tid >> 6) << 4)) >= n) continue;                      // (a wave without a column in this round)
-        const int imax = uni(min(q0 + (((tid >> 6) + 1) << 4) - 1, n - 1)); // the wave's longest column
+    // (the 64 LONGEST columns first, the n - 64 shortest in a second round: the rounds are as long as their longest column)
+    const int qoff = max(n - kThreads / 4, 0);
+    for (int round = 0; round < (qoff > 0 ? 2 : 1); ++round) {
+        const int qb = round == 0 ? qoff : 0, qe = round == 0 ? n : qoff; // columns [qb, qe)
+        const int q = qb + (tid >> 2), kc = tid & 3;
+        const int qs = min(q, qe - 1);
+        if (uni(qb + ((tid >> 6) << 4)) >= qe) continue;                      // (a wave without a column in this round)
+        const int imax = uni(min(qb + (((tid >> 6) + 1) << 4) - 1, qe - 1)); // the wave's longest column
         for (int i = imax - 1; i >= 0; --i) {
             double acc = 0.0;
             if (i < qs) {
@@ -155,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
                 if (kc == 0) acc = fma(c.J[qs * ldj + i], c.dinv[qs], acc); // p = q: L(q,i) X(q,q)
             }
             acc = quad_sum(acc);
-            if (kc == 0 && i < q && q < n) c.J[i * ldj + q] = -acc * c.dinv[i];
+            if (kc == 0 && i < q && q < qe) c.J[i * ldj + q] = -acc * c.dinv[i];
         }
     }
     bsync();
@@ -173,8 +188,27 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
         c.u[i] = 0.0;
         c.A[i] = 0;
     }
+    // ---- x = -H^-1 g = -J (J' g): two triangular matvecs, a thread per column, then per row (the first form solved L y = g, L' x = y
+    //      on one wave: 2 n dependent steps with a division each -- 32 us of a Talos-sized QP)
+    if (tid < n) {
+        double acc = 0.0;
+        for (int i = 0; i <= tid; ++i) acc = fma(c.J[i * ldj + tid], c.g[i], acc);
+        c.d[tid] = acc;
+    }
     bsync();
+    double part = 0.0;
+    if (tid < n) {
+        const double* Jr = c.J + tid * ldj;
+        double acc = 0.0;
+        for (int j = tid; j < n; ++j) acc = fma(Jr[j], c.d[j], acc);
+        c.x[tid] = -acc;
+        part = 0.5 * c.g[tid] * (-acc);
+    }
+    double f_value = block_sum(c, part);
 
+#if WBCQP_DENSE_STOP == 2
+    return;
+#endif
     int status = -2, iter = 0;
     // ---- equalities, one by one (eiquadprog's order)
     for (int i = 0; i < neq && status == -2; ++i) {
@@ -204,6 +238,9 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
         f_value += 0.5 * (t2 * t2) * znp;
         if (!add_constraint_hh(c, dn2)) status = HQP_ERROR; // redundant equalities
     }
+#if WBCQP_DENSE_STOP == 3
+    return;
+#endif
     // ---- inequalities
     if (status == -2) {
         for (int i = tid; i < nin; i += kThreads) c.iai[i] = i;
