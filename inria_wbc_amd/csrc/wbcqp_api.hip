@@ -797,9 +797,15 @@ int wbcqp_solve_dense(wbcqp_handle* h, int batch, int n, int neq, int nin, int m
     a.n = n; a.neq = neq; a.nin = nin; a.ldj = odd(n);
     int o = 0;
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; };
+    a.blocked_eq = (neq >= 1 && neq <= 22 && n <= 80) ? 1 : 0;
+    a.ldb = 2 * odd((4 * ((neq + 3) / 4) + 1) / 2); // as the structured layout's (derive): rows stay 16-byte aligned for the 4-wide column groups
     a.o_J = take(n * a.ldj);
-    a.o_R = take(n * (n + 3) / 2 + 2);
+    int rsize = n * (n + 3) / 2 + 2;
+    if (a.blocked_eq && 256 + (n + 17) * a.ldb + 8 > rsize) rsize = 256 + (n + 17) * a.ldb + 8; // B of the blocked equality phase
+    a.o_R = take(rsize);
     a.o_vec = take(V_COUNT * kSlot);
+    a.o_eqw = take(a.blocked_eq ? (n + 1) * a.ldb + 8 : 0);
+    a.o_eqt = take(a.blocked_eq ? neq * (neq + 1) + 4 * neq + 16 : 0);
     a.o_int = o;
     o += kIntCount / 2 + 2;
     const int lds_bytes = o * 8;

@@ -11,6 +11,7 @@
 
 #include "wbcqp_prims.hpp"
 #include "wbcqp_activeset.hpp"
+#include "wbcqp_equality.hpp"
 
 #ifndef WBCQP_DENSE_STOP
 #define WBCQP_DENSE_STOP 0
@@ -21,7 +22,10 @@ namespace wbcqp {
 struct DenseArgs {
     int n, neq, nin;            // nin = rows of CI as eiquadprog sees them (tsid: 2 x nIn two-sided rows)
     int ldj;                    // odd
+    int ldb;                    // leading dimension of N = CE' / B = J0'N (blocked equality phase)
+    int blocked_eq;             // 1 <= neq <= 22 and n <= 80: the equalities enter in one blocked phase (wbcqp_equality.hpp)
     int o_J, o_R, o_vec, o_int; // LDS layout (doubles)
+    int o_eqw, o_eqt;           // blocked equality phase: N (n x ldb), then T / tau / rhs
     int max_iter;
     int count;
     const void *H, *g, *CE, *ce0, *CI, *ci0; // [count][...] row-major, the handle's dtype
@@ -57,7 +61,9 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
         c.red = vec + V_RED * kSlot; c.prm = vec + V_PRM * kSlot; c.b1 = vec + V_B1 * kSlot; c.s = vec + V_S * kSlot;
         c.stash = vec + V_STASH * kSlot; c.part = vec + V_PART * kSlot;
     }
-    c.eqw = c.eqt = nullptr;
+    c.eqw = a.blocked_eq ? lds + a.o_eqw : nullptr;
+    c.eqt = a.blocked_eq ? lds + a.o_eqt : nullptr;
+    c.ldb = a.ldb;
     int* ia = reinterpret_cast<int*>(lds + a.o_int);
     c.A = ia + kIntA; c.Aold = ia + kIntAold; c.gskip = ia + kIntGskip; c.iai = ia + kIntIai; c.iaexcl = ia + kIntIaexcl;
     c.meta = ia + kIntMeta;
@@ -210,8 +216,27 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
     return;
 #endif
     int status = -2, iter = 0;
-    // ---- equalities, one by one (eiquadprog's order)
-    for (int i = 0; i < neq && status == -2; ++i) {
+    // ---- equalities: in one blocked phase where it applies (N = CE', B = J0'N, Householder QR with J <- J Q in its shadow: the same
+    //      (J, R, x, f) as neq add_constraint calls, wbcqp_equality.hpp; 18 equalities one by one were 92 us of a Talos-sized QP) ...
+    if (a.blocked_eq) {
+        const bool ok = equality_phase_blocked_t(
+            c, f_value,
+            [&](double* Nm) __attribute__((always_inline)) {
+                const int e = tid & 31, k8 = tid >> 5;
+                if (e < neq) {
+                    TI v[10];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) v[i] = CE[(size_t)e * n + min(k8 + 8 * i, n - 1)];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i)
+                        if (k8 + 8 * i < n) Nm[(k8 + 8 * i) * a.ldb + e] = (double)v[i];
+                }
+            },
+            [&](int e) __attribute__((always_inline)) { return (double)ce0[e]; });
+        if (!ok) status = HQP_ERROR; // redundant equalities
+    }
+    // ---- ... else one by one (eiquadprog's order)
+    for (int i = 0; i < neq && status == -2 && !a.blocked_eq; ++i) {
         if (tid < n) c.np[tid] = (double)CE[(size_t)i * n + tid];
         const double ce = (double)ce0[i];
         bsync();

@@ -225,45 +225,18 @@ __device__ __forceinline__ void solve_y(Ctx& c, double* rhs)
 // Returns false on (numerically) redundant equalities -- upstream's REDUNDANT_EQUALITIES.
 // Requires n <= 80, 1 <= m <= 22.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
+// build_n(Nm) writes N = CE' (n x m, leading dimension c.ldb) -- every thread calls it, a barrier follows; ce0_of(e) is ce0 of equality e
+template <typename BuildN, typename Ce0>
+__device__ __forceinline__ bool equality_phase_blocked_t(Ctx& c, double& f_value, BuildN build_n, Ce0 ce0_of)
 {
-    const int n = c.n, m = c.neq, nv = c.nv, nu = c.nu, ldj = c.ldj, ldb = c.ldb, tid = c.tid;
+    const int n = c.n, m = c.neq, nv = c.nv, ldj = c.ldj, ldb = c.ldb, tid = c.tid;
     double* Nm = c.eqw;        // N = CE' (n x m), later W = J0 V
     double* Bm = c.R + 256;    // B -> V (lower trapezoid) / R (strict upper), in the unused tail of the R region
     double* Tm = c.eqt;        // T (m x (m+1))
     double* tau = Tm + m * (m + 1);
     double* rhs = tau + 2 * m;  // later y
 
-    // ---- N = CE': base dynamics rows [M_u | -J_u'], then the contact motion rows [A_c | 0].  Thread = (equality e,
-    //      every 8th row): no index division, the ten loads of a thread are in flight together (m <= 22, n <= 80)
-    {
-        const int e = tid & 31, k8 = tid >> 5;
-        if (e < m) {
-            // both candidate sources are read unconditionally (clamped addresses) and selected: a load behind a per-lane
-            // branch waits for its own round trip
-            double v[10];
-            if (e < nu) {
-#pragma unroll
-                for (int i = 0; i < 10; ++i) {
-                    const int kk = min(k8 + 8 * i, n - 1);
-                    const double mv = c.M[min(kk, nv - 1) * c.ldm + e];
-                    const double jv = (n > nv) ? c.Jc[max(kk - nv, 0) * c.ldc + e] : 0.0;
-                    v[i] = (kk < nv) ? mv : -jv;
-                }
-            }
-            else {
-#pragma unroll
-                for (int i = 0; i < 10; ++i) {
-                    const int kk = min(k8 + 8 * i, n - 1);
-                    const double av = c.Ac[(e - nu) * nv + min(kk, nv - 1)];
-                    v[i] = (kk < nv) ? av : 0.0;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 10; ++i)
-                if (k8 + 8 * i < n) Nm[(k8 + 8 * i) * ldb + e] = v[i];
-        }
-    }
+    build_n(Nm);
     bsync();
     STAMP(21)
     // ---- rhs_e = -(N(:,e)'x0 + ce0_e): 8 lanes per equality, ten terms each in flight
@@ -280,8 +253,7 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
         }
         const double acc = grp8_sum(a0 + a1);
         if (e < m && kc == 0) {
-            const double ce0 = (e < nu) ? c.h[e] : -c.bc[e - nu];
-            rhs[e] = -(acc + ce0);
+            rhs[e] = -(acc + ce0_of(e));
         }
     }
     STAMP(22)
@@ -339,6 +311,47 @@ __device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
     c.iq = m;
     bsync();
     return true;
+}
+
+// The structured layout's form: N from the record's blocks in LDS (M, Jc = T'A_c, A_c), ce0 = h_u | -bc.
+__device__ __forceinline__ bool equality_phase_blocked(Ctx& c, double& f_value)
+{
+    return equality_phase_blocked_t(
+        c, f_value,
+        [&](double* Nm) __attribute__((always_inline)) {
+            const int n = c.n, m = c.neq, nv = c.nv, nu = c.nu, ldb = c.ldb, tid = c.tid;
+    // ---- N = CE': base dynamics rows [M_u | -J_u'], then the contact motion rows [A_c | 0].  Thread = (equality e,
+    //      every 8th row): no index division, the ten loads of a thread are in flight together (m <= 22, n <= 80)
+    {
+        const int e = tid & 31, k8 = tid >> 5;
+        if (e < m) {
+            // both candidate sources are read unconditionally (clamped addresses) and selected: a load behind a per-lane
+            // branch waits for its own round trip
+            double v[10];
+            if (e < nu) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const int kk = min(k8 + 8 * i, n - 1);
+                    const double mv = c.M[min(kk, nv - 1) * c.ldm + e];
+                    const double jv = (n > nv) ? c.Jc[max(kk - nv, 0) * c.ldc + e] : 0.0;
+                    v[i] = (kk < nv) ? mv : -jv;
+                }
+            }
+            else {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const int kk = min(k8 + 8 * i, n - 1);
+                    const double av = c.Ac[(e - nu) * nv + min(kk, nv - 1)];
+                    v[i] = (kk < nv) ? av : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+                if (k8 + 8 * i < n) Nm[(k8 + 8 * i) * ldb + e] = v[i];
+        }
+    }
+        },
+        [&](int e) __attribute__((always_inline)) { return (e < c.nu) ? c.h[e] : -c.bc[e - c.nu]; });
 }
 
 #endif // __HIPCC__
