@@ -6,12 +6,15 @@
 // H only while it is factorised, CE and CI read row by row from HBM / L2.  This is the compatibility path for a caller that
 // owns its own HQPData (a tsid SolverHQPBase subclass); the batched structured path
 // (wbcqp_solve_batch) is the fast one and the one bench.py times.  Same Goldfarb-Idnani steps, status map and stopping rule as
-// solve_one; equalities are added one by one (eiquadprog's own order), add_constraint in its one-reflector form.
+// solve_one.  For n <= 80 the set-up is the structured kernels': H -> J = L^-T by the blocked elimination in registers
+// (wbcqp_factor.hpp) and, for 1 <= neq <= 22, the equalities in one blocked phase (wbcqp_equality.hpp); beyond those sizes Cholesky
+// in LDS, a triangular inverse and the equalities one by one (eiquadprog's own order), add_constraint in its one-reflector form.
 #pragma once
 
 #include "wbcqp_prims.hpp"
 #include "wbcqp_activeset.hpp"
 #include "wbcqp_equality.hpp"
+#include "wbcqp_factor.hpp"
 
 #ifndef WBCQP_DENSE_STOP
 #define WBCQP_DENSE_STOP 0
@@ -78,6 +81,46 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
     const double eps = 2.220446049250313e-16;
     const double inf = __builtin_huge_val();
 
+    double c1, tr2 = 0.0;
+    if (n <= 80) {
+        // ---- H -> J = L^-T by the structured kernels' blocked elimination (wbcqp_factor.hpp): a 16 x 16 thread grid keeps the
+        //      positions (ta + 16 u, te + 16 w), u <= w < 5, of H and of Y = U^-1 in registers, four pivots per barrier, only the pivot
+        //      rows and columns travel through LDS (the J region, idle until J is written).  (Cholesky in LDS, then the triangular
+        //      inverse, were 110 us of a Talos-sized QP.)  The lower triangle of H is what is read, as Eigen's LLT does.
+        const int ta = tid >> 4, te = tid & 15;
+        double h[5][5], y[5][5];
+        double tr = 0.0;
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+            for (int w = 0; w < 5; ++w) {
+                const int r = ta + 16 * u, q = te + 16 * w;
+                const int hi = min(max(r, q), n - 1), lo = min(min(r, q), n - 1);
+                const double v = (w >= u) ? (double)H[(size_t)hi * n + lo] : 0.0;
+                h[u][w] = (r < n && q < n) ? v : ((r == q) ? 1.0 : 0.0);
+                y[u][w] = 0.0;
+                if (w >= u && r == q && r < n) tr += v;
+            }
+        for (int i = tid; i < n; i += kThreads) c.g[i] = (double)g[i];
+        c1 = block_sum(c, tr);
+        double* RB = c.J;
+        double* YB = c.J + 2 * 5 * 16 * 4;
+        publish_panel<4, 5, false, 0>(c, h, y, ta, te, 0, RB, YB);
+        eliminate_block<4, 5, false, 0>(c, h, y, ta, te, (n + 3) & ~3, RB, YB, c.dinv, tid >= 128 && tid < 132, tid & 3);
+        bsync(); // the panels are dead: the region becomes J
+        for (int e = tid; e < n * ldj; e += kThreads) c.J[e] = 0.0;
+        bsync(); // J is zero, every 1 / sqrt(pivot) is published
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+            for (int w = u; w < 5; ++w) {
+                const int r = ta + 16 * u, q = te + 16 * w;
+                if (q < n && r < q) c.J[r * ldj + q] = y[u][w] * c.dinv[q];
+                else if (r == q && r < n) c.J[r * ldj + r] = c.dinv[r];
+            }
+        for (int i = tid; i < n; i += kThreads) tr2 += c.dinv[i];
+    }
+    else {
     // ---- H (lower triangle is read) into the J region, g; c1 = tr H
     double tr = 0.0;
     {
@@ -94,7 +137,7 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
         }
     }
     for (int i = tid; i < n; i += kThreads) c.g[i] = (double)g[i];
-    const double c1 = block_sum(c, tr);
+    c1 = block_sum(c, tr);
     // ---- Cholesky H = L L' in place, right-looking, ONE barrier per column: the trailing update uses the unscaled pivot column,
     //      A(i, k) -= A(i, j) A(k, j) / A(j, j), on a 16 x 16 thread grid (no index divisions), and the columns are scaled by
     //      1 / sqrt(pivot) in one pass at the end (the first form scaled the column first: three barriers per column and an integer
@@ -181,13 +224,13 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
     }
     bsync();
     // lower triangle := 0, diagonal := 1 / L(q,q): J = L^-T complete
-    double tr2 = 0.0;
     for (int i = tid >> 4; i < n; i += 16) {
         for (int j = tid & 15; j < i; j += 16) c.J[i * ldj + j] = 0.0;
         if ((tid & 15) == 0) {
             c.J[i * ldj + i] = c.dinv[i];
             tr2 += c.dinv[i];
         }
+    }
     }
     const double c2 = block_sum(c, tr2);
     for (int i = tid; i < n + 2; i += kThreads) {

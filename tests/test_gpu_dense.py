@@ -47,7 +47,10 @@ def test_dense_seam_matches_eiquadprog_on_assembled_stacks(oracle_mod, robot, no
 def test_dense_seam_on_random_qps_and_failure_statuses(oracle_mod):
     rng = np.random.default_rng(3)
     h = capi.Handle(0, capi.F64)
-    for n, neq, nin in ((5, 0, 0), (12, 3, 0), (20, 0, 30), (33, 7, 41), (64, 10, 100), (96, 12, 200)):
+    # sizes on both sides of the kernel's two switches: the blocked elimination (n <= 80) and the blocked equality phase (n <= 80 and
+    # 1 <= neq <= 22); beyond them Cholesky in LDS and the equalities one by one
+    for n, neq, nin in ((5, 0, 0), (12, 3, 0), (20, 0, 30), (33, 7, 41), (64, 10, 100), (40, 25, 30), (80, 22, 60), (81, 5, 20),
+                        (96, 12, 200)):
         G = rng.standard_normal((n, n))
         H = G @ G.T + 0.5 * np.eye(n)
         g = rng.standard_normal(n)
