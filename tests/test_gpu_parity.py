@@ -132,6 +132,37 @@ def test_device_pointer_path_and_ragged(handle, oracle_mod):
         assert_parity(st, got, ref, what="ragged:" + st.name)
 
 
+def test_empty_batch_and_empty_group_are_no_ops(handle, oracle_mod):
+    """batch = 0 (a fleet with nobody in it this tick) returns at once, and a ragged launch with an EMPTY group among its groups
+    solves the others as if it were not there -- the empty inputs the reference's callers can produce (a robot type absent from
+    the mix; utest.hpp:62-96 builds its controller lists the same way)."""
+    import torch
+    st = structure.talos_structure()
+    sf = structure.franka_structure()
+    handle.set_structure(2, st)
+    handle.set_structure(3, sf)
+    empty_in = {k: torch.zeros(0, v, dtype=torch.float64, device="cuda") for k, v in st.field_lengths().items() if v}
+    sentinel = dict(x=torch.full((1, st.n), 7.0, dtype=torch.float64, device="cuda"), tau=torch.full((1, st.na), 7.0, dtype=torch.float64, device="cuda"),
+                    status=torch.full((1,), -99, dtype=torch.int32, device="cuda"), iters=torch.full((1,), -5, dtype=torch.int32, device="cuda"))
+    stream = torch.cuda.current_stream().cuda_stream
+    handle.solve_batch(2, 0, empty_in, {k: v[:0] for k, v in sentinel.items()}, stream=stream)
+    torch.cuda.synchronize()
+    assert float(sentinel["x"].min()) == 7.0 and int(sentinel["status"][0]) == -99 and int(sentinel["iters"][0]) == -5
+    batch = 6
+    inputs = synth.generate(st, batch, synth.SEED_BASE["talos"] + 77, task_noise=1.0)
+    ref = oracle_mod.tick_batch(st, inputs)
+    dev_in = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in inputs.items() if v.size}
+    dev_out = dict(x=torch.zeros(batch, st.n, dtype=torch.float64, device="cuda"), tau=torch.zeros(batch, st.na, dtype=torch.float64, device="cuda"),
+                   status=torch.full((batch,), -99, dtype=torch.int32, device="cuda"), iters=torch.zeros(batch, dtype=torch.int32, device="cuda"))
+    empty_f = {k: torch.zeros(0, v, dtype=torch.float64, device="cuda") for k, v in sf.field_lengths().items() if v}
+    empty_out = dict(x=torch.zeros(0, sf.n, dtype=torch.float64, device="cuda"), tau=torch.zeros(0, sf.na, dtype=torch.float64, device="cuda"),
+                     status=torch.zeros(0, dtype=torch.int32, device="cuda"), iters=torch.zeros(0, dtype=torch.int32, device="cuda"))
+    handle.solve_ragged([(3, 0, empty_f, empty_out), (2, batch, dev_in, dev_out), (3, 0, empty_f, empty_out)], stream=stream)
+    torch.cuda.synchronize()
+    got = dict(x=dev_out["x"].cpu().numpy(), tau=dev_out["tau"].cpu().numpy(), status=dev_out["status"].cpu().numpy(), iters=dev_out["iters"].cpu().numpy())
+    assert_parity(st, got, ref, what="ragged with empty groups")
+
+
 def test_full_size_properties(handle, oracle_mod):
     """BASELINE config 2 at full size (Talos, B = 1024): every QP optimal; size-independent properties:
     equality residuals, inequality feasibility within the solver's own psi tolerance, tau consistent with
