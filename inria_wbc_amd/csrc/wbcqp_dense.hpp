@@ -16,9 +16,6 @@
 #include "wbcqp_equality.hpp"
 #include "wbcqp_factor.hpp"
 
-#ifndef WBCQP_DENSE_STOP
-#define WBCQP_DENSE_STOP 0
-#endif
 namespace wbcqp {
 #ifdef __HIPCC__
 
@@ -191,9 +188,6 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
         }
         bsync();
     }
-#if WBCQP_DENSE_STOP == 1
-    return;
-#endif
     // ---- J = L^-T (upper triangular): column q of J solves L' J(:, q) = e_q; thread per column, rows q .. 0.
     //      L is read from the lower triangle, J lands in a second array (the R region is too small: use part of it plus ...)
     //      -> done in place column by column is impossible (J overwrites L): stage L^-T through the vector area is too small
@@ -255,9 +249,6 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
     }
     double f_value = block_sum(c, part);
 
-#if WBCQP_DENSE_STOP == 2
-    return;
-#endif
     int status = -2, iter = 0;
     // ---- equalities: in one blocked phase where it applies (N = CE', B = J0'N, Householder QR with J <- J Q in its shadow: the same
     //      (J, R, x, f) as neq add_constraint calls, wbcqp_equality.hpp; 18 equalities one by one were 92 us of a Talos-sized QP) ...
@@ -306,9 +297,6 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
         f_value += 0.5 * (t2 * t2) * znp;
         if (!add_constraint_hh(c, dn2)) status = HQP_ERROR; // redundant equalities
     }
-#if WBCQP_DENSE_STOP == 3
-    return;
-#endif
     // ---- inequalities
     if (status == -2) {
         for (int i = tid; i < nin; i += kThreads) c.iai[i] = i;
