@@ -318,7 +318,42 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
                 for (int i = tid; i < n; i += kThreads) c.xold[i] = c.x[i];
                 double psi = 0.0;
                 // eight lanes per row, consecutive columns across them: a load instruction touches one cache line per row (a lane per
-                // row walked its own row: 64 lines per instruction)
+                // row walked its own row: 64 lines per instruction); four rows per lane group in flight at once (a pass of 32 rows is one
+                // round trip to L2: 244 rows one pass at a time were eight of them per evaluation)
+                if (n <= 80) {
+                    for (int i0 = 0; i0 < nin; i0 += kThreads / 2) {
+                        const int l8 = tid & 7;
+                        TI rv[4][10];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const TI* row = CI + (size_t)min(i0 + 32 * p + (tid >> 3), nin - 1) * n;
+#pragma unroll
+                            for (int q = 0; q < 10; ++q) rv[p][q] = row[min(l8 + 8 * q, n - 1)];
+                        }
+                        double xv[10];
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) xv[q] = (l8 + 8 * q < n) ? c.x[min(l8 + 8 * q, n - 1)] : 0.0;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const int i = i0 + 32 * p + (tid >> 3);
+                            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                            for (int q = 0; q < 10; q += 2) {
+                                s0 = fma((double)rv[p][q], xv[q], s0);
+                                s1 = fma((double)rv[p][q + 1], xv[q + 1], s1);
+                            }
+                            const double sum = grp8_sum(s0 + s1);
+                            if (l8 == 0 && i < nin) {
+                                const double v = sum + (double)ci0[i];
+                                c.s[i] = v;
+                                c.iaexcl[i] = 1;
+                                psi += fmin(0.0, v);
+                                if (v < 0.0 && c.iai[i] != -1) best = vi_min(best, ValIdx{v, i});
+                            }
+                        }
+                    }
+                }
+                else
                 for (int i0 = 0; i0 < nin; i0 += kThreads / 8) {
                     const int i = i0 + (tid >> 3), l8 = tid & 7;
                     const TI* row = CI + (size_t)min(i, nin - 1) * n;
