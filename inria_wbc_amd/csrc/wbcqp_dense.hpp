@@ -323,12 +323,14 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
                 if (n <= 80) {
                     for (int i0 = 0; i0 < nin; i0 += kThreads / 2) {
                         const int l8 = tid & 7;
-                        TI rv[4][10];
+                        TI rv[4][10], cv[4];
 #pragma unroll
                         for (int p = 0; p < 4; ++p) {
-                            const TI* row = CI + (size_t)min(i0 + 32 * p + (tid >> 3), nin - 1) * n;
+                            const int ir = min(i0 + 32 * p + (tid >> 3), nin - 1);
+                            const TI* row = CI + (size_t)ir * n;
 #pragma unroll
                             for (int q = 0; q < 10; ++q) rv[p][q] = row[min(l8 + 8 * q, n - 1)];
+                            cv[p] = ci0[ir]; // (with the row, not behind its reduction)
                         }
                         double xv[10];
 #pragma unroll
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
                             }
                             const double sum = grp8_sum(s0 + s1);
                             if (l8 == 0 && i < nin) {
-                                const double v = sum + (double)ci0[i];
+                                const double v = sum + (double)cv[p];
                                 c.s[i] = v;
                                 c.iaexcl[i] = 1;
                                 psi += fmin(0.0, v);
