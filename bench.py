@@ -52,6 +52,8 @@ def parse():
     p.add_argument("--allgather", action="store_true",
                    help="N > 1: also all-gather the joint torques over RCCL inside every step (BASELINE config 4's optional\n"
                         "exchange; the path itself has none -- the QPs of a batch are independent)")
+    p.add_argument("--no-exchange", action="store_true", help="N > 1: skip the all-gather leg that is timed apart from the solve")
+    p.add_argument("--exchange-timeout", type=float, default=120.0, help="seconds after which the all-gather leg is abandoned")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-compare", action="store_true", help="skip the extra runs reported beside `value`")
     p.add_argument("--no-sweep", action="store_true", help="skip the batch 1..8192 table")
@@ -374,17 +376,122 @@ def dense_seam(local_rank, st, inputs, cpu=True):
     return res
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def child_command(n, port, argv):
+    """The command line `python bench.py --gpus N ...` turns itself into when it is typed without a launcher: the driver's own
+    (one process per GPU under torch.distributed.run), same flags."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` typed as is (no WORLD_SIZE): this process never touches the GPU -- it starts the N ranks as a
+    CHILD process (no exec), passes their stderr through, prints rank 0's JSON line and returns the child's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = child_command(args.gpus, free_port(), argv)
+    print("bench.py: --gpus %d without WORLD_SIZE: starting %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT)
+    line, other = None, []
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            try:
+                json.loads(t)
+                line = t
+                continue
+            except ValueError:
+                pass
+        other.append(ln)
+    rc = proc.wait()
+    for ln in other:  # whatever else the ranks wrote to stdout is not the result line
+        sys.stderr.write(ln)
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("bench.py: the %d-rank child printed no JSON line" % args.gpus, file=sys.stderr)
+    return rc
+
+
+def exchange_leg(torch, dist, h, gather, rank, world, dev, d_out, st, B, tdt, sp, step, fence, timeout_s):
+    """All-gather of the joint torques on every rank: `reps` calls of wbcqp_allgather_tau alone, then the same number
+    of solve + all-gather steps; returns the figures (rank 0 reports them) or {"error": ...}.  Runs in a worker thread so that a
+    collective that never returns is abandoned after `timeout_s` (the process then leaves through os._exit at the end of main)."""
+    import threading
+    res = {}
+
+    def work():
+        try:
+            from inria_wbc_amd import rccl
+            torch.cuda.set_device(dev)  # the HIP device is a per-thread setting
+            comm = gather["comm"]
+            if comm is None:
+                comm = rccl.comm_from_torch(dist, rank, world, dev)
+            na = max(st.na, 1)
+            tau_all = torch.zeros(world * B, na, dtype=tdt, device=dev)
+            reps = 50
+            for _ in range(5):
+                h.allgather_tau(comm, d_out["tau"].data_ptr(), tau_all.data_ptr(), B * na, stream=sp)
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                h.allgather_tau(comm, d_out["tau"].data_ptr(), tau_all.data_ptr(), B * na, stream=sp)
+            e1.record()
+            fence()
+            us = e0.elapsed_time(e1) / reps * 1e3
+            # the gathered block of every rank must be that rank's tau: rank r's own block against what it sent
+            own_ok = bool(torch.equal(tau_all[rank * B:(rank + 1) * B], d_out["tau"]))
+            t0 = time.perf_counter()
+            for t in range(reps):
+                step(t)
+                if not gather["ok"]:  # --allgather already gathers inside the step
+                    h.allgather_tau(comm, d_out["tau"].data_ptr(), tau_all.data_ptr(), B * na, stream=sp)
+            fence()
+            both = (time.perf_counter() - t0) / reps
+            esz = 4 if tdt == torch.float32 else 8
+            res.update({"us_per_allgather": us, "bytes_per_rank": B * na * esz, "bytes_gathered": world * B * na * esz,
+                        "GBps_per_rank_in": (world - 1) * B * na * esz / (us * 1e-6) / 1e9,
+                        "rccl_nranks": rccl.comm_count(comm), "own_block_intact": own_ok,
+                        "solve_plus_allgather_qps": world * B / both, "ms_per_step_with_allgather": both * 1e3,
+                        "note": "wbcqp_allgather_tau (RCCL ncclAllGather over xGMI) of the joint torques, timed apart from the solve: `value` is "
+                                "the path, which has no collective; solve_plus_allgather_qps is a step that also gathers"})
+        except Exception as e:  # noqa: BLE001
+            res["error"] = "%s: %s" % (type(e).__name__, e)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return {"error": "no answer from the exchange leg within %.0f s (abandoned)" % timeout_s, "hung": True}
+    return res
+
+
 def main():
     args = parse()
     if args.headline_only:
         args.no_compare = args.no_sweep = args.no_cpu_baseline = True
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit("bench.py --gpus %d needs one process per GPU: launch it as\n  python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...\n"
-                         "(WORLD_SIZE is %d here)" % (args.gpus, args.gpus, args.gpus, world))
+        raise SystemExit("bench.py --gpus %d under a launcher that started %d ranks (WORLD_SIZE): one process per GPU -- launch it as\n"
+                         "  python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port 29500 "
+                         "bench.py --gpus %d ...\nor type `python bench.py --gpus %d ...` alone and it starts the ranks itself"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -527,6 +634,13 @@ def main():
         elapsed = float(t.item())
     kern_avg_s = ev_s / args.steps
 
+    # ---- the optional exchange step of BASELINE config 4, timed APART from the solve (the path itself has no collective): the
+    # library's own wbcqp_allgather_tau on a communicator of this job's ranks.  It has never run on more than one rank before the
+    # driver's 8-GPU run, so it runs under a watchdog: a hang costs the exchange figures, never the line.
+    exchange = None
+    if distributed and args.backend == "nccl" and not args.no_exchange:
+        exchange = exchange_leg(torch, dist, h, gather, rank, world, dev, d_out, st, B, tdt, sp, step, fence, args.exchange_timeout)
+
     # the last timed step's outputs, with the tick they belong to (parity sample below)
     last_tick = (t_first + args.warmup + args.steps - 1) % len(tick_dicts)
     status = d_out["status"].cpu().numpy()
@@ -598,6 +712,10 @@ def main():
                 result["config"]["rccl_nranks_error"] = repr(e)
         if window is not None:
             result["window"] = window
+        if exchange is not None:
+            result["allgather_tau"] = {k: v for k, v in exchange.items() if k != "hung"}
+            if "rccl_nranks" in exchange:
+                result["config"]["rccl_nranks"] = exchange["rccl_nranks"]
 
         if world == 1 and stream and not args.headline_only:
             # how alike are consecutive ticks?  (the launch order is built on it)
@@ -826,6 +944,10 @@ def main():
             }
         print(json.dumps(result), flush=True)
 
+    if exchange is not None and exchange.get("hung"):
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)  # a collective that never returned holds this process' stream: no barrier, no destructors
     h.close()
     if distributed:
         dist.barrier()

@@ -17,12 +17,19 @@
  *
  * Plain pointers and sizes only; no C++/torch types.  Nothing throws across this boundary: every
  * entry point returns a wbcqp_status and wbcqp_last_error() gives the text.  A handle is bound to one
- * HIP device and is not thread-safe; distinct handles may be used concurrently (the reference's
- * Controller is single-threaded and non-copyable, controller.hpp:50-51).  The device-pointer solve
- * entry points allocate nothing in the steady state (upstream's solver runs under
- * EIGEN_MALLOC_NOT_ALLOWED); the FIRST launch of a larger batch than any before it (launch-order buffer,
- * 8 bytes per QP, with one stream synchronisation) and the first launch on a new stream (an 8-byte queue
- * counter) do allocate.  A captured tick (wbcqp_tick_graph_create) owns its buffers and never does.
+ * HIP device and is not thread-safe: one host thread at a time calls into it; distinct handles may be
+ * used concurrently (the reference's Controller is single-threaded and non-copyable,
+ * controller.hpp:50-51).  That one thread may launch on SEVERAL HIP streams: the handle keeps its
+ * launch-order buffer and its queue counter per stream (up to 16 distinct streams; a launch on a 17th runs
+ * in index order on the hardware's dispatcher and keeps no state), so launches in flight on two streams
+ * share nothing -- tests/test_gpu_streams.py interleaves two streams on one handle and compares bit for
+ * bit.  A stream's state is keyed by the stream handle's value: destroy a stream only after its launches
+ * have completed.  wbcqp_rollout waits for the previous roll-out of the same handle (on whatever stream it
+ * ran) before it reuses the handle's roll-out buffers.  The device-pointer solve entry points allocate
+ * nothing in the steady state (upstream's solver runs under EIGEN_MALLOC_NOT_ALLOWED); the FIRST launch
+ * on a stream of a larger batch than any before it on that stream (launch-order buffer, 8 bytes per QP,
+ * with one synchronisation of that stream) and the first launch on a new stream (an 8-byte queue counter)
+ * do allocate.  A captured tick (wbcqp_tick_graph_create) owns its buffers and never does.
  */
 #ifndef WBCQP_H
 #define WBCQP_H
@@ -34,7 +41,7 @@
 extern "C" {
 #endif
 
-#define WBCQP_VERSION 140 /* 0.1.4: + wbcqp_rollout, wbcqp_outputs.active_mask (WBCQP_FLAG_WARM_START), wbcqp_state.momentum, wbcqp_layout.wave_per_qp (WBCQP_FLAG_WORKGROUP_PER_QP); 130: wbcqp_integrate, wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions; 121: queue + packed launch order, wbcqp_launch_order */
+#define WBCQP_VERSION 150 /* 0.1.5: launch-order state per (handle, stream), active_mask written by every kernel, torque / cop task rows (wbcqp_structure.n_acteq, cop_*), posture mask; 140: + wbcqp_rollout, wbcqp_outputs.active_mask (WBCQP_FLAG_WARM_START), wbcqp_state.momentum, wbcqp_layout.wave_per_qp (WBCQP_FLAG_WORKGROUP_PER_QP); 130: wbcqp_integrate, wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions; 121: queue + packed launch order, wbcqp_launch_order */
 #define WBCQP_MAX_STRUCTURES 16
 #define WBCQP_MAX_INEQ_BLOCKS 16
 #define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: every per-QP vector fits one 128-entry LDS slot, n + 2 <= 128 */
@@ -150,7 +157,9 @@ typedef struct {
     int32_t* n_active;/* [batch] size of the final active set incl. equalities, may be NULL  */
     uint32_t* active_mask; /* [batch][8], may be NULL.  OUT: bit r of the 256-bit mask = one-sided inequality row r is active at the
                          solution.  With WBCQP_FLAG_WARM_START also IN: the mask a previous tick left for the same instance (zeros: no
-                         hint).  Device pointer on the device entry points.  Structures on the compact layout only (nin2 <= 256). */
+                         hint).  Device pointer on the device entry points.  Written by every kernel (rows beyond the 256th have no bit;
+                         all zero where the status is not OPTIMAL); READ as the hint by the compact-layout kernel only -- structures on
+                         the one-wavefront-per-QP kernel (wbcqp_layout.wave_per_qp) and on the full layout ignore the hint. */
 } wbcqp_outputs;
 
 /* wbcqp_desc.flags */
@@ -178,9 +187,13 @@ typedef struct {
 #define WBCQP_FLAG_WARM_START 64 /* OPT-IN, not what the reference does: among the violated constraints the active-set loop first picks
                                     those that were active at the previous tick's solution (wbcqp_outputs.active_mask, in/out), the most
                                     violated of them first; when none of them is violated, eiquadprog's rule (the most violated row).
-                                    Still Goldfarb-Idnani -- any violated constraint is a legal pick, the QP is strictly convex, so x
-                                    and tau are those of the cold start up to rounding -- but the add / drop churn of a cold start is
-                                    avoided: iteration counts fall to about the number of constraints active at the solution.
+                                    Still Goldfarb-Idnani -- any violated constraint is a legal pick, the QP is strictly convex, so the
+                                    EXACT solution is the cold start's -- but eiquadprog's loop ends on |sum min(s, 0)| <= nIneq eps
+                                    tr(H) tr(J) 100 (about 0.3 for the humanoid stacks), so x and tau equal the cold start's only up to
+                                    that termination tolerance: the two pick orders may end on different iterates (measured on the
+                                    squat stream: 2-4 of 1024 QPs per tick, |dx| up to 4e-4 relative; bench.py's warm_start.parity
+                                    counts them, tests/test_gpu_warm.py bounds them).  What it buys: the add / drop churn of a cold
+                                    start is avoided, iteration counts fall to about the number of constraints active at the solution.
                                     eiquadprog-fast has no such thing: bench.py reports it BESIDE the headline, never as it */
 #define WBCQP_FLAG_REFRESH_SHIFT 8
 #define WBCQP_FLAG_REFRESH(n) (((n) & 0xff) << WBCQP_FLAG_REFRESH_SHIFT) /* renew the launch order every n-th launch of a shape

@@ -56,8 +56,10 @@ constexpr size_t kPackedBytes = 1u << 20; // above this the arrays go up one by 
 } // namespace
 
 // launch-order state: the order left by one launch for the next one of the same shape on the same stream.  The handle has
-// one; every captured tick (wbcqp_graph) has its own, so that a replay never touches a buffer another launch may resize or
-// overwrite (a graph bakes the buffer's address into its kernel nodes).
+// one PER STREAM it has launched on (two launches in flight on two streams share neither the order buffer -- the schedule
+// kernel of one would overwrite what the solve kernel of the other is reading -- nor the queue counter); every captured tick
+// (wbcqp_graph) and every sub-batch of a roll-out has its own, so that a replay never touches a buffer another launch may
+// resize or overwrite (a graph bakes the buffer's address into its kernel nodes).
 struct OrderState {
     int* order = nullptr;        // [2][cap]: longest-first, then the packed order (pack_order_kernel)
     bool packed = false;         // the second half is valid for total / sig / stream
@@ -66,7 +68,7 @@ struct OrderState {
     int total = 0;               // 0: no valid order
     unsigned long long sig = 0;  // shape of the launch the order belongs to
     hipStream_t stream = nullptr;
-    int* queue = nullptr;        // graphs only: their own queue counter
+    int* queue = nullptr;        // the queue counter pair of solve_queue_kernel that goes with this order (allocated on first use)
 };
 
 constexpr size_t kMaxQueues = 16;
@@ -84,16 +86,16 @@ struct wbcqp_handle {
     long long* dbg = nullptr; // diagnostic builds only (wbcqp_debug_set_stamp_buffer)
     // longest-first schedule (schedule_kernel): launch order for the next solve of the same shape on the same stream
     int flags = 0;
-    OrderState ord;
+    // one order state (order buffer + queue counter pair) per stream this handle has launched on; a launch on a stream beyond
+    // kMaxQueues distinct ones runs in index order on the hardware's dispatcher and leaves no state behind
+    struct StreamState {
+        hipStream_t stream;
+        OrderState ord;
+    };
+    std::vector<StreamState> streams;
+    int last_stream = -1;            // index of the stream state the most recent launch used (wbcqp_launch_order reports that one)
     OrderState* graph_ord = nullptr; // wbcqp_tick_graph_create: the launches of this tick use the graph's own order state
     bool capturing = false;          // ... and a captured tick always renews its order
-    // solve_queue_kernel: one counter pair per stream this handle has launched on (two launches in flight on two streams
-    // must not share one); more streams than kMaxQueues fall back to the hardware's dispatch
-    struct Queue {
-        hipStream_t stream;
-        int* ctr;
-    };
-    std::vector<Queue> queues;
     int n_cu = 0;
     int dense_max_lds = 0;
     // wbcqp_solve_dense_host: the reference's HQPOutput, owned by the solver and valid until the next call
@@ -111,6 +113,7 @@ struct wbcqp_handle {
     };
     std::vector<RollSub> roll_subs;
     hipEvent_t roll_start = nullptr;
+    hipEvent_t roll_done = nullptr;  // end of the previous roll-out: the next one (on whatever stream) waits for it before it reuses the buffers
     Staging roll_rec, roll_state;
 };
 
@@ -312,7 +315,7 @@ void fill_group(GroupArgs<TI>& g, const Slot& s, bool compact, int batch, const 
     g.tlb = static_cast<const TI*>(in->tlb); g.tub = static_cast<const TI*>(in->tub); g.w = static_cast<const TI*>(in->w);
     g.x = static_cast<TI*>(out->x); g.tau = static_cast<TI*>(out->tau); g.objective = static_cast<TI*>(out->objective);
     g.status = out->status; g.iters = out->iters; g.n_active = out->n_active;
-    g.amask = compact ? out->active_mask : nullptr; // (the compact kernel keeps the mask; the other kernels ignore it)
+    g.amask = out->active_mask; // every kernel writes the mask; only the compact one takes it as the pick hint (g.warm)
     g.warm = 0;
     g.dbg = nullptr;
     g.count = batch;
@@ -352,7 +355,22 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     }
     // schedule: the order left by the previous launch is used when it is of this very shape and was produced on this
     // stream (stream order then guarantees that it is complete); otherwise index order
-    const bool sched = !(h->flags & WBCQP_FLAG_INDEX_ORDER) && total > 1;
+    OrderState* osp = h->graph_ord;
+    if (!osp) {
+        for (size_t i = 0; i < h->streams.size() && !osp; ++i)
+            if (h->streams[i].stream == stream) { osp = &h->streams[i].ord; h->last_stream = (int)i; }
+        if (!osp && h->streams.size() < kMaxQueues) {
+            h->streams.push_back({stream, OrderState{}});
+            h->last_stream = (int)h->streams.size() - 1;
+            osp = &h->streams.back().ord;
+            osp->stream = stream;
+        }
+        else if (!osp)
+            h->last_stream = -1;
+    }
+    OrderState none{};
+    OrderState& os = osp ? *osp : none;
+    const bool sched = osp && !(h->flags & WBCQP_FLAG_INDEX_ORDER) && total > 1;
     unsigned long long sig = 1469598103934665603ull;
     ScheduleArgs sa{};
     sa.n = tab.n;
@@ -363,9 +381,7 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         sa.iters[g] = tab.g[g].iters;
         sa.count[g] = tab.g[g].count;
     }
-    OrderState& os = h->graph_ord ? *h->graph_ord : h->ord;
-    tab.order = (sched && os.total == total && os.sig == sig && os.stream == stream)
-                    ? os.order + (os.packed ? os.cap : 0) : nullptr;
+    tab.order = (sched && os.total == total && os.sig == sig) ? os.order + (os.packed ? os.cap : 0) : nullptr;
     // The queue pays when a QP is long enough for a hand-over (1 us: atomic + order entry) to vanish and few enough workgroups
     // fit a CU for the dispatcher's binding of a workgroup to one shader engine to leave CUs idle: the humanoid stacks (one
     // or two workgroups per CU; measured on the compact layout, tools/dispatch_sweep.py: 1-2 % over the dispatcher at every
@@ -380,16 +396,12 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     }
     const int queue_occ = h->queue_occ[V];
     int* queue = nullptr;
-    if (!(h->flags & WBCQP_FLAG_HW_DISPATCH) && (lds_bytes >= kQueueMinLds || (h->flags & WBCQP_FLAG_QUEUE))) {
-        if (h->graph_ord) queue = h->graph_ord->queue;
-        else
-            for (auto& q : h->queues)
-                if (q.stream == stream) queue = q.ctr;
-        if (!queue && !h->graph_ord && h->queues.size() < kMaxQueues) {
-            HIP_TRY(h, hipMalloc(&queue, 2 * sizeof(int)));
-            HIP_TRY(h, hipMemset(queue, 0, 2 * sizeof(int)));
-            h->queues.push_back({stream, queue});
+    if (osp && !(h->flags & WBCQP_FLAG_HW_DISPATCH) && (lds_bytes >= kQueueMinLds || (h->flags & WBCQP_FLAG_QUEUE))) {
+        if (!os.queue && !h->graph_ord) {
+            HIP_TRY(h, hipMalloc(&os.queue, 2 * sizeof(int)));
+            HIP_TRY(h, hipMemset(os.queue, 0, 2 * sizeof(int)));
         }
+        queue = os.queue;
     }
     if (queue) {
         const long long resident = (long long)queue_occ * h->n_cu;
@@ -538,8 +550,11 @@ int wbcqp_destroy(wbcqp_handle* h)
         if (r.ord.queue) (void)hipFree(r.ord.queue);
     }
     if (h->roll_start) (void)hipEventDestroy(h->roll_start);
-    if (h->ord.order) (void)hipFree(h->ord.order);
-    for (auto& q : h->queues) (void)hipFree(q.ctr);
+    if (h->roll_done) (void)hipEventDestroy(h->roll_done);
+    for (auto& ss : h->streams) {
+        if (ss.ord.order) (void)hipFree(ss.ord.order);
+        if (ss.ord.queue) (void)hipFree(ss.ord.queue);
+    }
     delete h;
     return WBCQP_OK;
 }
@@ -952,13 +967,15 @@ int wbcqp_launch_order(wbcqp_handle* h, int32_t* order, int32_t capacity, int32_
 {
     if (!h || !order || capacity < 0) return WBCQP_ERR_INVALID;
     if (packed) *packed = 0;
-    if (!h->ord.order || h->ord.total <= 0) return 0;
-    if (capacity < h->ord.total) return fail(h, WBCQP_ERR_INVALID, "wbcqp_launch_order: capacity below the order's length");
+    if (h->last_stream < 0 || h->last_stream >= (int)h->streams.size()) return 0;
+    const OrderState& o = h->streams[h->last_stream].ord; // the stream of the most recent launch
+    if (!o.order || o.total <= 0) return 0;
+    if (capacity < o.total) return fail(h, WBCQP_ERR_INVALID, "wbcqp_launch_order: capacity below the order's length");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(order, h->ord.order + (h->ord.packed ? h->ord.cap : 0), sizeof(int) * (size_t)h->ord.total, hipMemcpyDeviceToHost));
-    if (packed) *packed = h->ord.packed ? 1 : 0;
-    return h->ord.total;
+    HIP_TRY(h, hipMemcpy(order, o.order + (o.packed ? o.cap : 0), sizeof(int) * (size_t)o.total, hipMemcpyDeviceToHost));
+    if (packed) *packed = o.packed ? 1 : 0;
+    return o.total;
 }
 
 int wbcqp_debug_set_stamp_buffer(wbcqp_handle* h, void* dev_ptr)
@@ -1375,15 +1392,20 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
     // overrides (1 = what K calls of wbcqp_tick do)
     int S = batch >= 512 ? 2 : 1;
     if (const char* ev = std::getenv("WBCQP_ROLLOUT_STREAMS")) S = std::max(1, std::min({std::atoi(ev), 8, batch}));
-    while ((int)h->roll_subs.size() < S) {
-        wbcqp_handle::RollSub r;
-        HIP_TRY(h, hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
-        HIP_TRY(h, hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
-        HIP_TRY(h, hipMalloc(&r.ord.queue, 2 * sizeof(int)));
-        HIP_TRY(h, hipMemset(r.ord.queue, 0, 2 * sizeof(int)));
-        h->roll_subs.push_back(r);
+    for (int k = 0; k < S; ++k) { // the handle owns a sub-batch's stream, event and counters from the moment they exist (a failure half
+        // way leaves them to wbcqp_destroy)
+        if ((int)h->roll_subs.size() <= k) h->roll_subs.emplace_back();
+        wbcqp_handle::RollSub& r = h->roll_subs[k];
+        if (!r.stream) HIP_TRY(h, hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+        if (!r.done) HIP_TRY(h, hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+        if (!r.ord.queue) {
+            HIP_TRY(h, hipMalloc(&r.ord.queue, 2 * sizeof(int)));
+            HIP_TRY(h, hipMemset(r.ord.queue, 0, 2 * sizeof(int)));
+        }
     }
     if (!h->roll_start) HIP_TRY(h, hipEventCreateWithFlags(&h->roll_start, hipEventDisableTiming));
+    const bool had_roll = h->roll_done != nullptr;
+    if (!h->roll_done) HIP_TRY(h, hipEventCreateWithFlags(&h->roll_done, hipEventDisableTiming));
     // the record of every instance (the rows kernel's output, the solve's input) and the state ping-pong
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const int rlen[8] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub};
@@ -1414,6 +1436,9 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
     char* stt = static_cast<char*>(h->roll_state.dev);
     char* qbuf[2] = {stt, stt + qb};
     char* vbuf[2] = {stt + 2 * qb, stt + 2 * qb + vb};
+    // the sub-streams of the previous roll-out may still be on the ping-pong buffers and the record when this one comes in on
+    // another stream: wait for that roll-out's end first (on the same stream the wait is already implied)
+    if (had_roll) HIP_TRY(h, hipStreamWaitEvent(sm, h->roll_done, 0));
     HIP_TRY(h, hipMemcpyAsync(qbuf[0], io->state.q, (size_t)T.nq * B * es, hipMemcpyDeviceToDevice, sm));
     HIP_TRY(h, hipMemcpyAsync(vbuf[0], io->state.v, (size_t)T.nv * B * es, hipMemcpyDeviceToDevice, sm));
     HIP_TRY(h, hipEventRecord(h->roll_start, sm));
@@ -1462,6 +1487,7 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
         HIP_TRY(h, hipEventRecord(h->roll_subs[k].done, h->roll_subs[k].stream));
         HIP_TRY(h, hipStreamWaitEvent(sm, h->roll_subs[k].done, 0));
     }
+    HIP_TRY(h, hipEventRecord(h->roll_done, sm));
     return rc_all;
 }
 

@@ -1070,7 +1070,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     const int mi = iq - neq;
                     const double rl = ri_matvec(c, Ri, mi, dsrc, dsg);
                     ValIdx bt{inf, 0x7fffffff};
-                    if (c.lane < mi && rl > 0.0) bt = ValIdx{c.u[neq + c.lane] * fast_rcp(rl), neq + c.lane};
+                    if (c.lane < mi && rl > 0.0) bt = ValIdx{ratio_pos(c.u[neq + c.lane], rl), neq + c.lane};
                     bt = wave_argmin(bt);
                     if (c.lane == 0) {
                         slot[12] = bt.v;
@@ -1095,7 +1095,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             while (true) {
                 const int iq = c.iq;
                 // ---- step lengths
-                const double t2 = (fabs(zz) > eps) ? (-sip * fast_rcp(znp)) : inf;
+                const double t2 = (fabs(zz) > eps) ? ratio_pos(-sip, znp) : inf;
                 const double t = fmin(t1, t2);
                 if (t >= inf) {
                     status = HQP_INFEASIBLE; // eiquadprog UNBOUNDED (dual) -> tsid INFEASIBLE
@@ -1284,7 +1284,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         }
                         if (i == mi) c.A[iq - 1] = ip; // the candidate moves with its position
                         ValIdx bt{inf, 0x7fffffff};
-                        if (has && rn > 0.0) bt = ValIdx{uu * fast_rcp(rn), neq + i2};
+                        if (has && rn > 0.0) bt = ValIdx{ratio_pos(uu, rn), neq + i2};
                         bt = wave_argmin(bt);
                         if (c.lane == 0) {
                             slot[12] = bt.v;

@@ -809,6 +809,14 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         }
         for (int rr = tid; rr < na; rr += kThreads) to[rr] = (TI)(c.h[nu + rr] + tact[rr]);
     }
+    if (ga.amask) { // bit r = one-sided row r (r < 256) is active at the solution; this layout does not take the mask as a hint
+        const bool on = (status == HQP_OPTIMAL) && nin2 > 0 && tid < nin2 && c.iai[tid] == -1;
+        const unsigned long long m = __ballot(on);
+        if ((tid & 63) == 0) {
+            ga.amask[qp * 8 + 2 * (tid >> 6)] = (unsigned)(m & 0xffffffffull);
+            ga.amask[qp * 8 + 2 * (tid >> 6) + 1] = (unsigned)(m >> 32);
+        }
+    }
     if (tid == 0) {
         ga.status[qp] = status;
         ga.iters[qp] = iter;

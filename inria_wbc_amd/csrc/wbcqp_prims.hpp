@@ -221,6 +221,10 @@ __device__ __forceinline__ double fast_rcp(double x)
     e = fma(-x, r, 1.0);
     return fma(r, e, r);
 }
+// u / r of the step-length ratio tests (r > 0).  The reciprocal form, except where 1 / r leaves the double range: v_rcp_f64 of an r
+// below 2^-1022 overflows and the Newton steps turn the infinity into NaN, which the argmin would silently drop -- eiquadprog's u / r
+// is 0 there for u = 0 and huge otherwise.  That (never observed) case takes the IEEE division, under a branch no lane enters.
+__device__ __forceinline__ double ratio_pos(double u, double r) { return (r >= 0x1p-1020) ? u * fast_rcp(r) : u / r; }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ double2v ld2(const double* p) { return *reinterpret_cast<const double2v*>(__builtin_assume_aligned(p, 16)); }
 __device__ __forceinline__ int wave_min_int(int v) { return -wave_max_int(-v); }

@@ -217,6 +217,7 @@ __device__ __forceinline__ void solve_one_wave(const GroupArgs<TI>& ga, const De
     }
 
     int status = -2, iter = 0, iq = 0;
+    bool act_i = false; // this lane's row is in the active set
     // ---------------- inequality loop (bounds only): GI steps 1, 2, 2a-2c, one wave ----------------
     if (nin2 > 0) {
         int ocol = 0;
@@ -230,7 +231,7 @@ __device__ __forceinline__ void solve_one_wave(const GroupArgs<TI>& ga, const De
             osg = neg ? -1.0 : 1.0;
             oci0 = neg ? (L + sm::BUB)[orr] : -(L + sm::BLB)[orr];
         }
-        bool act_i = false, excl_i = true;
+        bool excl_i = true;
         double s_i = 0.0, R_norm = 1.0;
         const double psi_tol = (double)nin2 * eps * c1 * c2 * 100.0;
         double* dcur = L + sm::D0;
@@ -288,13 +289,13 @@ __device__ __forceinline__ void solve_one_wave(const GroupArgs<TI>& ga, const De
             double znp = dn2; // z'n = |d2|^2
             double rl = ri_matvec(c, RI, iq, dcur, 1.0);
             ValIdx bt{inf, 0x7fffffff};
-            if (lane < iq && rl > 0.0) bt = ValIdx{U[lane] * fast_rcp(rl), lane};
+            if (lane < iq && rl > 0.0) bt = ValIdx{ratio_pos(U[lane], rl), lane};
             bt = wave_argmin(bt);
             double t1 = bt.v;
             int lpos = bt.i;
             double uiq = 0.0;
             while (true) {
-                const double t2 = (fabs(zz) > eps) ? (-sip * fast_rcp(znp)) : inf;
+                const double t2 = (fabs(zz) > eps) ? ratio_pos(-sip, znp) : inf;
                 const double t = fmin(t1, t2);
                 if (t >= inf) {
                     status = HQP_INFEASIBLE;
@@ -418,7 +419,7 @@ __device__ __forceinline__ void solve_one_wave(const GroupArgs<TI>& ga, const De
                 --iq;
                 rl = (lane < iq) ? (L + sm::R)[lane] : 0.0;
                 bt = ValIdx{inf, 0x7fffffff};
-                if (lane < iq && rl > 0.0) bt = ValIdx{U[lane] * fast_rcp(rl), lane};
+                if (lane < iq && rl > 0.0) bt = ValIdx{ratio_pos(U[lane], rl), lane};
                 bt = wave_argmin(bt);
                 t1 = bt.v;
                 lpos = bt.i;
@@ -444,6 +445,11 @@ __device__ __forceinline__ void solve_one_wave(const GroupArgs<TI>& ga, const De
         acc = quad_sum(acc);
         if (lane < n) ga.x[qp * n + lane] = (TI)X[lane];
         if (S.na > 0 && q4 == 0 && (lane >> 2) < S.na) ga.tau[qp * S.na + (lane >> 2)] = (TI)((double)vh + acc);
+        if (ga.amask) { // nin2 <= 32: the rows active at the solution are one ballot (the hint itself is not taken here: these QPs are
+            // a handful of iterations long)
+            const unsigned long long m = __ballot(act_i && status == HQP_OPTIMAL);
+            if (lane < 8) ga.amask[qp * 8 + lane] = lane == 0 ? (unsigned)(m & 0xffffffffull) : 0u;
+        }
         if (lane == 0) {
             ga.status[qp] = status;
             ga.iters[qp] = iter;

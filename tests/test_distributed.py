@@ -108,21 +108,43 @@ def test_ragged_shards_balance_cost_and_cover_every_qp():
     assert shard.contiguous_shards(8192, 8)[3] == (3072, 4096)
 
 
-def test_bench_refuses_a_rank_count_mismatch_and_needs_a_gpu(tmp_path):
-    """bench.py --gpus N: one process per GPU.  Without N ranks it says how to launch instead of quietly running on one GPU;
-    launched as the driver launches it (torch.distributed.run, two ranks) it gets as far as the first GPU call on this
-    GPU-less box and stops there with the product's own message (there is no CPU path to fall back to)."""
-    import subprocess
+def _clean_env():
     env = dict(os.environ)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
+    return env
+
+
+def test_bench_gpus_n_starts_its_own_ranks_as_a_child(tmp_path):
+    """`python bench.py --gpus N` exactly as typed (no launcher, no WORLD_SIZE): the parent never touches the GPU and starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>`
+    as a child -- the driver's own command.  On this GPU-less box the ranks get as far as the first GPU call and stop with the
+    product's own message (no CPU path to fall back to); the parent hands the child's exit code on."""
+    import importlib
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd = bench.child_command(8, 29512, argv)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[3:10] == ["--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29512"]
+    assert cmd[10] == os.path.join(ROOT, "bench.py") and cmd[11:] == argv
+    if torch.cuda.is_available():
+        return  # the GPU box runs the two ranks for real: tests/test_gpu_bench.py
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--headline-only"],
+                       capture_output=True, text=True, timeout=600, env=_clean_env())
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert "--nproc-per-node 2" in out and "torch.distributed.run" in out, out[-2000:]
+    assert out.count("bench.py needs an MI355X: the product path has no CPU fallback") == 2, out[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]  # no result line from a run that failed
+
+
+def test_bench_refuses_a_rank_count_mismatch_under_a_launcher():
+    """Under a launcher whose rank count differs from --gpus the bench stops with the way to launch it."""
+    import subprocess
+    env = _clean_env()
+    env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode != 0 and "torch.distributed.run" in (r.stdout + r.stderr) and "--nproc-per-node 2" in (r.stdout + r.stderr)
-    if torch.cuda.is_available():
-        return  # on a GPU box the two-rank run is the driver's to make
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode != 0
-    assert "bench.py needs an MI355X: the product path has no CPU fallback" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
+    assert r.returncode != 0 and "--nproc-per-node 2" in (r.stdout + r.stderr) and "started 3 ranks" in (r.stdout + r.stderr)

@@ -1,0 +1,53 @@
+"""bench.py on the GPU box, the way the driver types it: `python bench.py --gpus N ...` with no launcher around it starts its own
+ranks (a child `torch.distributed.run`), and the N = 1 line is what the plain run prints.  Two ranks share cuda:0 here (gloo,
+--single-device): what is under test is the launch path and the N > 1 code path of the bench, RCCL needs one GPU per rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    return env
+
+
+def _line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_gpus_2_typed_without_a_launcher_prints_one_line_with_n_gpus_2(built_lib):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+                        "--steps", "6", "--warmup", "2", "--headline-only"], capture_output=True, text=True, timeout=900, env=_env())
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "batch-shard x2" and d["config"]["batch_per_gpu"] == 1024
+    # whole-job aggregate: both ranks' QPs over the slower rank's time
+    assert abs(d["value"] - 2 * 1024 * 6 / (d["ms_per_step"] * 6e-3)) <= 1e-6 * d["value"]
+    assert d["active_set"]["status_optimal"] == 1024
+    assert "torch.distributed.run" in r.stderr  # the parent says what it starts
+
+
+def test_n1_line_has_the_contract_keys(built_lib):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-compare",
+                        "--no-sweep", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900, env=_env())
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["parity"]["status_equal"] and d["parity"]["max_rel_dx"] <= 1e-8

@@ -1,0 +1,137 @@
+"""One handle, several HIP streams (include/wbcqp.h, threading paragraph): the launch-order buffer and the queue counter are kept
+per (handle, stream), so launches in flight on two streams share nothing.  Before round 4 the handle had ONE order buffer: a launch on
+a second stream had `schedule_kernel` overwrite it while the first stream's `solve_queue_kernel` was still reading it (a QP solved
+twice, another never).  The reference has nothing like it (one controller, one thread: controller.hpp:50-51); the check is bitwise
+equality with an index-order run."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _outs(torch, dev, B, st):
+    return dict(x=torch.full((B, st.n), float("nan"), dtype=torch.float64, device=dev),
+                tau=torch.full((B, st.na), float("nan"), dtype=torch.float64, device=dev),
+                status=torch.full((B,), -99, dtype=torch.int32, device=dev),
+                iters=torch.full((B,), -1, dtype=torch.int32, device=dev),
+                active_mask=torch.full((B, 8), -1, dtype=torch.int32, device=dev))
+
+
+def test_two_streams_on_one_handle_interleaved_for_50_rounds():
+    import torch
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.talos_structure()
+    B, rounds = 1024, 50
+    dev = torch.device("cuda", 0)
+    # two different batches (different iteration profiles, hence different orders), the heavier one with long QPs
+    ins = [synth.generate(st, B, synth.SEED_BASE["talos"] + 900 + 7 * j, task_noise=(1.0, 3.0)[j]) for j in range(2)]
+    d_in = [{k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in i.items() if v.size} for i in ins]
+    # the answer: index order on the hardware's dispatcher, one launch at a time
+    hp = capi.Handle(0, capi.F64, flags=capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH)
+    hp.set_structure(0, st)
+    plain = []
+    for j in range(2):
+        o = _outs(torch, dev, B, st)
+        hp.solve_batch(0, B, d_in[j], o, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        plain.append({k: v.cpu().numpy() for k, v in o.items()})
+        assert (plain[j]["status"] != -99).all()
+    hp.close()
+    h = capi.Handle(0, capi.F64, flags=capi.flag_refresh(1))  # the order renewed after EVERY launch: the schedule kernel always runs
+    h.set_structure(0, st)
+    s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[_outs(torch, dev, B, st) for _ in range(rounds)] for _ in range(2)]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for j in range(2):  # no synchronisation between the two streams, ever
+            h.solve_batch(0, B, d_in[j], outs[j][r], stream=s[j].cuda_stream)
+    torch.cuda.synchronize()
+    for j in range(2):
+        for r in range(rounds):
+            for k in ("x", "tau", "status", "iters", "active_mask"):
+                assert np.array_equal(outs[j][r][k].cpu().numpy(), plain[j][k], equal_nan=True), (j, r, k)
+    # each stream has its own order: the last launch was on stream 1, whose order is longest-first by batch 1's counts
+    order, packed = h.launch_order()
+    assert sorted(order.tolist()) == list(range(B))
+    assert np.all(np.diff(np.minimum(plain[1]["iters"], 63)[order]) <= 0)
+    h.close()
+
+
+def test_a_seventeenth_stream_still_solves():
+    """Beyond 16 distinct streams a launch keeps no state (index order, hardware dispatch): same bits."""
+    import torch
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.talos_structure()
+    B = 96
+    dev = torch.device("cuda", 0)
+    inp = synth.generate(st, B, synth.SEED_BASE["talos"] + 77)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items() if v.size}
+    h = capi.Handle(0, capi.F64)
+    h.set_structure(0, st)
+    streams = [torch.cuda.Stream() for _ in range(18)]
+    res = []
+    for sm in streams:
+        for _ in range(2):
+            o = _outs(torch, dev, B, st)
+            h.solve_batch(0, B, d_in, o, stream=sm.cuda_stream)
+        res.append(o)
+    torch.cuda.synchronize()
+    first = {k: v.cpu().numpy() for k, v in res[0].items()}
+    assert (first["status"] == 0).all()
+    for o in res[1:]:
+        for k in ("x", "tau", "status", "iters", "active_mask"):
+            assert np.array_equal(o[k].cpu().numpy(), first[k], equal_nan=True), k
+    h.close()
+
+
+def test_every_kernel_writes_the_active_mask():
+    """wbcqp_outputs.active_mask is an output of every kernel (round 3: the compact one only; the caller's buffer came back untouched from the
+    one-wavefront-per-QP kernel and from the full layout): the same rows from the compact and the full layout, and for a small structure
+    the bits of the bounds that hold at the solution."""
+    import torch
+    from inria_wbc_amd import capi, structure, synth
+    dev = torch.device("cuda", 0)
+    st = structure.talos_structure()
+    B = 64
+    inp = synth.generate(st, B, synth.SEED_BASE["talos"] + 5, task_noise=2.0)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items() if v.size}
+    masks = {}
+    for name, flags in (("compact", 0), ("full", capi.FLAG_FULL_LDS)):
+        h = capi.Handle(0, capi.F64, flags=flags)
+        h.set_structure(0, st)
+        o = _outs(torch, dev, B, st)
+        h.solve_batch(0, B, d_in, o, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        masks[name] = o["active_mask"].cpu().numpy().view(np.uint32)
+        nact = np.array([bin(int(w)).count("1") for w in masks[name].ravel()]).reshape(B, 8).sum(axis=1)
+        assert (o["status"].cpu().numpy() == 0).all()
+        assert nact.max() > 0 and (nact <= o["iters"].cpu().numpy()).all()  # a row enters the active set in an iteration of its own
+        h.close()
+    same = (masks["compact"] == masks["full"]).all(axis=1).mean()
+    assert same >= 0.95, same  # the two layouts agree on the active set wherever no tie is broken by rounding
+    # Tiago: bounds only, one wavefront per QP
+    stt = structure.STRUCTURES["tiago"]()
+    inp = synth.generate(stt, 256, synth.SEED_BASE["tiago"] + 3, task_noise=30.0)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items() if v.size}
+    got = {}
+    for name, flags in (("wave", 0), ("workgroup", capi.FLAG_WORKGROUP_PER_QP)):
+        h = capi.Handle(0, capi.F64, flags=flags)
+        h.set_structure(0, stt)
+        o = _outs(torch, dev, 256, stt)
+        h.solve_batch(0, 256, d_in, o, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got[name] = {k: v.cpu().numpy() for k, v in o.items()}
+        h.close()
+    mw = got["wave"]["active_mask"].view(np.uint32)
+    assert (mw[:, 1:] == 0).all() and (mw[:, 0] != 0).any()  # nin2 <= 32: word 0 only, and this batch does activate bounds
+    assert np.array_equal(mw, got["workgroup"]["active_mask"].view(np.uint32))
+    # a set bit is a bound that holds with equality at the solution
+    x = got["wave"]["x"]
+    lay = capi.layout_of(stt)
+    for i in np.where(mw[:, 0] != 0)[0][:20]:
+        bits = [r for r in range(lay["nin2"]) if (int(mw[i, 0]) >> r) & 1]
+        nb = stt.n_bound
+        for r in bits:
+            col = int(stt.bound_col[r % nb])
+            lim = inp["blb"][i, r % nb] if r < nb else inp["bub"][i, r % nb]
+            assert abs(x[i, col] - lim) <= 1e-7 * max(1.0, abs(lim)), (i, r, x[i, col], lim)

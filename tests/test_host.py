@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(built_lib)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.wbcqp_version() == 140
+    assert lib.wbcqp_version() == 150
 
 
 def test_layout_without_gpu(built_lib):
