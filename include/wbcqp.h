@@ -109,6 +109,21 @@ typedef struct {
     const int32_t* ineq_arg;       /* [n_ineq_blocks] contact index for WBCQP_INEQ_FORCE                   */
     double hessian_reg;            /* tsid default 1e-8                                                    */
     int32_t max_iter;              /* eiquadprog-fast default 1000                                         */
+    /* Two level-1 task types of the reference's factory that no shipped stack uses.  Each couples blocks of H that every other
+     * task keeps apart (dv with f, one contact's forces with another's), so a stack that has one runs the full LDS layout with H
+     * assembled and factored as ONE n x n matrix (wbcqp_layout.dense_h; n <= 80) instead of a dv block and a 12 x 12 block per
+     * contact.  CE, CI and the decode are what they are without them: level-1 tasks only enter H and g.
+     *  "torque" (tasks.cpp:227-271, tsid TaskActuationEquality): n_acteq rows, one per 1 of the task's mask,
+     *      scale_j [M_a(joint_j, :) | -J_a(:, joint_j)'] x = scale_j tau_ref_j - scale_j h_a(joint_j)   (SURVEY A.1 step 6);
+     *      scale = the task's weight vector (`scaling:`, tasks.cpp:256-261), tau_ref = 0 in the reference (tasks.cpp:263-265); the
+     *      products scale_j tau_ref_j are the task's entries of wbcqp_inputs.b1.
+     *  "cop" (tasks.cpp:156-178, tsid TaskCopEquality): 3 rows over ALL 12 nc force variables (the task is associated with no
+     *      single contact), given per QP in wbcqp_inputs.Acop -- they depend on the contact frames' placements; right-hand side in b1. */
+    int32_t n_acteq;               /* rows of the torque task; 0: none                                     */
+    const int32_t* acteq_joint;    /* [n_acteq] actuated joint in [0, na), ascending                       */
+    const double* acteq_scale;     /* [n_acteq]                                                            */
+    int32_t acteq_task;            /* -> index into w                                                      */
+    int32_t cop_task;              /* -> index into w; -1: no cop task (a zero-initialised structure must set it to -1) */
 } wbcqp_structure;
 
 /* Sizes derived from a structure (what PosTracker prints under `verbose`, pos_tracker.cpp:150-158). */
@@ -117,7 +132,7 @@ typedef struct {
     int32_t neq;  /* tsid nEq  = (nv - na) + 6 nc */
     int32_t nin;  /* tsid nIn  (two-sided rows) */
     int32_t nin2; /* one-sided rows of eiquadprog's CI = 2 nin */
-    int32_t r1;   /* level-1 rows = n_dense + n_sel + 6 nc */
+    int32_t r1;   /* level-1 rows = n_dense + n_sel + 6 nc + n_acteq + (3 if a cop task) */
     /* element counts of the per-QP input arrays below */
     int32_t len_M, len_h, len_A, len_b1, len_Ac, len_bc, len_blb, len_bub, len_tlb, len_tub, len_w;
     int32_t lds_bytes;         /* dynamic LDS one QP (one 256-thread workgroup) needs */
@@ -126,6 +141,8 @@ typedef struct {
     int32_t wave_per_qp;       /* 1: the structure runs one WAVEFRONT per QP (n <= 16, fixed base, no contacts, bounds only: Franka, Tiago),
                                   four QPs per workgroup, 7.7 KB of LDS per QP; lds_bytes / waves_per_cu then describe the four-wave
                                   kernel that WBCQP_FLAG_WORKGROUP_PER_QP selects */
+    int32_t dense_h;           /* 1: the stack has a torque or a cop task -- full layout, H factored as one n x n matrix (never compact) */
+    int32_t len_Acop;          /* element count of wbcqp_inputs.Acop: 3 * 12 nc with a cop task, else 0 */
     int32_t reserved_;
 } wbcqp_layout;
 
@@ -138,7 +155,8 @@ typedef struct {
     const void* h;   /* [batch][nv]  non-linear effects                                                     */
     const void* A;   /* [batch][n_dense][nv] dense level-1 task rows (TaskSE3Equality & co: ex_task.cpp:175-247,
                         task-momentum-equality.cpp:144-173, task-self-collision.cpp:84-203)                   */
-    const void* b1;  /* [batch][r1] level-1 right-hand sides: dense | selection | force-regularisation      */
+    const void* b1;  /* [batch][r1] level-1 right-hand sides: dense | selection | force-regularisation
+                        | torque task (scale_j tau_ref_j, n_acteq) | cop task (3)                             */
     const void* Ac;  /* [batch][nc][6][nv] contact motion-task matrices (local frame)                       */
     const void* bc;  /* [batch][nc][6]     contact motion-task right-hand sides                             */
     const void* blb; /* [batch][n_bound]   acceleration bounds                                              */
@@ -146,6 +164,7 @@ typedef struct {
     const void* tlb; /* [batch][na]        torque bounds, before the -h_a shift (NULL if !act_bounds)       */
     const void* tub; /* [batch][na]                                                                         */
     const void* w;   /* [batch][n_tasks]   level-1 task weights (PosTracker::update_task_weights)           */
+    const void* Acop;/* [batch][3][12 nc]  rows of the cop task over the force variables (NULL without one)      */
 } wbcqp_inputs;
 
 typedef struct {

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwbcqp.so")
 WBCQP_OK = 0
 ERR_NAMES = {0: "OK", 1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "NO_DEVICE", 5: "RCCL"}
 F64, F32 = 0, 1
-FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
+FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w", "Acop")
 
 # every symbol include/wbcqp.h declares
 EXPORTS = ("wbcqp_version", "wbcqp_last_error", "wbcqp_create", "wbcqp_destroy", "wbcqp_set_structure",
@@ -49,13 +49,14 @@ class CStructure(C.Structure):
         ("n_bound", C.c_int32), ("bound_col", c_i32_p), ("act_bounds", C.c_int32),
         ("n_ineq_blocks", C.c_int32), ("ineq_kind", c_i32_p), ("ineq_arg", c_i32_p),
         ("hessian_reg", C.c_double), ("max_iter", C.c_int32),
+        ("n_acteq", C.c_int32), ("acteq_joint", c_i32_p), ("acteq_scale", c_f64_p), ("acteq_task", C.c_int32), ("cop_task", C.c_int32),
     ]
 
 
 class CLayout(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n", "neq", "nin", "nin2", "r1", "len_M", "len_h", "len_A", "len_b1", "len_Ac",
                                          "len_bc", "len_blb", "len_bub", "len_tlb", "len_tub", "len_w", "lds_bytes",
-                                         "waves_per_cu")] + [("algorithmic_bytes", C.c_int64), ("wave_per_qp", C.c_int32), ("reserved_", C.c_int32)]
+                                         "waves_per_cu")] + [("algorithmic_bytes", C.c_int64), ("wave_per_qp", C.c_int32), ("dense_h", C.c_int32), ("len_Acop", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class CInputs(C.Structure):
@@ -241,6 +242,11 @@ class StructureBuffers:
         s.ineq_arg = ip([a for _, a in st.ineq_blocks])
         s.hessian_reg = st.hessian_reg
         s.max_iter = st.max_iter
+        s.n_acteq = st.n_acteq
+        s.acteq_joint = ip(st.acteq_joint)
+        s.acteq_scale = dp(st.acteq_scale)
+        s.acteq_task = int(st.acteq_task)
+        s.cop_task = int(st.cop_task)
         self.c = s
 
 

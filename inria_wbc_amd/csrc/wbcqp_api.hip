@@ -45,7 +45,7 @@ struct Staging {
     void* dev = nullptr;
     size_t bytes = 0;
 };
-// page-locked host memory for the host-pointer entry points at small batches: the eleven input arrays of a QP record (five output
+// page-locked host memory for the host-pointer entry points at small batches: the input arrays of a QP record (eleven, twelve with a cop task; five output
 // arrays) cross PCIe as ONE copy each way instead of eleven (five) -- at batch 1 the copies' fixed cost is most of the call
 struct Pinned {
     void* host = nullptr;
@@ -155,7 +155,24 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
     D.n_dense = st->n_dense; D.n_tasks = st->n_tasks; D.n_sel = st->n_sel; D.n_bound = st->n_bound;
     D.act_bounds = st->act_bounds ? 1 : 0;
     D.neq = D.nu + 6 * D.nc;
-    D.r1 = D.n_dense + D.n_sel + 6 * D.nc;
+    // level-1 tasks that couple the blocks of H ("torque", "cop"): H dense, full layout
+    D.n_acteq = st->n_acteq;
+    D.acteq_task = st->acteq_task;
+    D.cop_task = st->cop_task;
+    if (D.n_acteq < 0 || D.n_acteq > D.na) { why = "n_acteq outside [0, na]"; return WBCQP_ERR_INVALID; }
+    if (D.n_acteq > 0) {
+        if (!st->acteq_joint || !st->acteq_scale) { why = "acteq_joint / acteq_scale is NULL"; return WBCQP_ERR_INVALID; }
+        if (D.acteq_task < 0 || D.acteq_task >= D.n_tasks) { why = "acteq_task out of range"; return WBCQP_ERR_INVALID; }
+        for (int j = 0; j < D.n_acteq; ++j)
+            if (st->acteq_joint[j] < 0 || st->acteq_joint[j] >= D.na || (j > 0 && st->acteq_joint[j] <= st->acteq_joint[j - 1])) { why = "acteq_joint must be ascending in [0, na)"; return WBCQP_ERR_INVALID; }
+    }
+    if (D.cop_task >= D.n_tasks) { why = "cop_task out of range"; return WBCQP_ERR_INVALID; }
+    if (D.cop_task < 0) D.cop_task = -1;
+    if (D.cop_task >= 0 && D.nc == 0) { why = "a cop task needs a contact"; return WBCQP_ERR_INVALID; }
+    D.dense_h = (D.n_acteq > 0 || D.cop_task >= 0) ? 1 : 0;
+    if (D.dense_h && D.n > 80) { why = "a torque / cop task makes H dense: supported for n <= 80 (the dense seam, wbcqp_solve_dense, carries n <= 96)"; return WBCQP_ERR_UNSUPPORTED; }
+    if (D.cop_task >= 0 && 3 * D.k > kSlot) { why = "cop rows exceed one 128-entry slot"; return WBCQP_ERR_UNSUPPORTED; }
+    D.r1 = D.n_dense + D.n_sel + 6 * D.nc + D.n_acteq + (D.cop_task >= 0 ? 3 : 0);
     HB.n_blocks = st->n_ineq_blocks;
     int off = 0;
     bool has_act = false;
@@ -217,9 +234,11 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
     L.len_M = nv * (nv + 1) / 2; L.len_h = nv; L.len_A = D.n_dense * nv; L.len_b1 = D.r1;
     L.len_Ac = D.nc * 6 * nv; L.len_bc = D.nc * 6; L.len_blb = D.n_bound; L.len_bub = D.n_bound;
     L.len_tlb = D.act_bounds ? D.na : 0; L.len_tub = L.len_tlb; L.len_w = D.n_tasks;
+    L.len_Acop = D.cop_task >= 0 ? 3 * D.k : 0;
+    L.dense_h = D.dense_h;
     set_lds(L, o * 8);
     const int64_t n_in = (int64_t)L.len_M + L.len_h + L.len_A + L.len_b1 + L.len_Ac + L.len_bc + L.len_blb + L.len_bub +
-                         L.len_tlb + L.len_tub + L.len_w;
+                         L.len_tlb + L.len_tub + L.len_w + L.len_Acop;
     L.algorithmic_bytes = 8 * (n_in + n + D.na) + 8;
     if (L.lds_bytes > 160 * 1024) { why = "QP does not fit the 160 KiB LDS of one CU"; return WBCQP_ERR_UNSUPPORTED; }
     return WBCQP_OK;
@@ -230,6 +249,7 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
 // one wavefront per QP (wbcqp_small.hpp): fixed base, no contacts, n = nv <= 16, bounds as the only inequality rows
 bool small_ok(const DevStruct& D, const HostBlocks& HB)
 {
+    if (D.dense_h) return false;
     if (!(D.nc == 0 && D.nu == 0 && D.neq == 0 && D.n == D.nv && D.n >= 1 && D.n <= 16 && D.na <= 16 && D.n_dense <= 16 && D.n_sel <= 16 &&
           D.n_tasks >= 1 && D.n_tasks <= 16 && D.n_bound <= 16 && D.nin2 <= 32 && D.r1 >= 1 && D.r1 <= 32 && !D.act_bounds))
         return false;
@@ -242,6 +262,7 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
 {
     D = F;
     D.compact = 0;
+    if (F.dense_h) return false; // a torque / cop task: H is one n x n matrix, the compact kernel factors a dv block and 12 x 12 blocks
     const int n = F.n, nv = F.nv;
     if (!(n <= 80 && F.neq <= 22 && nv <= 52 && F.nc <= 2 && F.nu <= 8 && F.na <= 64 && F.n_bound <= 64 && F.nin2 <= 256 &&
           F.r1 <= 128 && F.n_tasks <= 64 && (!F.act_bounds || F.act_off >= 0) && n - F.neq <= 64))
@@ -313,6 +334,7 @@ void fill_group(GroupArgs<TI>& g, const Slot& s, bool compact, int batch, const 
     g.b1 = static_cast<const TI*>(in->b1); g.Ac = static_cast<const TI*>(in->Ac); g.bc = static_cast<const TI*>(in->bc);
     g.blb = static_cast<const TI*>(in->blb); g.bub = static_cast<const TI*>(in->bub);
     g.tlb = static_cast<const TI*>(in->tlb); g.tub = static_cast<const TI*>(in->tub); g.w = static_cast<const TI*>(in->w);
+    g.Acop = static_cast<const TI*>(in->Acop);
     g.x = static_cast<TI*>(out->x); g.tau = static_cast<TI*>(out->tau); g.objective = static_cast<TI*>(out->objective);
     g.status = out->status; g.iters = out->iters; g.n_active = out->n_active;
     g.amask = out->active_mask; // every kernel writes the mask; only the compact one takes it as the pick hint (g.warm)
@@ -334,7 +356,7 @@ int check_io(wbcqp_handle* h, const Slot& s, int batch, const wbcqp_inputs* in, 
     if (!need(in->M, L.len_M, "M") || !need(in->h, L.len_h, "h") || !need(in->A, L.len_A, "A") || !need(in->b1, L.len_b1, "b1") ||
         !need(in->Ac, L.len_Ac, "Ac") || !need(in->bc, L.len_bc, "bc") || !need(in->blb, L.len_blb, "blb") ||
         !need(in->bub, L.len_bub, "bub") || !need(in->tlb, L.len_tlb, "tlb") || !need(in->tub, L.len_tub, "tub") ||
-        !need(in->w, L.len_w, "w"))
+        !need(in->w, L.len_w, "w") || !need(in->Acop, L.len_Acop, "Acop"))
         return WBCQP_ERR_INVALID;
     if (!out->x || !out->status || !out->iters || (s.host.na > 0 && !out->tau))
         return fail(h, WBCQP_ERR_INVALID, "output arrays x, tau, status, iters are required");
@@ -596,6 +618,8 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     UP(sel_task, st->sel_task, D.n_sel);
     UP(forcereg_task, st->forcereg_task, nc);
     UP(bound_col, st->bound_col, D.n_bound);
+    UP(acteq_joint, st->acteq_joint, D.n_acteq);
+    UP(acteq_scale, st->acteq_scale, D.n_acteq);
     UP(force_gen, st->force_gen, nc * 72);
     UP(ftf, ftf.data(), nc * 144);
     UP(ft, ft.data(), nc * 72);
@@ -725,11 +749,12 @@ int wbcqp_solve_batch_host(wbcqp_handle* h, int slot, int batch, const wbcqp_inp
     HIP_TRY(h, hipSetDevice(h->device));
     const wbcqp_layout& L = s.layout;
     const size_t es = (h->dtype == WBCQP_F64) ? 8 : 4;
-    const int lens[11] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub, L.len_tlb, L.len_tub, L.len_w};
-    const void* src[11] = {in->M, in->h, in->A, in->b1, in->Ac, in->bc, in->blb, in->bub, in->tlb, in->tub, in->w};
+    constexpr int NF = 12;
+    const int lens[NF] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub, L.len_tlb, L.len_tub, L.len_w, L.len_Acop};
+    const void* src[NF] = {in->M, in->h, in->A, in->b1, in->Ac, in->bc, in->blb, in->bub, in->tlb, in->tub, in->w, in->Acop};
     size_t in_bytes = 0;
-    size_t offs[11];
-    for (int f = 0; f < 11; ++f) {
+    size_t offs[NF];
+    for (int f = 0; f < NF; ++f) {
         offs[f] = in_bytes;
         in_bytes += (((size_t)lens[f] * batch * es) + 255) & ~(size_t)255;
     }
@@ -754,15 +779,15 @@ int wbcqp_solve_batch_host(wbcqp_handle* h, int slot, int batch, const wbcqp_inp
         rc = ensure_pinned(h, h->pin_out, kPackedBytes);
         if (rc != WBCQP_OK) return rc;
         char* pin = static_cast<char*>(h->pin_in.host);
-        for (int f = 0; f < 11; ++f)
+        for (int f = 0; f < NF; ++f)
             if (lens[f] > 0) std::memcpy(pin + offs[f], src[f], (size_t)lens[f] * batch * es);
         HIP_TRY(h, hipMemcpyAsync(din, pin, in_bytes, hipMemcpyHostToDevice, nullptr));
     }
     else
-        for (int f = 0; f < 11; ++f)
+        for (int f = 0; f < NF; ++f)
             if (lens[f] > 0) HIP_TRY(h, hipMemcpyAsync(din + offs[f], src[f], (size_t)lens[f] * batch * es, hipMemcpyHostToDevice, nullptr));
     wbcqp_inputs di = {din + offs[0], din + offs[1], din + offs[2], din + offs[3], din + offs[4], din + offs[5],
-                       din + offs[6], din + offs[7], din + offs[8], din + offs[9], din + offs[10]};
+                       din + offs[6], din + offs[7], din + offs[8], din + offs[9], din + offs[10], din + offs[11]};
     wbcqp_outputs dso{};
     dso.x = dout + o_x; dso.tau = dout + o_tau; dso.objective = dout + o_obj;
     dso.status = reinterpret_cast<int32_t*>(dout + o_st); dso.iters = reinterpret_cast<int32_t*>(dout + o_it);

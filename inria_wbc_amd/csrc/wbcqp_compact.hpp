@@ -235,6 +235,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     c.lane = tid & (kWave - 1);
     c.wave = uni(tid >> 6);
     c.rslot = 0;
+    c.nblk = S.nv;
     c.nv = S.nv; c.na = S.na; c.nc = S.nc; c.k = S.k; c.n = S.n; c.nu = S.nu;
     c.neq = S.neq; c.nin2 = S.nin2; c.ldj = S.ldj; c.ldm = 0; c.ldc = 0; c.ldb = S.ldb;
     c.J = lds + S.o_J; c.R = lds + S.o_R;

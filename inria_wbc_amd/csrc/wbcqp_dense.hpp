@@ -48,6 +48,7 @@ __global__ __launch_bounds__(kThreads) void solve_dense_kernel(const DenseArgs a
     c.lane = tid & (kWave - 1);
     c.wave = uni(tid >> 6);
     c.rslot = 0;
+    c.nblk = n;
     c.nv = n; c.na = 0; c.nc = 0; c.k = 0; c.n = n; c.nu = 0; c.neq = neq; c.nin2 = nin; c.ldj = ldj; c.ldm = 0; c.ldc = 0; c.ldb = 0;
     c.J = lds + a.o_J; c.R = lds + a.o_R;
     c.M = c.Jc = c.Ac = nullptr;

@@ -30,6 +30,155 @@
 namespace wbcqp {
 #ifdef __HIPCC__
 
+
+// ------------------------------------------------------------------------------------------------
+// Phases 1-2 for a stack with a "torque" or a "cop" task (tasks.cpp:227-271, :156-178): those level-1 rows couple dv with f and
+// one contact's forces with another's, so H is ONE n x n matrix (n <= 80, checked on the host) -- a 16 x 16 thread grid keeps the
+// positions (ta + 16 u, te + 16 w), u <= w < 5, in registers, accumulates every level-1 row into them and eliminates with the
+// same eliminate_block the dense seam uses (wbcqp_dense.hpp).  Sources of the rows: the staged motion rows (columns < nv), the
+// actuation rows scale_j [M_a(joint_j, :) | -J_a(:, joint_j)'] read in place from M and Jc in LDS, the cop rows from the record
+// (c.xold), the selection rows' diagonal (c.z), the force-regularisation blocks w F'F.  g: dv part formed here, force part = what
+// phase 0 left (force regularisation) minus these rows' share.  Leaves J = U^-1 (upper triangular, dense), c1 = tr H, c2 = tr J.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void assemble_eliminate_dense(Ctx& c, const DevStruct& S, const double* As, double& c1, double& c2)
+{
+    const int tid = c.tid, n = c.n, nv = c.nv, nu = c.nu, nc = c.nc, k = c.k, ldj = c.ldj, ldm = c.ldm, ldc = c.ldc;
+    const int n_dense = S.n_dense, n_sel = S.n_sel;
+    const int ta = tid >> 4, te = tid & 15;
+    double h[5][5], y[5][5], gacc[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        gacc[u] = 0.0;
+#pragma unroll
+        for (int w = 0; w < 5; ++w) {
+            h[u][w] = 0.0;
+            y[u][w] = 0.0;
+        }
+    }
+    // (a) motion rows: columns < nv <= 64 live in the tile's first four positions (what is staged past nv was never written)
+    {
+        const double* WB = As + n_dense * 64;
+        for (int r = 0; r < n_dense; ++r) {
+            const double2v ai0 = ld2(As + r * 64 + ta * 4), ai1 = ld2(As + r * 64 + ta * 4 + 2);
+            const double2v aj0 = ld2(As + r * 64 + te * 4), aj1 = ld2(As + r * 64 + te * 4 + 2);
+            const double2v wb = ld2(WB + 2 * r);
+            const double a[4] = {ai0.x, ai0.y, ai1.x, ai1.y};
+            const double b[4] = {aj0.x, aj0.y, aj1.x, aj1.y};
+            double am[4], bw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                am[u] = (ta + 16 * u < nv) ? a[u] : 0.0;
+                bw[u] = (te + 16 * u < nv) ? b[u] * wb.x : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = u; w < 4; ++w) h[u][w] = fma(am[u], bw[w], h[u][w]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) gacc[w] = fma(bw[w], wb.y, gacc[w]);
+        }
+    }
+    // (b) torque task: row j = scale_j [M(nu + joint_j, :) | -Jc(:, nu + joint_j)'], rhs scale_j tau_ref_j - scale_j h_a(joint_j)
+    if (S.n_acteq > 0) {
+        const double wt = c.w[S.acteq_task];
+        const double* bt = c.b1 + n_dense + n_sel + 6 * nc;
+        for (int j = 0; j < S.n_acteq; ++j) {
+            const int ax = nu + S.acteq_joint[j];
+            const double sc = S.acteq_scale[j];
+            const double bj = bt[j] - sc * c.h[ax];
+            const double ws = wt * sc * sc, wg = wt * sc * bj;
+            double ai[5], aj[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int ci = ta + 16 * u, cj = te + 16 * u;
+                const double mi = c.M[ax * ldm + min(ci, nv - 1)], mj = c.M[ax * ldm + min(cj, nv - 1)];
+                const double ji = (k > 0) ? c.Jc[min(max(ci - nv, 0), max(k - 1, 0)) * ldc + ax] : 0.0;
+                const double jj = (k > 0) ? c.Jc[min(max(cj - nv, 0), max(k - 1, 0)) * ldc + ax] : 0.0;
+                ai[u] = (ci < nv) ? mi : ((ci < n) ? -ji : 0.0);
+                aj[u] = (cj < nv) ? mj : ((cj < n) ? -jj : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+#pragma unroll
+                for (int w = u; w < 5; ++w) h[u][w] = fma(ws * ai[u], aj[w], h[u][w]);
+#pragma unroll
+            for (int w = 0; w < 5; ++w) gacc[w] = fma(wg, aj[w], gacc[w]);
+        }
+    }
+    // (c) cop task: three rows over the force columns, staged in c.xold by phase 0
+    if (S.cop_task >= 0) {
+        const double wt = c.w[S.cop_task];
+        const double* bcop = c.b1 + n_dense + n_sel + 6 * nc + S.n_acteq;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double* row = c.xold + r * k;
+            const double wb = wt * bcop[r];
+            double ai[5], aj[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int ci = ta + 16 * u, cj = te + 16 * u;
+                const double vi = row[min(max(ci - nv, 0), k - 1)], vj = row[min(max(cj - nv, 0), k - 1)];
+                ai[u] = (ci >= nv && ci < n) ? vi : 0.0;
+                aj[u] = (cj >= nv && cj < n) ? vj : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+#pragma unroll
+                for (int w = u; w < 5; ++w) h[u][w] = fma(wt * ai[u], aj[w], h[u][w]);
+#pragma unroll
+            for (int w = 0; w < 5; ++w) gacc[w] = fma(wb, aj[w], gacc[w]);
+        }
+    }
+    // (d) g: the dv part is formed here (selection rows' share in c.d), the force part already holds the force regularisation's
+    if (ta == 0) {
+#pragma unroll
+        for (int w = 0; w < 5; ++w) {
+            const int col = te + 16 * w;
+            if (col < nv) c.g[col] = -gacc[w] - c.d[col];
+            else if (col < n) c.g[col] -= gacc[w];
+        }
+    }
+    // (e) force regularisation w F'F on each contact's 12 x 12 block, the selection rows and the regulariser on the diagonal
+    double trace = 0.0;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int w = u; w < 5; ++w) {
+            const int r = ta + 16 * u, q = te + 16 * w;
+            if (nc > 0) {
+                const int cr = max(r - nv, 0) / 12, cq = max(q - nv, 0) / 12;
+                const bool in = r >= nv && q >= nv && r < n && q < n && cr == cq;
+                const int cs = min(cr, nc - 1);
+                const double fv = S.ftf[cs * 144 + min(max(r - nv - 12 * cs, 0), 11) * 12 + min(max(q - nv - 12 * cs, 0), 11)];
+                const double wf = c.w[S.forcereg_task[cs]];
+                if (in) h[u][w] = fma(wf, fv, h[u][w]);
+            }
+            if (r == q && r < n) {
+                h[u][w] += ((r < nv) ? c.z[min(r, nv - 1)] : 0.0) + S.hessian_reg;
+                trace += h[u][w];
+            }
+            if (r >= n || q >= n) h[u][w] = (r == q) ? 1.0 : 0.0; // positions past the matrix: identity (inert pivots)
+        }
+    c1 = block_sum(c, trace);
+    // ---- H -> J = U^-1 (wbcqp_factor.hpp), panels in the s / stash / part slots (11 x 128 doubles, contiguous)
+    double* RB = c.s;
+    double* YB = c.s + 2 * 5 * 16 * 4;
+    publish_panel<4, 5, false, 0>(c, h, y, ta, te, 0, RB, YB);
+    eliminate_block<4, 5, false, 0>(c, h, y, ta, te, (n + 3) & ~3, RB, YB, c.dinv, tid >= 128 && tid < 132, tid & 3);
+    bsync();
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int w = u; w < 5; ++w) {
+            const int r = ta + 16 * u, q = te + 16 * w;
+            if (q < n && r < q) c.J[r * ldj + q] = y[u][w] * c.dinv[q];
+            else if (r == q && r < n) c.J[r * ldj + r] = c.dinv[r];
+        }
+    double tr2 = 0.0;
+    for (int i = tid; i < n; i += kThreads) tr2 += c.dinv[i];
+    c2 = block_sum(c, tr2);
+}
+
 // ------------------------------------------------------------------------------------------------
 // one QP on one workgroup of 256 threads
 // ------------------------------------------------------------------------------------------------
@@ -43,6 +192,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     c.wave = uni(tid >> 6);
     c.rslot = 0;
     c.nv = S.nv; c.na = S.na; c.nc = S.nc; c.k = S.k; c.n = S.n; c.nu = S.nu;
+    c.nblk = S.dense_h ? S.n : S.nv;
     c.neq = S.neq; c.nin2 = S.nin2; c.ldj = S.ldj; c.ldm = S.ldm; c.ldc = S.ldc;
     c.J = lds + S.o_J; c.R = lds + S.o_R; c.M = lds + S.o_M; c.Jc = lds + S.o_Jc; c.Ac = lds + S.o_Ac;
     {
@@ -160,6 +310,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
             c.tl[tid] = (double)vtl - (double)vha;
             c.tu[tid] = (double)vtu - (double)vha;
         }
+        if (S.cop_task >= 0 && tid < 3 * k) c.xold[tid] = (double)ga.Acop[qp * (size_t)(3 * k) + tid]; // cop rows (slot idle until the loop)
         if (tid < nin2) c.meta[tid] = meta0;
         if (tid + kThreads < nin2) c.meta[tid + kThreads] = meta1;
         c.iai[tid] = drt; // parked until w has landed (iai is initialised in phase 4)
@@ -226,7 +377,8 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     // Thread (ta, te) of a 16 x 16 grid OWNS the strided positions (ta + 16u, te + 16w) of the upper triangle of the
     // dv block for the whole pipeline: H is accumulated, factorised and inverted in its registers (eliminate_block).
     double c1, c2;
-    { // nv <= 64 is checked on the host
+    if (S.dense_h) assemble_eliminate_dense(c, S, As, c1, c2);
+    else { // nv <= 64 is checked on the host
         const int ta = tid >> 4, te = tid & 15;
         double h[4][4];
         double trace = 0.0;
@@ -380,7 +532,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         const int idx = tid >> 1, hf = tid & 1;
         const int ic = min(idx, n - 1);
         {
-            const int kb0 = blk_begin(ic, nv), len = ic + 1 - kb0, hl = (len + 1) >> 1;
+            const int kb0 = blk_begin(ic, c.nblk), len = ic + 1 - kb0, hl = (len + 1) >> 1;
             const int ka = kb0 + hf * hl, kb = hf ? ic + 1 : kb0 + hl;
             double dv = dot8(c.J + ic, ldj, c.g, 1, ka, kb);
             dv += dpp_get<0xB1>(dv);
@@ -394,7 +546,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
         bsync();
         double part = 0.0;
         {
-            const int ce = blk_end(ic, nv), len = ce - ic, hl = (len + 1) >> 1;
+            const int ce = blk_end(ic, c.nblk), len = ce - ic, hl = (len + 1) >> 1;
             const int ca = ic + hf * hl, cb = hf ? ce : ic + hl;
             double zv = dot8(c.J + ic * ldj, 1, c.d, 1, ca, cb);
             zv += dpp_get<0xB1>(zv);

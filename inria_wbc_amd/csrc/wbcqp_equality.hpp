@@ -229,7 +229,7 @@ __device__ __forceinline__ void solve_y(Ctx& c, double* rhs)
 template <typename BuildN, typename Ce0>
 __device__ __forceinline__ bool equality_phase_blocked_t(Ctx& c, double& f_value, BuildN build_n, Ce0 ce0_of)
 {
-    const int n = c.n, m = c.neq, nv = c.nv, ldj = c.ldj, ldb = c.ldb, tid = c.tid;
+    const int n = c.n, m = c.neq, ldj = c.ldj, ldb = c.ldb, tid = c.tid;
     double* Nm = c.eqw;        // N = CE' (n x m), later W = J0 V
     double* Bm = c.R + 256;    // B -> V (lower trapezoid) / R (strict upper), in the unused tail of the R region
     double* Tm = c.eqt;        // T (m x (m+1))
@@ -265,7 +265,7 @@ __device__ __forceinline__ bool equality_phase_blocked_t(Ctx& c, double& f_value
         const int cp = tid / ncg, cg = tid - cp * ncg;
         const int c0 = 2 * cp, c1 = min(c0 + 1, n - 1);
         const bool act = c0 < n;
-        int kmin = act ? blk_begin(c0, nv) : n, kmax = act ? c1 + 1 : 0;
+        int kmin = act ? blk_begin(c0, c.nblk) : n, kmax = act ? c1 + 1 : 0;
         kmin = wave_min_int(kmin);
         kmax = wave_max_int(kmax);
         double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};

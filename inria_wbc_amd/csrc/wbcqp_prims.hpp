@@ -138,6 +138,7 @@ struct Ctx {
     const DevStruct* S;
     int tid, lane, wave;
     int nv, na, nc, k, n, nu, neq, nin2, ldj, ldm, ldc, ldb;
+    int nblk; // J0 = U^-1 is block diagonal [dv | 12 | 12 ..] with the first block nblk wide (blk_begin / blk_end); n where H is dense
     double *J, *R, *M, *Jc, *Ac, *h, *x, *np, *d, *z, *xold, *r, *u, *uold, *s;
     double *blb, *bub, *tl, *tu, *bc, *prm, *rdinv, *dinv, *g, *w, *b1, *q, *wrow, *red, *part, *stash, *eqw, *eqt;
     int *A, *Aold, *iai, *iaexcl, *gskip, *meta;

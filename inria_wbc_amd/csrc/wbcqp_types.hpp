@@ -65,12 +65,17 @@ struct DevStruct {
     int act_off;             // first one-sided row of the actuation block (+A rows; the -A rows follow na later), -1: none
     int o_pan;               // elimination panels, offset inside the J region (behind the staged task rows)
     const unsigned* acpack;  // [nc 6 nv] contact-Jacobian element (rr, kk) -> offset kk ldb + nu + rr in N = CE'
+    // level-1 tasks that make H dense (full layout only): torque rows scale_j [M_a(joint_j,:) | -J_a(:,joint_j)'], cop rows from the record
+    int dense_h;             // 1: H is assembled and eliminated as one n x n matrix (n <= 80)
+    int n_acteq, acteq_task, cop_task;
+    const int* acteq_joint;  // [n_acteq]
+    const double* acteq_scale;
 };
 
 template <typename TI>
 struct GroupArgs {
     DevStruct st; // by value: the sizes, offsets and table pointers arrive with the kernel arguments, not behind a pointer
-    const TI *M, *h, *A, *b1, *Ac, *bc, *blb, *bub, *tlb, *tub, *w;
+    const TI *M, *h, *A, *b1, *Ac, *bc, *blb, *bub, *tlb, *tub, *w, *Acop;
     TI *x, *tau, *objective;
     int *status, *iters, *n_active;
     unsigned* amask; // [count][8] active-set mask of the solution (out; in as the pick hint when warm != 0), or null
@@ -85,6 +90,8 @@ struct GroupTable {
     const int* order; // launch order -> QP index (longest-first schedule of the previous launch of this shape), or null
     GroupArgs<TI> g[kMaxGroups];
 };
+
+static_assert(sizeof(GroupTable<double>) <= 4000, "the group table travels as a kernel argument: the kernarg segment is 4 KiB");
 
 // iteration counts of the launch just finished, for the schedule of the next one
 struct ScheduleArgs {

@@ -114,6 +114,13 @@ class Structure:
     hessian_reg: float = HESSIAN_REGULARIZATION
     max_iter: int = MAX_ITER
     kp: Dict[str, float] = field(default_factory=dict)  # task gains (only used by reference-stream generators)
+    # level-1 tasks that make H dense (registered by the reference's factory, in none of its shipped stacks):
+    # "torque" (tasks.cpp:227-271) rows scale_j [M_a(joint_j, :) | -J_a(:, joint_j)'] over the mask's ones, and
+    # "cop" (tasks.cpp:156-178) 3 rows over all force variables, given per QP (field Acop)
+    acteq_joint: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))  # [n_acteq] actuated joint in [0, na)
+    acteq_scale: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))  # [n_acteq] `scaling:` entry, 1 without
+    acteq_task: int = -1  # index into w
+    cop_task: int = -1  # index into w, -1: none
 
     # ---- sizes -------------------------------------------------------------------------
     @property
@@ -166,8 +173,21 @@ class Structure:
         return 2 * self.nin
 
     @property
+    def n_acteq(self) -> int:
+        return int(self.acteq_joint.size)
+
+    @property
+    def n_cop(self) -> int:
+        return 3 if self.cop_task >= 0 else 0
+
+    @property
+    def dense_h(self) -> bool:
+        """H is no longer block diagonal [dv | f_1 | f_2 ...]: the stack runs the full layout with a dense H (wbcqp_layout.dense_h)."""
+        return self.n_acteq > 0 or self.cop_task >= 0
+
+    @property
     def r1(self) -> int:
-        return self.n_dense + self.n_sel + 6 * self.nc
+        return self.n_dense + self.n_sel + 6 * self.nc + self.n_acteq + self.n_cop
 
     # ---- constant blocks ---------------------------------------------------------------
     def force_gen(self) -> np.ndarray:
@@ -196,6 +216,7 @@ class Structure:
             "tlb": self.na if self.act_bounds else 0,
             "tub": self.na if self.act_bounds else 0,
             "w": self.n_tasks,
+            "Acop": 3 * self.k if self.cop_task >= 0 else 0,
         }
 
     def flops_estimate(self, iters: float = 0.0) -> float:
@@ -209,6 +230,10 @@ class Structure:
         qr = 2.0 * n * m * m - 2.0 * m ** 3 / 3.0
         jq = 4.0 * n * n * m
         per_iter = 2.0 * (n * n + n * (n - m) + n * (n - m)) + 2.0 * self.na * n + 24.0 * 17 * 2 * self.nc
+        if self.dense_h:  # H assembled and eliminated as one n x n matrix
+            asm += (self.n_acteq + self.n_cop) * n * (n + 1)
+            elim = 4.0 * n ** 3 / 3.0
+            x0 = 2.0 * n * n
         return asm + elim + x0 + b + qr + jq + iters * per_iter
 
     def algorithmic_bytes(self, itemsize: int = 8) -> int:
@@ -326,6 +351,67 @@ def three_contact_structure(nv: int = 36, na: int = 30) -> Structure:
     return _mk("three_contact", nv, na, contacts, dense, None, [], True, True, level0)
 
 
+def with_torque_task(st: Structure, weight: float = 1.0, mask: Sequence[int] = None, scaling: Sequence[float] = None,
+                     name: str = "torque") -> Structure:
+    """The stack with a `type: torque` task added (tasks.cpp:227-271): mask over the na actuated joints (default all ones),
+    `scaling` = the task's weight vector (default ones), reference zero.  Appended to the level-1 list like a task at the end
+    of tasks.yaml."""
+    import dataclasses
+    if st.n_acteq:
+        raise ValueError("one torque task per stack")
+    m = np.ones(st.na, np.int64) if mask is None else np.asarray(mask, np.int64)
+    if m.size != st.na:
+        raise ValueError("wrong size in torque mask, expected:%d got:%d" % (st.na, m.size))
+    sc = np.ones(st.na) if scaling is None else np.asarray(scaling, np.float64)
+    if sc.size != st.na:
+        raise ValueError("wrong size in torque scaling, expected:%d got:%d" % (st.na, sc.size))
+    joints = np.where(m != 0)[0].astype(np.int32)
+    return dataclasses.replace(st, name=st.name + "+torque", task_names=st.task_names + [name],
+                               default_weights=np.append(st.default_weights, weight), acteq_joint=joints,
+                               acteq_scale=np.ascontiguousarray(sc[joints]), acteq_task=len(st.task_names))
+
+
+def with_cop_task(st: Structure, weight: float = 1.0, name: str = "cop") -> Structure:
+    """The stack with a `type: cop` task added (tasks.cpp:156-178): 3 rows over all contact-force variables."""
+    import dataclasses
+    if st.cop_task >= 0:
+        raise ValueError("one cop task per stack")
+    if st.nc == 0:
+        raise ValueError("a cop task needs a contact")
+    return dataclasses.replace(st, name=st.name + "+cop", task_names=st.task_names + [name],
+                               default_weights=np.append(st.default_weights, weight), cop_task=len(st.task_names))
+
+
+def with_posture_mask(st: Structure, mask: Sequence[int]) -> Structure:
+    """The stack with `mask:` on its posture task (tasks.cpp:205-214): one character per actuated joint, the selection rows
+    are the ones."""
+    import dataclasses
+    m = np.asarray(mask, np.int64)
+    if m.size != st.na:
+        raise ValueError("wrong size in posture mask, expected:%d got:%d" % (st.na, m.size))
+    if st.n_sel != st.na:
+        raise ValueError("the stack's posture task already carries a mask")
+    keep = m != 0
+    return dataclasses.replace(st, name=st.name + "+posture_mask", sel_col=np.ascontiguousarray(st.sel_col[keep]),
+                               sel_task=np.ascontiguousarray(st.sel_task[keep]))
+
+
+def cop_rows(st: Structure, placements: Sequence[Tuple[np.ndarray, np.ndarray]], cop_ref=(0.0, 0.0, 0.0),
+             normal=(0.0, 0.0, 1.0)) -> np.ndarray:
+    """3 x k matrix of tsid TaskCopEquality::compute [UPSTREAM-RECALL]: contact c's frame has placement (R, p) in the world,
+    its contact point i sits at p_w = R p_i + p; with d = p_w - cop_ref and the forces expressed in the contact frame, the moment of
+    the contact forces about the reference point has no component in the plane normal to n:
+    n x sum_i (d_i x R f_i) = sum_i (d_i n' - (n . d_i) I) R f_i = 0."""
+    n = np.asarray(normal, np.float64)
+    A = np.zeros((3, st.k))
+    for c, contact in enumerate(st.contacts):
+        R, p = placements[c]
+        for i in range(4):
+            d = R @ contact.points[:, i] + p - np.asarray(cop_ref, np.float64)
+            A[:, 12 * c + 3 * i:12 * c + 3 * i + 3] = (np.outer(d, n) - float(n @ d) * np.eye(3)) @ R
+    return A
+
+
 STRUCTURES = {
     "talos": talos_structure,
     "talos_single_support": lambda: talos_structure(single_support=True),
@@ -333,4 +419,9 @@ STRUCTURES = {
     "franka": franka_structure,
     "tiago": tiago_structure,
     "three_contact": three_contact_structure,
+    # the two task types of the factory no shipped stack uses (weights: a torque-minimisation term and a CoP term one would add)
+    "talos_torque": lambda: with_torque_task(talos_structure(), 1e-2),
+    "talos_cop": lambda: with_cop_task(talos_structure(), 10.0),
+    "talos_torque_cop": lambda: with_cop_task(with_torque_task(talos_structure(), 1e-2), 10.0),
+    "icub_torque": lambda: with_torque_task(icub_structure(), 1e-3),
 }

@@ -15,13 +15,14 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from .structure import Structure, contact6d_friction
+from .structure import Structure, contact6d_friction, cop_rows
 from .trajs import move_com_stream
 
-FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
+FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w", "Acop")
 
 SEED_BASE = {"franka": 1_000_000, "talos": 2_000_000, "icub": 3_000_000, "talos_squat": 4_000_000, "ragged": 5_000_000,
-             "tiago": 6_000_000, "talos_single_support": 7_000_000, "three_contact": 8_000_000}
+             "tiago": 6_000_000, "talos_single_support": 7_000_000, "three_contact": 8_000_000,
+             "talos_torque": 9_000_000, "talos_cop": 10_000_000, "talos_torque_cop": 11_000_000, "icub_torque": 12_000_000}
 
 
 def _spd_mass(rng, nv: int, nu: int) -> np.ndarray:
@@ -74,7 +75,7 @@ def _foot_jacobian(rng, c: int, nv: int, nu: int) -> np.ndarray:
 
 
 def generate_one(st: Structure, seed: int, p_act: float = 0.10, p_bnd: float = 0.05, task_noise: float = 0.5,
-                 com_ref: Optional[np.ndarray] = None, weight_jitter: float = 0.0) -> Dict[str, np.ndarray]:
+                 com_ref: Optional[np.ndarray] = None, weight_jitter: float = 0.0, torque_ref_noise: float = 0.0) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     nv, na, nu, nc = st.nv, st.na, st.nu, st.nc
     L = st.field_lengths()
@@ -146,13 +147,31 @@ def generate_one(st: Structure, seed: int, p_act: float = 0.10, p_bnd: float = 0
     if com_ref is not None and "com" in names:
         rows = np.where(st.dense_row_task == names.index("com"))[0]
         b1[rows] += com_ref[:rows.size]
+    # torque task (tasks.cpp:227-271): the reference torque is zero there (:262-263); `torque_ref_noise` exercises the general rhs
+    # S tau_ref.  cop task (tasks.cpp:156-178): rows from the contact frames' placements in the world, reference point (0, 0, 0), rhs 0.
+    # (drawn from a generator of their own so that the rest of the record is the plain stack's)
+    Acop = np.zeros(0)
+    if st.n_acteq or st.cop_task >= 0:
+        rng2 = np.random.default_rng(seed + 0x5eed)
+        o = st.n_dense + st.n_sel + 6 * nc
+        if st.n_acteq:
+            b1[o:o + st.n_acteq] = st.acteq_scale * torque_ref_noise * rng2.standard_normal(st.n_acteq)
+        if st.cop_task >= 0:
+            placements = []
+            for c in range(nc):
+                side = 1.0 if c % 2 == 0 else -1.0
+                wv = 0.05 * rng2.standard_normal(3)
+                Rq, _ = np.linalg.qr(np.eye(3) + _skew(wv))
+                Rq = Rq * np.sign(np.diag(Rq))
+                placements.append((Rq, np.array([rng2.uniform(-0.05, 0.05), side * rng2.uniform(0.07, 0.10), rng2.uniform(-0.01, 0.01)])))
+            Acop = cop_rows(st, placements).reshape(-1)
     w = st.default_weights.copy()
     if weight_jitter > 0.0:
         w = w * np.exp(rng.uniform(-weight_jitter, weight_jitter, w.size))
 
     iu = np.tril_indices(nv)
     out = dict(M=M[iu], h=h, A=A.reshape(-1), b1=b1, Ac=Ac.reshape(-1), bc=bc.reshape(-1),
-               blb=blb, bub=bub, tlb=tlb, tub=tub, w=w)
+               blb=blb, bub=bub, tlb=tlb, tub=tub, w=w, Acop=Acop)
     for k_ in FIELDS:
         assert out[k_].size == L[k_], (k_, out[k_].size, L[k_])
     out["_dv_star"] = dv

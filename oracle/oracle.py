@@ -34,11 +34,12 @@ class _Structure(C.Structure):
         ("act_bounds", C.c_int),
         ("n_ineq_blocks", C.c_int), ("ineq_kind", c_int_p), ("ineq_arg", c_int_p),
         ("hessian_reg", C.c_double), ("max_iter", C.c_int),
+        ("n_acteq", C.c_int), ("acteq_joint", c_int_p), ("acteq_scale", c_double_p), ("acteq_task", C.c_int), ("cop_task", C.c_int),
     ]
 
 
 class _Inputs(C.Structure):
-    _fields_ = [(k, c_double_p) for k in ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")]
+    _fields_ = [(k, c_double_p) for k in ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w", "Acop")]
 
 
 class _Outputs(C.Structure):
@@ -47,7 +48,7 @@ class _Outputs(C.Structure):
 
 
 class _BatchInputs(C.Structure):
-    _fields_ = [(k, c_double_p) for k in ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")]
+    _fields_ = [(k, c_double_p) for k in ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w", "Acop")]
 
 
 class _BatchOutputs(C.Structure):
@@ -134,16 +135,24 @@ class OracleStructure:
         s.ineq_arg = _ip(args)
         s.hessian_reg = st.hessian_reg
         s.max_iter = st.max_iter
+        s.n_acteq = st.n_acteq
+        s.acteq_joint = _ip(keep(st.acteq_joint if st.n_acteq else [0], np.int32))
+        s.acteq_scale = _dp(keep(st.acteq_scale if st.n_acteq else [1.0], np.float64))
+        s.acteq_task = int(st.acteq_task)
+        s.cop_task = int(st.cop_task)
         self.c = s
 
 
-_FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w")
+_FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w", "Acop")
 
 
 def _prep_inputs(st, inputs: Dict[str, np.ndarray], batch: int):
     lens = st.field_lengths()
     arrs = {}
     for k in _FIELDS:
+        if lens[k] == 0 and k not in inputs:  # (records written before a field existed: Acop)
+            arrs[k] = np.zeros((batch, 1))
+            continue
         a = np.ascontiguousarray(inputs[k], dtype=np.float64).reshape(batch, -1)
         assert a.shape[1] == lens[k], (k, a.shape, lens[k])
         if a.size == 0:

@@ -32,7 +32,7 @@ void wbco_sizes(const wbco_structure* st, int* n, int* neq, int* nin2, int* r1)
     if (n) *n = st->nv + k;
     if (neq) *neq = nu + 6 * st->nc;
     if (nin2) *nin2 = 2 * nin;
-    if (r1) *r1 = st->n_dense + st->n_sel + 6 * st->nc;
+    if (r1) *r1 = st->n_dense + st->n_sel + 6 * st->nc + st->n_acteq + (st->cop_task >= 0 ? 3 : 0);
 }
 
 /* M(i,j) from the packed lower triangle */
@@ -192,6 +192,40 @@ static void wbco_assemble_ws(const wbco_structure* st, const wbco_inputs* in,
                 double s = 0.0;
                 for (int q = 0; q < 6; ++q) s += F[IDX(q, a, 12)] * F[IDX(q, bb, 12)];
                 H[IDX(nv + 12 * c + a, nv + 12 * c + bb, n)] += w * s;
+            }
+        }
+    }
+    /* actuation task ("torque", tasks.cpp:227-271; tsid TaskActuationEquality through computeProblemData's actuation-task
+     * branch): A = S [M_a | -J_a'], b = S tau_ref - S h_a, S(j, joint_j) = scale_j */
+    if (st->n_acteq > 0) {
+        const double w = in->w[st->acteq_task];
+        const double* bt = in->b1 + st->n_dense + st->n_sel + 6 * nc;
+        memset(Ht, 0, sizeof(double) * (size_t)n * n);
+        memset(gt, 0, sizeof(double) * (size_t)n);
+        for (int j = 0; j < st->n_acteq; ++j) {
+            const int a = st->acteq_joint[j];
+            const double sc = st->acteq_scale[j];
+            for (int c = 0; c < nv; ++c) Arow[c] = sc * Msym(in->M, nu + a, c);
+            for (int m = 0; m < k; ++m) Arow[nv + m] = -sc * Jc[IDX(m, nu + a, nv)];
+            const double b = bt[j] - sc * in->h[nu + a];
+            for (int i = 0; i < n; ++i) {
+                for (int c = 0; c < n; ++c) Ht[IDX(i, c, n)] += Arow[i] * Arow[c];
+                gt[i] += Arow[i] * b;
+            }
+        }
+        for (int i = 0; i < n * n; ++i) H[i] += w * Ht[i];
+        for (int i = 0; i < n; ++i) g[i] -= w * gt[i];
+    }
+    /* force task ("cop", tasks.cpp:156-178; tsid TaskCopEquality is associated with no single contact, so its 3 x k matrix
+     * lands in columns nv .. nv + k: computeProblemData's m_taskContactForces loop) */
+    if (st->cop_task >= 0 && k > 0) {
+        const double w = in->w[st->cop_task];
+        const double* bcop = in->b1 + st->n_dense + st->n_sel + 6 * nc + st->n_acteq;
+        for (int r3 = 0; r3 < 3; ++r3) {
+            const double* a = in->Acop + (size_t)r3 * k;
+            for (int i = 0; i < k; ++i) {
+                for (int c = 0; c < k; ++c) H[IDX(nv + i, nv + c, n)] += w * a[i] * a[c];
+                g[nv + i] -= w * a[i] * bcop[r3];
             }
         }
     }
@@ -720,6 +754,7 @@ static void* batch_worker(void* arg)
             in.tlb = job->in->tlb + (size_t)i * na;
             in.tub = job->in->tub + (size_t)i * na;
             in.w = job->in->w + (size_t)i * st->n_tasks;
+            in.Acop = (st->cop_task >= 0 && job->in->Acop) ? job->in->Acop + (size_t)i * 36 * nc : NULL;
             wbco_outputs out;
             out.x = first ? job->out->x + (size_t)i * n : sx;
             out.tau = first ? job->out->tau + (size_t)i * na : stau;

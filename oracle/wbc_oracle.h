@@ -71,6 +71,20 @@ typedef struct {
     const int* ineq_arg;       /* [n_ineq_blocks] contact index for FORCE, else 0 */
     double hessian_reg;        /* tsid DEFAULT_HESSIAN_REGULARIZATION = 1e-8 */
     int max_iter;              /* eiquadprog-fast DEFAULT_MAX_ITER = 1000 */
+    /* level-1 tasks that couple the acceleration and force blocks of H (unused in the shipped stacks, registered by the
+     * factory all the same):
+     *  "torque" (tasks.cpp:227-271): tsid TaskActuationEquality [UPSTREAM-RECALL] -- constraint S tau = S tau_ref with
+     *      S(j, joint_j) = weight(joint_j) over the mask's ones (task-actuation-equality.cpp: mask(), compute());
+     *      the formulation turns it into rows S [M_a | -J_a'] with vector S tau_ref - S h_a;
+     *  "cop" (tasks.cpp:156-178): tsid TaskCopEquality [UPSTREAM-RECALL] -- 3 rows over ALL contact forces (its
+     *      getAssociatedContactName() is empty: computeProblemData maps it to columns nv .. nv + k), per contact point
+     *      (d n' - (n.d) I) R with d = p_world - cop_ref, vector 0: n x (sum_i (p_i - c) x f_i) = 0.  The rows depend on
+     *      the contact frames' placements: a per-QP input (Acop). */
+    int n_acteq;               /* rows of the torque task (ones of its mask), 0: none */
+    const int* acteq_joint;    /* [n_acteq] actuated joint in [0, na) */
+    const double* acteq_scale; /* [n_acteq] weight-vector entry of that joint (`scaling:`), 1 without */
+    int acteq_task;            /* -> index into w */
+    int cop_task;              /* -> index into w, -1: no cop task */
 } wbco_structure;
 
 /* Per-QP inputs: outputs of "the step before the path" (pinocchio + task.compute()). */
@@ -78,7 +92,8 @@ typedef struct {
     const double* M;      /* [nv(nv+1)/2] joint-space inertia, packed lower triangle, row-major */
     const double* h;      /* [nv] non-linear effects */
     const double* A;      /* [n_dense][nv] dense level-1 rows */
-    const double* b1;     /* [n_dense + n_sel + 6*nc] all level-1 rhs (dense | selection | force-reg) */
+    const double* b1;     /* [n_dense + n_sel + 6*nc + n_acteq + 3 (cop)] all level-1 rhs
+                             (dense | selection | force-reg | torque: S tau_ref | cop: 0) */
     const double* Ac;     /* [nc][6][nv] contact motion-task matrices (local frame) */
     const double* bc;     /* [nc][6] contact motion-task rhs */
     const double* blb;    /* [n_bound] acceleration lower bounds */
@@ -86,6 +101,7 @@ typedef struct {
     const double* tlb;    /* [na] torque lower bounds (before the -h_a shift) */
     const double* tub;    /* [na] */
     const double* w;      /* [n_tasks] level-1 task weights */
+    const double* Acop;   /* [3][12 nc] rows of the cop task over the force variables (cop_task >= 0), else unused */
 } wbco_inputs;
 
 typedef struct {
@@ -125,7 +141,7 @@ int wbco_tick(const wbco_structure* st, const wbco_inputs* in, wbco_outputs* out
 /* Batched driver over contiguous [B][len] arrays, nthreads pthreads (one QP per work item,
  * in the style of qp_timer_test.cpp:55-63 / utest.hpp:62-96). Returns 0. */
 typedef struct {
-    const double *M, *h, *A, *b1, *Ac, *bc, *blb, *bub, *tlb, *tub, *w;
+    const double *M, *h, *A, *b1, *Ac, *bc, *blb, *bub, *tlb, *tub, *w, *Acop;
 } wbco_batch_inputs;
 typedef struct {
     double *x, *tau;
