@@ -27,7 +27,7 @@ EXPORTS = ("wbcqp_version", "wbcqp_last_error", "wbcqp_create", "wbcqp_destroy",
            "wbcqp_allgather_tau", "wbcqp_integrate", "wbcqp_integrate_host", "wbcqp_set_model", "wbcqp_check_model", "wbcqp_problem_data",
            "wbcqp_problem_data_host", "wbcqp_tick", "wbcqp_tick_host", "wbcqp_tick_graph_create", "wbcqp_tick_graph_launch", "wbcqp_tick_graph_destroy",
            "wbcqp_sync", "wbcqp_launch_order", "wbcqp_solve_dense", "wbcqp_solve_dense_host", "wbcqp_rollout")
-ROW_FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub")  # what wbcqp_problem_data writes
+ROW_FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "Acop")  # what wbcqp_problem_data writes (Acop: stacks with a cop task)
 
 c_i32_p = C.POINTER(C.c_int32)
 c_f64_p = C.POINTER(C.c_double)

@@ -49,7 +49,7 @@ namespace inria_wbc {
         // Per-tick inputs of the path for B instances, laid out exactly as wbcqp_inputs wants them ([B][len], row-major).
         struct TickInputs {
             int batch = 0;
-            std::vector<double> M, h, A, b1, Ac, bc, blb, bub, tlb, tub, w;
+            std::vector<double> M, h, A, b1, Ac, bc, blb, bub, tlb, tub, w, Acop;
             // sizes the arrays for B instances; contents are left alone when nothing changed (every tick overwrites what it uses)
             void resize(int B, const wbcqp_layout& L)
             {
@@ -58,7 +58,7 @@ namespace inria_wbc {
                     if (a.size() != (size_t)B * len) a.assign((size_t)B * len, 0.0);
                 };
                 fit(M, L.len_M); fit(h, L.len_h); fit(A, L.len_A); fit(b1, L.len_b1); fit(Ac, L.len_Ac); fit(bc, L.len_bc);
-                fit(blb, L.len_blb); fit(bub, L.len_bub); fit(tlb, L.len_tlb); fit(tub, L.len_tub); fit(w, L.len_w);
+                fit(blb, L.len_blb); fit(bub, L.len_bub); fit(tlb, L.len_tlb); fit(tub, L.len_tub); fit(w, L.len_w); fit(Acop, L.len_Acop);
             }
         };
 
@@ -278,7 +278,7 @@ namespace inria_wbc {
                 iters_.assign(B, 0);
                 objective_.assign(B, 0.0);
                 wbcqp_inputs in = {in_.M.data(), in_.h.data(), in_.A.data(), in_.b1.data(), in_.Ac.data(), in_.bc.data(),
-                                   in_.blb.data(), in_.bub.data(), in_.tlb.data(), in_.tub.data(), in_.w.data()};
+                                   in_.blb.data(), in_.bub.data(), in_.tlb.data(), in_.tub.data(), in_.w.data(), in_.Acop.data()};
                 wbcqp_outputs out = {x_.data(), tau_.data.data(), status_.data(), iters_.data(), objective_.data(), nullptr};
                 IWBC_ASSERT(q.cols == (floating_base_ ? nv + 1 : nv), "q must hold ", floating_base_ ? nv + 1 : nv, " entries per instance");
                 q_tsid_prev_ = q; // controller.cpp:237-241 (the reference keeps them when send_cmd_ is set; qp_step_back() returns here)
@@ -295,7 +295,7 @@ namespace inria_wbc {
                     wbcqp_tick_io io{};
                     io.state = {q.data.data(), dq.data.data(), source_->reference_data(), mom6.data()};
                     io.rows = in;
-                    io.rows.M = io.rows.h = io.rows.A = io.rows.b1 = io.rows.Ac = io.rows.bc = io.rows.blb = io.rows.bub = nullptr;
+                    io.rows.M = io.rows.h = io.rows.A = io.rows.b1 = io.rows.Ac = io.rows.bc = io.rows.blb = io.rows.bub = io.rows.Acop = nullptr;
                     last_q_ = q;
                     last_v_ = dq;
                     rows_valid_ = false;

@@ -115,7 +115,8 @@ namespace inria_wbc {
                         continue;
                     }
                     else if (type == "bounds") { bounds = true; continue; }
-                    else continue; // actuation-bounds: constant limits
+                    else continue; // actuation-bounds: constant limits; torque / cop: the rows are the structure's (task_stack.hpp), the
+                                   // cop rows come out of the rows kernel with the contact frames, the torque reference is zero (tasks.cpp:263)
                     av_begin.push_back(begin);
                     tasks_.push_back(t);
                     names_.push_back(kv.first);
@@ -204,7 +205,7 @@ namespace inria_wbc {
                 wbcqp_state st = {q.data.data(), v.data.data(), ref_.data()};
                 wbcqp_inputs rows{};
                 rows.M = in.M.data(); rows.h = in.h.data(); rows.A = in.A.data(); rows.b1 = in.b1.data(); rows.Ac = in.Ac.data();
-                rows.bc = in.bc.data(); rows.blb = in.blb.data(); rows.bub = in.bub.data();
+                rows.bc = in.bc.data(); rows.blb = in.blb.data(); rows.bub = in.bub.data(); rows.Acop = in.Acop.data();
                 if (wbcqp_problem_data_host(handle_, slot_, batch_, &st, &rows) != WBCQP_OK)
                     IWBC_ERROR("wbcqp_problem_data_host failed: ", wbcqp_last_error(handle_));
                 fill_limits(L, in);

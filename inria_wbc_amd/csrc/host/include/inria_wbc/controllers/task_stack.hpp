@@ -64,7 +64,9 @@ namespace inria_wbc {
             int n_dense() const { return (int)dense_row_task_.size(); }
             int n_sel() const { return (int)sel_col_.size(); }
             int n_tasks() const { return (int)weights_.size(); }
-            int level1_rows() const { return n_dense() + n_sel() + 6 * nc(); }
+            int n_acteq() const { return (int)acteq_joint_.size(); }
+            bool has_cop() const { return cop_task_ >= 0; }
+            int level1_rows() const { return n_dense() + n_sel() + 6 * nc() + n_acteq() + (has_cop() ? 3 : 0); }
             bool has_task(const std::string& name) const
             {
                 for (const auto& t : tasks_)
@@ -114,6 +116,8 @@ namespace inria_wbc {
                 s.n_ineq_blocks = (int)ineq_kind_.size(); s.ineq_kind = ineq_kind_.data(); s.ineq_arg = ineq_arg_.data();
                 s.hessian_reg = 1e-8; // tsid DEFAULT_HESSIAN_REGULARIZATION
                 s.max_iter = 1000;    // eiquadprog-fast DEFAULT_MAX_ITER
+                s.n_acteq = n_acteq(); s.acteq_joint = acteq_joint_.data(); s.acteq_scale = acteq_scale_.data();
+                s.acteq_task = acteq_task_; s.cop_task = cop_task_;
                 return s;
             }
 
@@ -128,6 +132,7 @@ namespace inria_wbc {
                     const std::string& name = kv.first;
                     const yaml::Node& node = kv.second;
                     const auto type = IWBC_CHECK(node["type"].as<std::string>());
+                    check_keys(name, type, node);
                     TaskSpec t;
                     t.name = name;
                     t.type = type;
@@ -153,15 +158,49 @@ namespace inria_wbc {
                         add_dense(t);
                     }
                     else if (type == "posture") {
-                        t.rows = na_;
+                        // tasks.cpp:205-214: without `mask:` every actuated joint, with it one character per actuated joint
+                        t.mask = node["mask"] ? IWBC_CHECK(node["mask"].as<std::string>()) : std::string((size_t)na_, '1');
+                        IWBC_ASSERT((int)t.mask.size() == na_, "wrong size in posture mask, expected:", na_, " got:", t.mask.size());
+                        t.rows = mask_rows(t.mask, (size_t)na_, name);
                         t.weight_index = (int)weights_.size();
                         t.first_row = (int)sel_col_.size();
                         weights_.push_back(t.weight);
                         weight_names_.push_back(name);
-                        for (int j = 0; j < na_; ++j) {
-                            sel_col_.push_back(nv_ - na_ + j);
-                            sel_task_.push_back(t.weight_index);
+                        for (int j = 0; j < na_; ++j)
+                            if (t.mask[j] == '1') {
+                                sel_col_.push_back(nv_ - na_ + j);
+                                sel_task_.push_back(t.weight_index);
+                            }
+                    }
+                    else if (type == "torque") {
+                        // tasks.cpp:227-271: tsid TaskActuationEquality, mask over the actuated joints (default all), `scaling:` = its
+                        // weight vector (default ones), reference zero, level 1.  Rows scale_j [M_a(j,:) | -J_a(:,j)']: H becomes one
+                        // n x n matrix (wbcqp_layout.dense_h)
+                        IWBC_ASSERT(acteq_task_ < 0, "one torque task per stack (task ", name, " is the second)");
+                        t.mask = node["mask"] ? IWBC_CHECK(node["mask"].as<std::string>()) : std::string((size_t)na_, '1');
+                        IWBC_ASSERT((int)t.mask.size() == na_, "wrong size in torque mask, expected:", na_, " got:", t.mask.size());
+                        std::vector<double> scaling((size_t)na_, 1.0);
+                        if (node["scaling"]) {
+                            scaling = IWBC_CHECK(node["scaling"].as<std::vector<double>>());
+                            IWBC_ASSERT((int)scaling.size() == na_, "wrong size in torque scaling, expected:", na_, " got:", scaling.size());
                         }
+                        t.rows = mask_rows(t.mask, (size_t)na_, name);
+                        t.weight_index = acteq_task_ = (int)weights_.size();
+                        weights_.push_back(t.weight);
+                        weight_names_.push_back(name);
+                        for (int j = 0; j < na_; ++j)
+                            if (t.mask[j] == '1') {
+                                acteq_joint_.push_back(j);
+                                acteq_scale_.push_back(scaling[j]);
+                            }
+                    }
+                    else if (type == "cop") {
+                        // tasks.cpp:156-178: tsid TaskCopEquality with reference (0, 0, 0), a force task on level 1 over all contact forces
+                        IWBC_ASSERT(cop_task_ < 0, "one cop task per stack (task ", name, " is the second)");
+                        t.rows = 3;
+                        t.weight_index = cop_task_ = (int)weights_.size();
+                        weights_.push_back(t.weight);
+                        weight_names_.push_back(name);
                     }
                     else if (type == "bounds") {
                         for (int j = 0; j < na_; ++j) bound_col_.push_back(nv_ - na_ + j);
@@ -174,9 +213,35 @@ namespace inria_wbc {
                         ineq_arg_.push_back(0);
                     }
                     else
-                        IWBC_ERROR("task type [", type, "] of task ", name, " is not handled by the batched path (known: se3, com, momentum, "
-                                   "posture, bounds, actuation-bounds, self-collision, contact)");
+                        IWBC_ERROR("task type [", type, "] of task ", name, " is not registered (known: se3, com, momentum, cop, posture, torque, "
+                                   "bounds, actuation-bounds, self-collision, contact: the reference's factory, tasks.cpp:85-404)");
                     tasks_.push_back(t);
+                }
+                IWBC_ASSERT(cop_task_ < 0 || !contacts_.empty(), "a cop task needs a contact");
+            }
+
+            // A key the factory of that type does not read is a typo in the stack, not a setting: the reference's yaml-cpp lookups
+            // would ignore it silently and solve another QP than the file describes; here it raises.
+            static void check_keys(const std::string& name, const std::string& type, const yaml::Node& node)
+            {
+                static const std::vector<std::pair<std::string, std::vector<std::string>>> known = {
+                    {"se3", {"type", "tracked", "weight", "kp", "kd", "mask"}},
+                    {"com", {"type", "weight", "kp", "kd", "mask"}},
+                    {"momentum", {"type", "weight", "kp", "kd", "mask"}},
+                    {"cop", {"type", "weight"}},
+                    {"posture", {"type", "weight", "kp", "kd", "ref", "mask"}},
+                    {"torque", {"type", "weight", "mask", "scaling"}},
+                    {"bounds", {"type", "weight"}},
+                    {"actuation-bounds", {"type", "weight"}},
+                    {"self-collision", {"type", "tracked", "weight", "kp", "kd", "radius", "margin", "m", "avoided"}},
+                    {"contact", {"type", "joint", "kp", "kd", "lxp", "lxn", "lyp", "lyn", "lz", "mu", "normal", "fmin", "fmax"}}};
+                for (const auto& k : known) {
+                    if (k.first != type) continue;
+                    for (const auto& kv : node) {
+                        bool ok = false;
+                        for (const auto& key : k.second) ok = ok || key == kv.first;
+                        if (!ok) IWBC_ERROR("task ", name, " (type ", type, "): unknown key [", kv.first, "]");
+                    }
                 }
             }
 
@@ -262,6 +327,9 @@ namespace inria_wbc {
 
             int nv_ = 0, na_ = 0;
             bool act_bounds_ = false;
+            int acteq_task_ = -1, cop_task_ = -1;
+            std::vector<int32_t> acteq_joint_;
+            std::vector<double> acteq_scale_;
             yaml::Node source_;
             std::vector<TaskSpec> tasks_;
             std::vector<ContactSpec> contacts_;

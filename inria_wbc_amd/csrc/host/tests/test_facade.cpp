@@ -56,8 +56,43 @@ int main(int argc, char** argv)
         UTEST_CHECK(ss.nVar() == 62 && ss.nEq() == 12 && ss.nIn() == 105 && ss.level1_rows() == 91);
         UTEST_CHECK_EXCEPTION(st.task("nope"), "not found");
     }
-    // ---- unknown task type is refused with its name ----
-    UTEST_CHECK_EXCEPTION(tasks::TaskStack(yaml::Load("t:\n  type: cop\n  weight: 1\n"), 9, 9), "not handled");
+    // ---- the task types no shipped stack uses (tasks.cpp:156-178 cop, :227-271 torque) and the posture mask (:205-214) ----
+    {
+        yaml::Node tasks = yaml::LoadFile(cfg + "/talos/tasks.yaml");
+        std::string mask(44, '1'), pmask(44, '1');
+        for (int j = 12; j < 44; ++j) mask[j] = '0'; // the legs' torques only
+        pmask[3] = pmask[40] = '0';
+        yaml::Node tq = yaml::Load("type: torque\nweight: 0.01\nmask: " + mask + "\n");
+        yaml::Node cop = yaml::Load("type: cop\nweight: 10.0\n");
+        tasks.set("torque", tq);
+        tasks.set("cop", cop);
+        yaml::Node post = tasks["posture"];
+        post.set("mask", pmask);
+        tasks.set("posture", post);
+        tasks::TaskStack st(tasks, 50, 44);
+        // tsid's nVar / nEq / nIn do not move (level-1 tasks); level-1 rows: 97 - 2 (posture mask) + 12 (torque) + 3 (cop)
+        UTEST_CHECK(st.nVar() == 74 && st.nEq() == 18 && st.nIn() == 122 && st.n_acteq() == 12 && st.has_cop() && st.n_sel() == 42);
+        UTEST_CHECK(st.level1_rows() == 97 - 2 + 12 + 3 && st.task("torque").rows == 12 && st.task("cop").rows == 3);
+        wbcqp_structure s = st.c_struct();
+        wbcqp_layout L;
+        UTEST_CHECK(wbcqp_layout_of(&s, &L) == WBCQP_OK);
+        UTEST_CHECK(L.r1 == st.level1_rows() && L.len_b1 == L.r1 && L.dense_h == 1 && L.len_Acop == 72 && L.waves_per_cu == 1);
+        UTEST_CHECK(s.acteq_joint[11] == 11 && s.acteq_scale[0] == 1.0 && s.cop_task == st.task("cop").weight_index);
+        // scaling: one entry per actuated joint
+        yaml::Node tq2 = yaml::Load("type: torque\nweight: 1\nscaling: [1, 2, 3]\n");
+        yaml::Node t2 = yaml::LoadFile(cfg + "/talos/tasks.yaml");
+        t2.set("torque", tq2);
+        UTEST_CHECK_EXCEPTION(tasks::TaskStack(t2, 50, 44), "wrong size in torque scaling");
+        post.set("mask", "101");
+        t2 = yaml::LoadFile(cfg + "/talos/tasks.yaml");
+        t2.set("posture", post);
+        UTEST_CHECK_EXCEPTION(tasks::TaskStack(t2, 50, 44), "wrong size in posture mask");
+    }
+    // a cop task without a contact, a second torque task, an unknown type and an unknown KEY are refused with the task's name
+    UTEST_CHECK_EXCEPTION(tasks::TaskStack(yaml::Load("t:\n  type: cop\n  weight: 1\n"), 9, 9), "needs a contact");
+    UTEST_CHECK_EXCEPTION(tasks::TaskStack(yaml::Load("a:\n  type: torque\n  weight: 1\nb:\n  type: torque\n  weight: 1\n"), 9, 9), "one torque task");
+    UTEST_CHECK_EXCEPTION(tasks::TaskStack(yaml::Load("t:\n  type: banana\n  weight: 1\n"), 9, 9), "is not registered");
+    UTEST_CHECK_EXCEPTION(tasks::TaskStack(yaml::Load("t:\n  type: posture\n  weight: 1\n  kp: 10\n  ref: x\n  maskk: 111111111\n"), 9, 9), "unknown key [maskk]");
     UTEST_CHECK_EXCEPTION(tasks::TaskStack(yaml::Load("t:\n  type: se3\n  weight: 1\n  mask: 11\n"), 9, 9), "mask");
     // ---- yaml subset ----
     {

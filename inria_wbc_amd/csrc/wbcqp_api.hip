@@ -36,6 +36,8 @@ struct Slot {
     wbcqp_layout layout{};      // what wbcqp_layout_of reports: the compact layout where the structure is eligible
     int lds_full = 0, lds_cp = 0;
     bool small = false;         // eligible for the one-wavefront-per-QP kernel (wbcqp_small.hpp)
+    std::vector<int> sel_col_h;       // host copies of what wbcqp_set_model needs of the structure: the posture task's columns
+    std::vector<double> force_gen_h;  // and the contacts' force generators (the contact points sit in their skew blocks)
     bool has_model = false;     // wbcqp_set_model: tree + task bindings for wbcqp_problem_data
     TermsDev terms{};
     std::vector<void*> model_allocs;
@@ -660,6 +662,8 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     }
 #undef UP
     s.host = D;
+    s.sel_col_h.assign(st->sel_col, st->sel_col + D.n_sel);
+    s.force_gen_h.assign(st->force_gen, st->force_gen + (size_t)nc * 72);
     s.lds_full = D.lds_doubles * 8;
     s.lds_cp = 0;
     s.host_cp = DevStruct{};
@@ -1073,8 +1077,9 @@ int wbcqp_integrate_host(wbcqp_handle* h, int batch, int nv, int floating_base, 
 
 // Validates a tree + task bindings against a structure and derives the rows kernel's tables and LDS layout.  Pure host code
 // (wbcqp_check_model runs it without a device; wbcqp_set_model uploads what it returns).
-static int derive_terms(wbcqp_handle* h, const DevStruct& D, const wbcqp_model* md, const wbcqp_taskmap* tm, TermsDev& T,
-                        std::vector<int>& ipool, std::vector<double>& dpool)
+// sel_host [D.n_sel]: the posture task's columns; force_gen_host [D.nc][6][12]: the contacts' force generators (host copies)
+static int derive_terms(wbcqp_handle* h, const DevStruct& D, const int* sel_host, const double* force_gen_host, const wbcqp_model* md,
+                        const wbcqp_taskmap* tm, TermsDev& T, std::vector<int>& ipool, std::vector<double>& dpool)
 {
     if (!md || !tm) return fail(h, WBCQP_ERR_INVALID, "model / taskmap is NULL");
     const int nb = md->nbody, fb = md->floating_base ? 1 : 0;
@@ -1199,11 +1204,24 @@ static int derive_terms(wbcqp_handle* h, const DevStruct& D, const wbcqp_model* 
     dpool.clear();
     auto puti = [&](const int* a, size_t n) { int at = (int)ipool.size(); ipool.insert(ipool.end(), a, a + n); ipool.push_back(0); return at; };
     auto putd = [&](const double* a, size_t n) { int at = (int)dpool.size(); dpool.insert(dpool.end(), a, a + n); dpool.push_back(0.0); return at; };
+    // the posture task's columns: the actuated joints its mask keeps (tasks.cpp:197-217), from the structure
     std::vector<int> sel(D.n_sel);
-    // the structure's selection columns live on the device already; the host copy comes from the posture convention
-    // (tasks.cpp:197-217: the actuated joints, in order) -- checked against n_sel
-    if (D.n_sel != 0 && D.n_sel != na) return fail(h, WBCQP_ERR_UNSUPPORTED, "a posture task over a subset of the actuated joints");
-    for (int r = 0; r < D.n_sel; ++r) sel[r] = nv - na + r;
+    for (int r = 0; r < D.n_sel; ++r) {
+        sel[r] = sel_host[r];
+        if (sel[r] < nv - na || sel[r] >= nv) return fail(h, WBCQP_ERR_INVALID, "a posture row selects a column that is not an actuated joint");
+    }
+    // cop task (tasks.cpp:156-178): the rows kernel forms its three rows from the contact frames; the contact points are the skew
+    // blocks of the force generators, T(3.., 3 p ..) = skew(p): x = T(5, 3p + 1), y = T(3, 3p + 2), z = T(4, 3p)
+    std::vector<double> cop_pts;
+    T.cop = D.cop_task >= 0 ? 1 : 0;
+    if (T.cop)
+        for (int c = 0; c < D.nc; ++c)
+            for (int p = 0; p < 4; ++p) {
+                const double* Tg = force_gen_host + (size_t)c * 72;
+                cop_pts.push_back(Tg[5 * 12 + 3 * p + 1]);
+                cop_pts.push_back(Tg[3 * 12 + 3 * p + 2]);
+                cop_pts.push_back(Tg[4 * 12 + 3 * p]);
+            }
     T.i_jtype = puti(md->jtype, nb); T.i_last = puti(last.data(), nb);
     T.i_anc = puti(anc.data(), (size_t)nrounds * nb);
     T.i_idxq = puti(idxq.data(), nb); T.i_idxv = puti(idxv.data(), nb); T.i_bodyof = puti(bodyof.data(), nv); T.i_kof = puti(kof.data(), nv);
@@ -1224,6 +1242,7 @@ static int derive_terms(wbcqp_handle* h, const DevStruct& D, const wbcqp_model* 
     T.d_scf_place = putd(scf_place.data(), scf_place.size());
     T.d_pair_par = putd(pair_par.data(), pair_par.size());
     T.d_blk_kp = putd(blk_kp.data(), blk_kp.size()); T.d_blk_kd = putd(blk_kd.data(), blk_kd.size());
+    T.d_cop_pts = putd(cop_pts.data(), cop_pts.size());
     T.d_qlb = putd(md->q_lb, D.n_bound ? na : 0); T.d_qub = putd(md->q_ub, D.n_bound ? na : 0); T.d_dqmax = putd(md->dq_max, D.n_bound ? na : 0);
     int o = 0;
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; };
@@ -1253,7 +1272,8 @@ int wbcqp_check_model(const wbcqp_structure* st, const wbcqp_model* md, const wb
     TermsDev T{};
     std::vector<int> ipool;
     std::vector<double> dpool;
-    rc = derive_terms(nullptr, D, md, tm, T, ipool, dpool);
+    if ((D.n_sel > 0 && !st->sel_col) || (D.nc > 0 && !st->force_gen)) return fail(nullptr, WBCQP_ERR_INVALID, "sel_col / force_gen is NULL");
+    rc = derive_terms(nullptr, D, st->sel_col, st->force_gen, md, tm, T, ipool, dpool);
     if (rc == WBCQP_OK && lds_bytes) *lds_bytes = T.lds_doubles * 8;
     return rc;
 }
@@ -1266,7 +1286,7 @@ int wbcqp_set_model(wbcqp_handle* h, int slot, const wbcqp_model* md, const wbcq
     TermsDev T{};
     std::vector<int> ipool;
     std::vector<double> dpool;
-    int rc = derive_terms(h, s.host, md, tm, T, ipool, dpool);
+    int rc = derive_terms(h, s.host, s.sel_col_h.data(), s.force_gen_h.data(), md, tm, T, ipool, dpool);
     if (rc != WBCQP_OK) return rc;
     const int o = T.lds_doubles;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1300,8 +1320,8 @@ int wbcqp_problem_data(wbcqp_handle* h, int slot, int batch, const wbcqp_state* 
     const wbcqp_layout& L = s.layout;
     if (!st || !rows || !st->q || !st->v || (s.terms.nref > 0 && !st->ref)) return fail(h, WBCQP_ERR_INVALID, "state arrays q / v / ref are required");
     if (!rows->M || !rows->h || (L.len_A && !rows->A) || (L.len_b1 && !rows->b1) || (L.len_Ac && !rows->Ac) || (L.len_bc && !rows->bc) ||
-        (L.len_blb && (!rows->blb || !rows->bub)))
-        return fail(h, WBCQP_ERR_INVALID, "row arrays M, h, A, b1, Ac, bc, blb, bub are required");
+        (L.len_blb && (!rows->blb || !rows->bub)) || (L.len_Acop && !rows->Acop))
+        return fail(h, WBCQP_ERR_INVALID, "row arrays M, h, A, b1, Ac, bc, blb, bub (Acop with a cop task) are required");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t sm = static_cast<hipStream_t>(stream);
     const int lds = s.terms.lds_doubles * 8;
@@ -1310,7 +1330,7 @@ int wbcqp_problem_data(wbcqp_handle* h, int slot, int batch, const wbcqp_state* 
         a.T = s.terms; a.batch = batch; a.dbg = h->dbg;
         a.q = static_cast<const double*>(st->q); a.v = static_cast<const double*>(st->v); a.ref = static_cast<const double*>(st->ref);
         a.M = (double*)rows->M; a.h = (double*)rows->h; a.A = (double*)rows->A; a.b1 = (double*)rows->b1; a.Ac = (double*)rows->Ac;
-        a.bc = (double*)rows->bc; a.blb = (double*)rows->blb; a.bub = (double*)rows->bub;
+        a.bc = (double*)rows->bc; a.blb = (double*)rows->blb; a.bub = (double*)rows->bub; a.Acop = (double*)rows->Acop;
         a.momentum = static_cast<double*>(st->momentum);
         hipLaunchKernelGGL(terms_kernel<double>, dim3(batch), dim3(kTermsThreads), lds, sm, a);
     }
@@ -1319,7 +1339,7 @@ int wbcqp_problem_data(wbcqp_handle* h, int slot, int batch, const wbcqp_state* 
         a.T = s.terms; a.batch = batch; a.dbg = h->dbg;
         a.q = static_cast<const float*>(st->q); a.v = static_cast<const float*>(st->v); a.ref = static_cast<const float*>(st->ref);
         a.M = (float*)rows->M; a.h = (float*)rows->h; a.A = (float*)rows->A; a.b1 = (float*)rows->b1; a.Ac = (float*)rows->Ac;
-        a.bc = (float*)rows->bc; a.blb = (float*)rows->blb; a.bub = (float*)rows->bub;
+        a.bc = (float*)rows->bc; a.blb = (float*)rows->blb; a.bub = (float*)rows->bub; a.Acop = (float*)rows->Acop;
         a.momentum = static_cast<float*>(st->momentum);
         hipLaunchKernelGGL(terms_kernel<float>, dim3(batch), dim3(kTermsThreads), lds, sm, a);
     }
@@ -1344,10 +1364,12 @@ int wbcqp_problem_data_host(wbcqp_handle* h, int slot, int batch, const wbcqp_st
     const void* isrc[3] = {st->q, st->v, st->ref};
     size_t ioff[3], in_bytes = 0;
     for (int f = 0; f < 3; ++f) { ioff[f] = in_bytes; in_bytes += al((size_t)ilen[f] * batch * es); }
-    const int olen[8] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub};
-    void* odst[8] = {(void*)rows->M, (void*)rows->h, (void*)rows->A, (void*)rows->b1, (void*)rows->Ac, (void*)rows->bc, (void*)rows->blb, (void*)rows->bub};
-    size_t ooff[8], out_bytes = 0;
-    for (int f = 0; f < 8; ++f) { ooff[f] = out_bytes; out_bytes += al((size_t)olen[f] * batch * es); }
+    constexpr int NR = 9; // row arrays of the record: the eight every stack has, and the cop rows
+    const int olen[NR] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub, L.len_Acop};
+    void* odst[NR] = {(void*)rows->M, (void*)rows->h, (void*)rows->A, (void*)rows->b1, (void*)rows->Ac, (void*)rows->bc, (void*)rows->blb, (void*)rows->bub,
+                      (void*)rows->Acop};
+    size_t ooff[NR], out_bytes = 0;
+    for (int f = 0; f < NR; ++f) { ooff[f] = out_bytes; out_bytes += al((size_t)olen[f] * batch * es); }
     const size_t omom = out_bytes;
     out_bytes += al((size_t)6 * batch * es);
     int rc = ensure(h, h->stage_in, in_bytes + 256);
@@ -1363,12 +1385,12 @@ int wbcqp_problem_data_host(wbcqp_handle* h, int slot, int batch, const wbcqp_st
     wbcqp_state ds = {din + ioff[0], din + ioff[1], din + ioff[2], st->momentum ? dout + omom : nullptr};
     wbcqp_inputs dr{};
     dr.M = dout + ooff[0]; dr.h = dout + ooff[1]; dr.A = dout + ooff[2]; dr.b1 = dout + ooff[3]; dr.Ac = dout + ooff[4];
-    dr.bc = dout + ooff[5]; dr.blb = dout + ooff[6]; dr.bub = dout + ooff[7];
+    dr.bc = dout + ooff[5]; dr.blb = dout + ooff[6]; dr.bub = dout + ooff[7]; dr.Acop = dout + ooff[8];
     rc = wbcqp_problem_data(h, slot, batch, &ds, &dr, nullptr);
     if (rc != WBCQP_OK) return rc;
     HIP_TRY(h, hipDeviceSynchronize());
-    for (int f = 0; f < 8; ++f) {
-        if (olen[f] > 0 && !odst[f]) return fail(h, WBCQP_ERR_INVALID, "row arrays M, h, A, b1, Ac, bc, blb, bub are required");
+    for (int f = 0; f < NR; ++f) {
+        if (olen[f] > 0 && !odst[f]) return fail(h, WBCQP_ERR_INVALID, "row arrays M, h, A, b1, Ac, bc, blb, bub (Acop with a cop task) are required");
         if (olen[f] > 0) HIP_TRY(h, hipMemcpy(odst[f], dout + ooff[f], (size_t)olen[f] * batch * es, hipMemcpyDeviceToHost));
     }
     if (st->momentum) HIP_TRY(h, hipMemcpy(st->momentum, dout + omom, (size_t)6 * batch * es, hipMemcpyDeviceToHost));
@@ -1433,9 +1455,9 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
     if (!h->roll_done) HIP_TRY(h, hipEventCreateWithFlags(&h->roll_done, hipEventDisableTiming));
     // the record of every instance (the rows kernel's output, the solve's input) and the state ping-pong
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const int rlen[8] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub};
-    size_t roff[8], rec_bytes = 0;
-    for (int f = 0; f < 8; ++f) { roff[f] = rec_bytes; rec_bytes += al((size_t)rlen[f] * B * es); }
+    const int rlen[9] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub, L.len_Acop};
+    size_t roff[9], rec_bytes = 0;
+    for (int f = 0; f < 9; ++f) { roff[f] = rec_bytes; rec_bytes += al((size_t)rlen[f] * B * es); }
     const size_t qb = al((size_t)T.nq * B * es), vb = al((size_t)T.nv * B * es);
     const int sub_cap = (batch + S - 1) / S;
     bool grow = h->roll_rec.bytes < rec_bytes || h->roll_state.bytes < 2 * (qb + vb);
@@ -1485,6 +1507,7 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
             d.rows.M = rec + roff[0] + b0 * rlen[0] * es; d.rows.h = rec + roff[1] + b0 * rlen[1] * es; d.rows.A = rec + roff[2] + b0 * rlen[2] * es;
             d.rows.b1 = rec + roff[3] + b0 * rlen[3] * es; d.rows.Ac = rec + roff[4] + b0 * rlen[4] * es; d.rows.bc = rec + roff[5] + b0 * rlen[5] * es;
             d.rows.blb = rec + roff[6] + b0 * rlen[6] * es; d.rows.bub = rec + roff[7] + b0 * rlen[7] * es;
+            d.rows.Acop = rec + roff[8] + b0 * rlen[8] * es;
             d.rows.tlb = at(io->tlb, b0 * L.len_tlb); d.rows.tub = at(io->tub, b0 * L.len_tub); d.rows.w = at(io->w, b0 * L.len_w);
             d.out.x = atw(io->out.x, b0 * L.n); d.out.tau = atw(io->out.tau, b0 * s.host.na); d.out.objective = atw(io->out.objective, b0);
             d.out.status = io->out.status + b0; d.out.iters = io->out.iters + b0;
@@ -1540,11 +1563,12 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     const void* isrc[6] = {io->state.q, io->state.v, io->state.ref, io->rows.tlb, io->rows.tub, io->rows.w};
     size_t ioff[6], in_bytes = 0;
     for (int f = 0; f < 6; ++f) { ioff[f] = in_bytes; in_bytes += al((size_t)ilen[f] * B * es); }
-    const int rlen[8] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub};
-    void* rdst[8] = {(void*)io->rows.M, (void*)io->rows.h, (void*)io->rows.A, (void*)io->rows.b1, (void*)io->rows.Ac, (void*)io->rows.bc,
-                     (void*)io->rows.blb, (void*)io->rows.bub};
-    size_t roff[8];
-    for (int f = 0; f < 8; ++f) { roff[f] = in_bytes; in_bytes += al((size_t)rlen[f] * B * es); }
+    constexpr int NR = 9;
+    const int rlen[NR] = {L.len_M, L.len_h, L.len_A, L.len_b1, L.len_Ac, L.len_bc, L.len_blb, L.len_bub, L.len_Acop};
+    void* rdst[NR] = {(void*)io->rows.M, (void*)io->rows.h, (void*)io->rows.A, (void*)io->rows.b1, (void*)io->rows.Ac, (void*)io->rows.bc,
+                      (void*)io->rows.blb, (void*)io->rows.bub, (void*)io->rows.Acop};
+    size_t roff[NR];
+    for (int f = 0; f < NR; ++f) { roff[f] = in_bytes; in_bytes += al((size_t)rlen[f] * B * es); }
     const size_t o_x = 0, o_tau = o_x + al((size_t)L.n * B * es), o_obj = o_tau + al((size_t)s.host.na * B * es), o_st = o_obj + al(B * es),
                  o_it = o_st + al(B * 4), o_na = o_it + al(B * 4), o_qn = o_na + al(B * 4), o_vn = o_qn + al((size_t)T.nq * B * es),
                  o_qs = o_vn + al((size_t)T.nv * B * es), o_mom = o_qs + al((size_t)T.nv * B * es), out_bytes = o_mom + al((size_t)6 * B * es);
@@ -1572,7 +1596,7 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     wbcqp_tick_io d{};
     d.state = {din + ioff[0], din + ioff[1], din + ioff[2], io->state.momentum ? dout + o_mom : nullptr};
     d.rows.M = din + roff[0]; d.rows.h = din + roff[1]; d.rows.A = din + roff[2]; d.rows.b1 = din + roff[3]; d.rows.Ac = din + roff[4];
-    d.rows.bc = din + roff[5]; d.rows.blb = din + roff[6]; d.rows.bub = din + roff[7];
+    d.rows.bc = din + roff[5]; d.rows.blb = din + roff[6]; d.rows.bub = din + roff[7]; d.rows.Acop = din + roff[8];
     d.rows.tlb = din + ioff[3]; d.rows.tub = din + ioff[4]; d.rows.w = din + ioff[5];
     d.out.x = dout + o_x; d.out.tau = dout + o_tau; d.out.objective = dout + o_obj;
     d.out.status = reinterpret_cast<int32_t*>(dout + o_st); d.out.iters = reinterpret_cast<int32_t*>(dout + o_it);
@@ -1584,7 +1608,7 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     if (packed) { // one copy down (the rows, when asked for, follow one by one), then taken apart on the host
         char* po = static_cast<char*>(h->pin_out.host);
         HIP_TRY(h, hipMemcpyAsync(po, dout, out_bytes, hipMemcpyDeviceToHost, nullptr));
-        for (int f = 0; f < 8; ++f)
+        for (int f = 0; f < NR; ++f)
             if (rlen[f] > 0 && rdst[f]) HIP_TRY(h, hipMemcpyAsync(rdst[f], din + roff[f], (size_t)rlen[f] * B * es, hipMemcpyDeviceToHost, nullptr));
         HIP_TRY(h, hipStreamSynchronize(nullptr));
         std::memcpy(io->out.x, po + o_x, (size_t)L.n * B * es);
@@ -1609,7 +1633,7 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     HIP_TRY(h, hipMemcpyAsync(io->v_next, d.v_next, (size_t)T.nv * B * es, hipMemcpyDeviceToHost, nullptr));
     if (io->q_solver) HIP_TRY(h, hipMemcpyAsync(io->q_solver, d.q_solver, (size_t)T.nv * B * es, hipMemcpyDeviceToHost, nullptr));
     if (io->state.momentum) HIP_TRY(h, hipMemcpyAsync(io->state.momentum, d.state.momentum, (size_t)6 * B * es, hipMemcpyDeviceToHost, nullptr));
-    for (int f = 0; f < 8; ++f)
+    for (int f = 0; f < NR; ++f)
         if (rlen[f] > 0 && rdst[f]) HIP_TRY(h, hipMemcpyAsync(rdst[f], din + roff[f], (size_t)rlen[f] * B * es, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipStreamSynchronize(nullptr));
     return WBCQP_OK;

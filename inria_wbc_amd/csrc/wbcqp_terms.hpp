@@ -42,6 +42,7 @@ struct TermsDev {
     int nb, nq, nv, na, floating_base, nrounds;
     int nlaw, npair, nscf, nblock, nc, n_dense, n_sel, n_bound, r1, nref;
     int posture_ref;
+    int cop;                                                // 1: the structure has a cop task -- the contact lanes also write its rows
     double posture_kp, posture_kd, dt;
     double g[3];
     const int* ipool;
@@ -61,6 +62,7 @@ struct TermsDev {
     int d_scf_place, d_pair_par;                             // [nscf][12], [npair][6]: aa, k, s_p, m, kp, kd
     int d_blk_kp, d_blk_kd;                                  // [nblock]
     int d_qlb, d_qub, d_dqmax;                               // [na]
+    int d_cop_pts;                                           // [nc][4][3] contact points in the contact frame (cop task)
     // LDS layout (doubles)
     int o_state, o_kin, o_scan, o_tot, o_sf, o_law, o_pair, o_scf, o_b1, o_bc;
     int lds_doubles;
@@ -71,6 +73,7 @@ struct TermsArgs {
     TermsDev T;
     const TI *q, *v, *ref;
     TI *M, *h, *A, *b1, *Ac, *bc, *blb, *bub;
+    TI* Acop;     // [batch][3][12 nc] rows of the cop task (T.cop), or null
     TI* momentum; // [batch][6] centroidal momentum (linear, angular about the CoM), or null
     int batch;
     long long* dbg; // per-instance phase cycle counters, only written by the WBCQP_STAMPS diagnostic build
@@ -632,6 +635,21 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
                     if ((mask >> i) & 1) out[o++] = rhs[i];
+                // cop task (tasks.cpp:156-178; tsid TaskCopEquality::compute [UPSTREAM-RECALL]): a contact's lane writes its 3 x 12
+                // block, per contact point (d n' - (n.d) I) R with d = oMf.act(p_i) - cop_ref, cop_ref = the world's origin
+                // (tasks.cpp:171), n = e_z: entry (a, b) = d_a R(2, b) - d_z R(a, b)
+                if (T.cop && ct >= 0 && args.Acop) {
+                    const int kk = 12 * T.nc;
+                    TI* oc = args.Acop + (size_t)rinst * 3 * kk + 12 * ct;
+                    for (int i = 0; i < 4; ++i) {
+                        const V3 d = (mv(f.R, ld3(dp + T.d_cop_pts + 12 * ct + 3 * i)) + f.p) + p0;
+                        const double da[3] = {d.x, d.y, d.z};
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) oc[a * kk + 3 * i + b] = (TI)(da[a] * f.R[6 + b] - d.z * f.R[3 * a + b]);
+                    }
+                }
             }
             // the same wave, lanes = columns now: the Jacobian rows of those tasks.  They need the frames just written and the
             // bodies' placements, not the prefix sums, so two thirds of the record's bytes leave here, while wave 0 is still

@@ -204,6 +204,9 @@ class TaskMap:
     n_bound: int
     dt: float
     nref: int
+    n_acteq: int = 0  # rows of a `torque` task (tasks.cpp:227-271): zero right-hand sides, nothing to compute per tick
+    cop: bool = False  # a `cop` task (tasks.cpp:156-178): three rows over the contact forces from the contact frames' placements
+    contact_points: np.ndarray = field(default_factory=lambda: np.zeros(0))  # [ncontact][4][3] (tasks.cpp:353-358)
 
     @property
     def n_dense(self) -> int:
@@ -225,7 +228,7 @@ class TaskMap:
     def algorithmic_bytes(self, model: Model, st: Structure, itemsize: int = 8) -> int:
         """Bytes one instance of the rows kernel must move: state and references in, QP record out."""
         L = st.field_lengths()
-        out = L["M"] + L["h"] + L["A"] + L["b1"] + L["Ac"] + L["bc"] + L["blb"] + L["bub"]
+        out = L["M"] + L["h"] + L["A"] + L["b1"] + L["Ac"] + L["bc"] + L["blb"] + L["bub"] + L["Acop"]
         return itemsize * (model.nq + model.nv + self.nref + out)
 
 
@@ -272,6 +275,8 @@ def build_taskmap(model: Model, st: Structure, stack: Sequence[dict], dt: float 
             has_bounds = True
         elif ty == "actuation-bounds":
             pass  # constant torque limits: part of the QP record (tlb / tub), nothing to compute per tick
+        elif ty in ("torque", "cop"):
+            pass  # which rows exist is the structure's business (st.n_acteq, st.cop_task); the cop rows need the contact frames, below
         else:
             raise KeyError("unknown task type [%s]" % ty)
     blocks = blocks + sc  # structure.py keeps the self-collision rows behind the se3 / com / momentum rows
@@ -287,7 +292,10 @@ def build_taskmap(model: Model, st: Structure, stack: Sequence[dict], dt: float 
     tm = TaskMap(blocks=blocks, sel_col=st.sel_col.copy(), posture_kp=pkp, posture_kd=2.0 * np.sqrt(pkp), posture_ref=posture_ref,
                  contact_frame=np.array([model.frame(c["joint"]) for c in contacts], dtype=np.int32),
                  contact_kp=ckp, contact_kd=2.0 * np.sqrt(ckp), contact_ref=np.array(cref, dtype=np.int32),
-                 n_bound=model.na if has_bounds else 0, dt=dt, nref=off)
+                 n_bound=model.na if has_bounds else 0, dt=dt, nref=off, n_acteq=st.n_acteq, cop=st.cop_task >= 0,
+                 contact_points=np.ascontiguousarray(np.stack([c.points.T for c in st.contacts])) if st.nc else np.zeros(0))
+    assert st.n_acteq == sum(int(np.sum(np.asarray([ch != "0" for ch in n.get("mask", "1" * model.na)]))) for n in stack if n["type"] == "torque")
+    assert (st.cop_task >= 0) == any(n["type"] == "cop" for n in stack)
     # the structure (which rows exist) and the map (how they are computed) must describe the same stack
     assert tm.n_dense == st.n_dense, (tm.n_dense, st.n_dense)
     assert [b.rows for b in tm.blocks] == [int((st.dense_row_task == t).sum()) for t in dict.fromkeys(st.dense_row_task.tolist())]

@@ -28,7 +28,8 @@ class _TaskMap(C.Structure):
     _fields_ = [("nblock", C.c_int), ("block", C.POINTER(_TaskBlock)), ("avoided_frame", c_int_p), ("avoided_r0", c_double_p),
                 ("n_sel", C.c_int), ("sel_col", c_int_p), ("posture_kp", C.c_double), ("posture_kd", C.c_double),
                 ("posture_ref", C.c_int), ("ncontact", C.c_int), ("contact_frame", c_int_p), ("contact_kp", c_double_p),
-                ("contact_kd", c_double_p), ("contact_ref", c_int_p), ("n_bound", C.c_int), ("dt", C.c_double), ("nref", C.c_int)]
+                ("contact_kd", c_double_p), ("contact_ref", c_int_p), ("n_bound", C.c_int), ("dt", C.c_double), ("nref", C.c_int),
+                ("n_acteq", C.c_int), ("cop", C.c_int), ("contact_points", c_double_p), ("cop_ref", C.c_double * 3)]
 
 
 class _Terms(C.Structure):
@@ -101,6 +102,9 @@ class OracleTaskMap:
         t.contact_kd = _dp(keep(tm.contact_kd, np.float64))
         t.contact_ref = _ip(keep(tm.contact_ref, np.int32))
         t.n_bound, t.dt, t.nref = tm.n_bound, tm.dt, tm.nref
+        t.n_acteq, t.cop = int(getattr(tm, "n_acteq", 0)), int(getattr(tm, "cop", False))
+        t.contact_points = _dp(keep(getattr(tm, "contact_points", np.zeros(0)), np.float64))
+        t.cop_ref[:] = [0.0, 0.0, 0.0]
         self.c = t
 
 
@@ -144,12 +148,13 @@ def log3(R: np.ndarray) -> np.ndarray:
 
 
 def task_rows(model, tm, st, q: np.ndarray, v: np.ndarray, ref: np.ndarray, n_threads: int = 1) -> Dict[str, np.ndarray]:
-    """QP record fields (M h A b1 Ac bc blb bub), [batch, len] each, for the states q / v and references ref."""
+    """QP record fields (M h A b1 Ac bc blb bub Acop), [batch, len] each, for the states q / v and references ref."""
     om, ot = OracleModel(model), OracleTaskMap(tm)
     B = q.shape[0]
-    L = st.field_lengths()
-    out = {k: np.zeros((B, max(L[k], 1))) for k in ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub")}
+    L = dict(st.field_lengths())
+    L.setdefault("Acop", 0)  # (a caller's own stand-in for the structure may know nothing of the cop task)
+    out = {k: np.zeros((B, max(L[k], 1))) for k in ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "Acop")}
     q, v, ref = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, v, ref))
     lib().wbco_task_rows_batch(C.byref(om.c), C.byref(ot.c), B, n_threads, st.n_dense, _dp(q), _dp(v), _dp(ref),
-                               *[_dp(out[k]) for k in ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub")])
+                               *[_dp(out[k]) for k in ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "Acop")])
     return {k: a[:, :L[k]] for k, a in out.items()}

@@ -549,7 +549,7 @@ static void se3_law(const double* oMf12, const double* vf, const double* af, con
 static double sqr(double x) { return x * x; }
 
 void wbco_task_rows(const wbco_model* m, const wbco_taskmap* map, const double* q, const double* v, const double* ref,
-                    double* Mp, double* h, double* A, double* b1, double* Ac, double* bc, double* blb, double* bub)
+                    double* Mp, double* h, double* A, double* b1, double* Ac, double* bc, double* blb, double* bub, double* Acop)
 {
     const int nv = m->nv, nf = m->nframe;
     wbco_terms T;
@@ -656,6 +656,30 @@ void wbco_task_rows(const wbco_model* m, const wbco_taskmap* map, const double* 
     }
     /* force regularisation rows: tsid Contact6d force regularisation task has a zero reference force */
     for (int c = 0; c < 6 * map->ncontact; ++c) b1[row++] = 0.0;
+    /* torque task: S tau_ref with tau_ref = 0 (tasks.cpp:263-265); cop task: TaskCopEquality's constraint vector is zero */
+    for (int j = 0; j < map->n_acteq + (map->cop ? 3 : 0); ++j) b1[row++] = 0.0;
+    if (map->cop && Acop) {
+        /* tsid TaskCopEquality::compute [UPSTREAM-RECALL]: with the forces of a contact given in its frame (oMf = (R, p)) the
+         * tangential moment about cop_ref, n x sum_i (d_i x R f_i), is sum_i (d_i n' - (n . d_i) I) R f_i; n = (0, 0, 1) (the ctor) */
+        const int k = 12 * map->ncontact;
+        const double nrm[3] = {0.0, 0.0, 1.0};
+        for (int c = 0; c < map->ncontact; ++c) {
+            const double* oM = T.oMf + 12 * map->contact_frame[c]; /* rotation row-major (9), translation (3) */
+            for (int i = 0; i < 4; ++i) {
+                const double* pl = map->contact_points + 12 * c + 3 * i;
+                double d[3];
+                for (int a = 0; a < 3; ++a)
+                    d[a] = oM[3 * a] * pl[0] + oM[3 * a + 1] * pl[1] + oM[3 * a + 2] * pl[2] + oM[9 + a] - map->cop_ref[a];
+                const double nd = dot3(nrm, d);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        double s = 0.0; /* ((d n' - nd I) R)(a, b) */
+                        for (int mm = 0; mm < 3; ++mm) s += (d[a] * nrm[mm] - (a == mm ? nd : 0.0)) * oM[3 * mm + b];
+                        Acop[(size_t)a * k + 12 * c + 3 * i + b] = s;
+                    }
+            }
+        }
+    }
     /* contacts: Contact6d::computeMotionTask = TaskSE3Equality in the local frame, all six rows; the reference is a full sample
      * (Contact6dExt::setReference, contact-6d-ext.hpp:18-21), velocity and acceleration zero unless a behaviour sets them
      * (tasks.cpp:359-362) */
@@ -709,7 +733,7 @@ typedef struct {
     const wbco_model* m; const wbco_taskmap* map;
     int lo, hi, n_dense;
     const double *q, *v, *ref;
-    double *M, *h, *A, *b1, *Ac, *bc, *blb, *bub;
+    double *M, *h, *A, *b1, *Ac, *bc, *blb, *bub, *Acop;
 } rows_job;
 
 static void* rows_worker(void* arg)
@@ -717,18 +741,19 @@ static void* rows_worker(void* arg)
     rows_job* J = (rows_job*)arg;
     const wbco_model* m = J->m;
     const wbco_taskmap* map = J->map;
-    const int nv = m->nv, lM = nv * (nv + 1) / 2, r1 = J->n_dense + map->n_sel + 6 * map->ncontact;
+    const int nv = m->nv, lM = nv * (nv + 1) / 2, r1 = J->n_dense + map->n_sel + 6 * map->ncontact + map->n_acteq + (map->cop ? 3 : 0);
     for (int i = J->lo; i < J->hi; ++i)
         wbco_task_rows(m, map, J->q + (size_t)i * m->nq, J->v + (size_t)i * nv, J->ref + (size_t)i * map->nref,
                        J->M + (size_t)i * lM, J->h + (size_t)i * nv, J->A + (size_t)i * J->n_dense * nv, J->b1 + (size_t)i * r1,
                        J->Ac + (size_t)i * map->ncontact * 6 * nv, J->bc + (size_t)i * map->ncontact * 6,
-                       J->blb + (size_t)i * map->n_bound, J->bub + (size_t)i * map->n_bound);
+                       J->blb + (size_t)i * map->n_bound, J->bub + (size_t)i * map->n_bound,
+                       (map->cop && J->Acop) ? J->Acop + (size_t)i * 36 * map->ncontact : NULL);
     return NULL;
 }
 
 void wbco_task_rows_batch(const wbco_model* m, const wbco_taskmap* map, int batch, int n_threads, int n_dense,
                           const double* q, const double* v, const double* ref,
-                          double* M, double* h, double* A, double* b1, double* Ac, double* bc, double* blb, double* bub)
+                          double* M, double* h, double* A, double* b1, double* Ac, double* bc, double* blb, double* bub, double* Acop)
 {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > batch) n_threads = batch > 0 ? batch : 1;
@@ -736,7 +761,7 @@ void wbco_task_rows_batch(const wbco_model* m, const wbco_taskmap* map, int batc
     rows_job* jobs = (rows_job*)malloc(sizeof(rows_job) * n_threads);
     for (int t = 0; t < n_threads; ++t) {
         rows_job j = {m, map, (int)((long long)batch * t / n_threads), (int)((long long)batch * (t + 1) / n_threads), n_dense,
-                      q, v, ref, M, h, A, b1, Ac, bc, blb, bub};
+                      q, v, ref, M, h, A, b1, Ac, bc, blb, bub, Acop};
         jobs[t] = j;
         if (n_threads == 1) rows_worker(&jobs[t]);
         else pthread_create(&th[t], NULL, rows_worker, &jobs[t]);

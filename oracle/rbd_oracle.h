@@ -74,6 +74,11 @@ typedef struct {
     int n_bound;               /* 0 or na */
     double dt;                 /* CONTROLLER.dt (tasks.cpp:283) */
     int nref;                  /* reference doubles per instance */
+    /* level-1 tasks whose rows the solver side forms or that need the contact frames (wbc_oracle.h: n_acteq, cop_task) */
+    int n_acteq;               /* "torque" task: n_acteq right-hand sides scale_j tau_ref_j, zero (tasks.cpp:263-265) */
+    int cop;                   /* 1: a "cop" task -- 3 rows over all contact forces from the contact frames' placements, rhs 0 */
+    const double* contact_points; /* [ncontact][4][3] contact points in the contact frame (tasks.cpp:353-358), used by the cop rows */
+    double cop_ref[3];         /* tasks.cpp:171: (0, 0, 0) */
 } wbco_taskmap;
 
 /* Reference layouts inside the per-instance reference vector (tsid TrajectorySample):
@@ -110,13 +115,14 @@ double wbco_energy(const wbco_model* model, const double* q, const double* v);
 void wbco_log3(const double* R_rowmajor, double* w);
 
 /* The rows of one instance in the record layout of include/wbcqp.h (wbcqp_inputs): M packed lower triangle, h,
- * A [n_dense][nv], b1 [n_dense + n_sel + 6 ncontact] (force-regularisation entries zero), Ac [ncontact][6][nv],
- * bc [ncontact][6], blb / bub [n_bound]. */
+ * A [n_dense][nv], b1 [n_dense + n_sel + 6 ncontact + n_acteq + 3 cop] (force-regularisation, torque and cop entries zero),
+ * Ac [ncontact][6][nv], bc [ncontact][6], blb / bub [n_bound], Acop [3][12 ncontact] (map->cop; may be NULL otherwise):
+ * tsid TaskCopEquality::compute [UPSTREAM-RECALL], per contact point (d n' - (n.d) I) R with d = oMf.act(p_i) - cop_ref, n = e_z. */
 void wbco_task_rows(const wbco_model* model, const wbco_taskmap* map, const double* q, const double* v, const double* ref,
-                    double* M, double* h, double* A, double* b1, double* Ac, double* bc, double* blb, double* bub);
+                    double* M, double* h, double* A, double* b1, double* Ac, double* bc, double* blb, double* bub, double* Acop);
 void wbco_task_rows_batch(const wbco_model* model, const wbco_taskmap* map, int batch, int n_threads, int n_dense,
                           const double* q, const double* v, const double* ref,
-                          double* M, double* h, double* A, double* b1, double* Ac, double* bc, double* blb, double* bub);
+                          double* M, double* h, double* A, double* b1, double* Ac, double* bc, double* blb, double* bub, double* Acop);
 
 #ifdef __cplusplus
 }

@@ -136,7 +136,8 @@ def test_bench_gpus_n_starts_its_own_ranks_as_a_child(tmp_path):
     out = r.stdout + r.stderr
     assert r.returncode != 0
     assert "--nproc-per-node 2" in out and "torch.distributed.run" in out, out[-2000:]
-    assert out.count("bench.py needs an MI355X: the product path has no CPU fallback") == 2, out[-2000:]
+    # (the launcher ends the other rank as soon as the first one fails: one or two copies of the message)
+    assert out.count("bench.py needs an MI355X: the product path has no CPU fallback") >= 1, out[-2000:]
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]  # no result line from a run that failed
 
 

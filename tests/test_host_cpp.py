@@ -119,6 +119,76 @@ def test_qp_timer_test_closed_loop_on_the_model(host_build, oracle_mod, tmp_path
 
 
 @pytest.mark.gpu
+def test_closed_loop_with_a_torque_task_a_cop_task_and_a_posture_mask(host_build, oracle_mod, tmp_path):
+    """A tasks.yaml that uses what no shipped stack does -- `type: torque` with mask and scaling (tasks.cpp:227-271), `type: cop`
+    (tasks.cpp:156-178) and `mask:` on the posture task (tasks.cpp:205-214) -- through PosTracker + humanoid::move_com for 25 ticks
+    of the squat on the model: the facade accepts the file, the library runs the stack on the full layout with H as one matrix, and
+    the final state equals the loop built from the oracles."""
+    from inria_wbc_amd import model as mdl, structure, trajs
+    from oracle import rbd
+    m = mdl.talos_like()
+    na = m.na
+    tmask = np.zeros(na, int); tmask[:12] = 1                       # the legs' torques
+    scaling = np.ones(na); scaling[:12] = np.linspace(0.5, 1.5, 12)
+    pmask = np.ones(na, int); pmask[[21, 22, 30, 43]] = 0
+    tasks = open(os.path.join(ROOT, "configs/talos/tasks.yaml")).read()
+    assert "posture:" in tasks
+    lines, out, in_posture = tasks.splitlines(), [], False
+    for ln in lines:
+        out.append(ln)
+        if ln.startswith("posture:"):
+            in_posture = True
+        elif in_posture and ln.strip().startswith("type:"):
+            out.append("  mask: %s" % "".join(str(b) for b in pmask))
+            in_posture = False
+    out += ["torque:", "  type: torque", "  weight: 0.02", "  mask: %s" % "".join(str(b) for b in tmask),
+            "  scaling: [%s]" % ", ".join("%.17g" % x for x in scaling), "cop:", "  type: cop", "  weight: 5.0"]
+    (tmp_path / "tasks_extra.yaml").write_text("\n".join(out) + "\n")
+    base = open(os.path.join(ROOT, "configs/talos/pos_tracker_model.yaml")).read()
+    for key in ("model", "frames"):
+        base = base.replace("  %s: " % key, "  %s: %s/" % (key, os.path.join(ROOT, "configs/talos")))
+    base = base.replace("  tasks: tasks.yaml", "  tasks: %s" % (tmp_path / "tasks_extra.yaml")).replace("  verbose: false", "  verbose: true")
+    cfg = tmp_path / "pos_tracker_extra.yaml"
+    cfg.write_text(base)
+    n_ticks = 25
+    tau_path, q_path = str(tmp_path / "tau.bin"), str(tmp_path / "q.bin")
+    r = subprocess.run([host_build["qp_timer_test"], str(cfg), os.path.join(ROOT, "configs/talos/squat.yaml"), "-", str(n_ticks), tau_path, "0", q_path],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    st = structure.with_cop_task(structure.with_torque_task(structure.with_posture_mask(structure.talos_structure(), pmask), 0.02, mask=tmask,
+                                                            scaling=scaling), 5.0)
+    stack = [dict(n, mask="".join(str(b) for b in pmask)) if n["type"] == "posture" else n for n in mdl.talos_stack()]
+    stack += [dict(name="torque", type="torque", weight=0.02, mask="".join(str(b) for b in tmask)), dict(name="cop", type="cop", weight=5.0)]
+    tm = mdl.build_taskmap(m, st, stack)
+    tau = np.fromfile(tau_path, dtype=np.float64).reshape(8, st.na)
+    q = np.fromfile(q_path, dtype=np.float64).reshape(8, m.nq)
+    assert all(np.array_equal(tau[0], tau[i]) and np.array_equal(q[0], q[i]) for i in range(1, 8))
+    s = mdl.sample_states(m, tm, 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+    oq, ov, oref = s["q"], s["v"], s["ref"]
+    com_blk = next(b for b in tm.blocks if b.kind == mdl.T_COM)
+    pos, vel, acc = trajs.move_com_stream(m.com(m.q0), [[0.0, 0.0, -0.2]], "001", tm.dt, 2.0, loop=True, absolute=False)
+    tl, tu, w = -m.tau_max[None], m.tau_max[None], st.default_weights[None]
+    for k in range(n_ticks):
+        oref[:, com_blk.ref:com_blk.ref + 9] = np.concatenate([pos[k], vel[k], acc[k]])
+        rows = rbd.task_rows(m, tm, st, oq, ov, oref)
+        oo = oracle_mod.tick_batch(st, dict(rows, tlb=tl, tub=tu, w=w))
+        assert oo["status"][0] == 0
+        nxt = oracle_mod.integrate(True, tm.dt, oq, ov, oo["x"][:, :st.nv])
+        oq, ov = nxt["q_next"], nxt["v_next"]
+    assert np.abs(q[0] - oq[0]).max() < 1e-8, np.abs(q[0] - oq[0]).max()
+    assert np.abs(tau[0] - oo["tau"][0]).max() < 1e-6 * max(1.0, np.abs(oo["tau"]).max())
+    # and the extra tasks did change the motion: the plain stack ends elsewhere
+    plain = structure.talos_structure()
+    tmp = mdl.build_taskmap(m, plain, mdl.talos_stack())
+    sp = mdl.sample_states(m, tmp, 1, 1, q_noise=0.0, v_noise=0.0, ref_noise=0.0)
+    rows = rbd.task_rows(m, tmp, plain, sp["q"], sp["v"], sp["ref"])
+    o2 = oracle_mod.tick_batch(plain, dict(rows, tlb=tl, tub=tu, w=plain.default_weights[None]))
+    rows1 = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"])
+    o1 = oracle_mod.tick_batch(st, dict(rows1, tlb=tl, tub=tu, w=w))
+    assert np.abs(o1["tau"] - o2["tau"]).max() > 1e-3
+
+
+@pytest.mark.gpu
 def test_mimic_filter_momentum_and_step_back(host_build, oracle_mod, tmp_path):
     """What the reference's robot-side consumers read after a tick (controller.cpp:208-229,245,369-397,445-450): tau() / q() with the
     mimic joints of CONTROLLER.mimic_dof_names filtered out (the real Talos has twelve: etc/talos/talos_pos_tracker.yaml:20-31),
