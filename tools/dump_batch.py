@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Dumps a synthetic batch for the C++ harnesses (inria_wbc::controllers::FileSource): 13 int64 header
-(magic, batch, 11 field lengths) followed by the 11 wbcqp_inputs fields as raw [B][len] doubles."""
+"""Dumps a synthetic batch for the C++ harnesses (inria_wbc::controllers::FileSource): 14 int64 header
+(magic 0x5742435151, batch, 12 field lengths) followed by the 12 wbcqp_inputs fields as raw [B][len] doubles (the reader also
+takes the older 13-word header with eleven fields, magic 0x5742435150: files written before the cop task's rows existed)."""
 import argparse
 import os
 import sys
@@ -16,7 +17,7 @@ def dump(path, st, inputs):
     B = inputs["h"].shape[0]
     L = st.field_lengths()
     with open(path, "wb") as f:
-        np.array([0x5742435150, B] + [L[k] for k in synth.FIELDS], dtype=np.int64).tofile(f)
+        np.array([0x5742435151, B] + [L[k] for k in synth.FIELDS], dtype=np.int64).tofile(f)
         for k in synth.FIELDS:
             np.ascontiguousarray(inputs[k], dtype=np.float64).tofile(f)
 
