@@ -339,14 +339,49 @@ def warm_start(local_rank, torch, st, tick_dicts, new_out, B, cdt, base_flags, s
 def dense_seam(local_rank, st, inputs, cpu=True):
     """Latency of ONE Talos QP through the two host-pointer seams: `wbcqp_solve_dense_host` -- what stands behind
     solver_->solve(HQPData) (controller.cpp:247), the reference's own use case at n_qp = 1 -- and `wbcqp_solve_batch_host`
-    (structured record in, batch 1), next to the CPU restatement on one thread.  Wall time per call, PCIe staging included."""
-    from inria_wbc_amd import capi
+    (structured record in, batch 1), next to the CPU restatement on one thread.  Both sides are timed FROM C: the GPU side by the
+    facade's harness (qp_timer_test --dense: the reference's Timer around each call, no ctypes between two calls), the CPU side by
+    loops inside the oracle library (wbco_tick_batch_timed on one thread, wbco_eiquadprog_timed), each warm and >= 200 repetitions.
+    The figures through the Python binding are kept beside them under `through_ctypes` (round 3 quoted those: the CPU ones were
+    about twice the C clock's).  Wall time per call, PCIe staging included."""
+    import subprocess
+    import tempfile
+    from inria_wbc_amd import build, capi
     from oracle import oracle
+    from tools import dump_batch, emit_configs
     one = {k: v[:1] for k, v in inputs.items()}
     H, g, CE, ce0, CI, ci0 = [np.ascontiguousarray(a) for a in oracle.assemble(st, inputs, 0)]
+    res = {"qp": "QP 0 of the headline batch (Talos, n %d, neq %d, %d one-sided rows)" % (st.n, st.neq, st.nin2),
+           "clock": "C on both sides: qp_timer_test --dense (utils::Timer around each call) and loops inside the oracle library"}
+    # ---- GPU side, from C ----
+    try:
+        host = build.build_host()
+        emit_configs.main()
+        with tempfile.TemporaryDirectory() as td:
+            dq, db = os.path.join(td, "dense.bin"), os.path.join(td, "batch.bin")
+            with open(dq, "wb") as fh:
+                np.array([st.n, st.neq, st.nin2], dtype=np.int64).tofile(fh)
+                for a in (H, g, CE, ce0, CI, ci0):
+                    np.ascontiguousarray(a, dtype=np.float64).tofile(fh)
+            dump_batch.dump(db, st, one)
+            r = subprocess.run([host["qp_timer_test"], "--dense", dq, db, os.path.join(ROOT, "configs", "talos", "tasks.yaml"), str(st.nv), str(st.na), "500"],
+                               capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError((r.stdout + r.stderr)[-400:])
+        for ln in r.stdout.splitlines():
+            w = ln.split()
+            if w and w[0] in ("dense_host_us:", "batch_host_us:"):
+                key = "solve_dense_host" if w[0].startswith("dense") else "solve_batch_host"
+                res[key + "_us"] = float(w[1])
+                res[key + "_min_us"] = float(w[3])
+            elif w and w[0] == "status":
+                res["iters"] = int(w[4])
+                res["agree_max_dx"] = float(w[-1])
+    except Exception as e:  # noqa: BLE001
+        res["from_c_error"] = "%s: %s" % (type(e).__name__, e)
+    # ---- the same two calls through the Python binding (what round 3 reported) ----
     h = capi.Handle(device=local_rank, dtype=capi.F64)
     h.set_structure(0, st)
-    res = {"qp": "QP 0 of the headline batch (Talos, n %d, neq %d, %d one-sided rows)" % (st.n, st.neq, st.nin2)}
 
     def wall(fn, reps=200):
         for _ in range(10):
@@ -358,20 +393,84 @@ def dense_seam(local_rank, st, inputs, cpu=True):
 
     us_d, rd = wall(lambda: h.solve_dense_host(H[None], g[None], CE[None], ce0[None], CI[None], ci0[None]))
     us_b, rb = wall(lambda: h.solve_batch_host(0, one))
-    res["solve_dense_host_us"] = us_d
-    res["solve_batch_host_us"] = us_b
-    res["iters"] = int(rb["iters"][0])
-    res["agree_max_dx"] = float(np.abs(rd["x"][0] - rb["x"][0]).max())
+    res["through_ctypes"] = {"solve_dense_host_us": us_d, "solve_batch_host_us": us_b}
+    res.setdefault("iters", int(rb["iters"][0]))
+    res.setdefault("agree_max_dx", float(np.abs(rd["x"][0] - rb["x"][0]).max()))
     if cpu:
+        s1, ref = oracle.tick_batch_timed(st, one, nthreads=1, reps=1)  # warm: page in, first malloc
+        s1, ref = oracle.tick_batch_timed(st, one, nthreads=1, reps=400)
+        res["cpu_port_single_thread_us"] = s1 / 400 * 1e6  # assembly + eiquadprog + decode, in C
+        se, est, eit = oracle.eiquadprog_timed(H, g, CE, ce0, CI, ci0, reps=400)
+        res["cpu_port_eiquadprog_only_us"] = se * 1e6
+        try:
+            sn, _ = oracle.tick_batch_timed(st, one, nthreads=1, reps=400, native=True)
+            res["cpu_port_single_thread_native_us"] = sn / 400 * 1e6
+        except Exception:  # noqa: BLE001
+            pass
         t0 = time.perf_counter()
         for _ in range(50):
-            ref = oracle.tick_batch(st, one)
-        res["cpu_port_single_thread_us"] = (time.perf_counter() - t0) / 50 * 1e6
-        t0 = time.perf_counter()
-        for _ in range(50):
-            oracle.eiquadprog(H, g, CE, ce0, CI, ci0)
-        res["cpu_port_eiquadprog_only_us"] = (time.perf_counter() - t0) / 50 * 1e6
+            oracle.tick_batch(st, one)
+        res["through_ctypes"]["cpu_port_single_thread_us"] = (time.perf_counter() - t0) / 50 * 1e6
         res["max_rel_dx_vs_oracle"] = float(np.abs(rb["x"][0] - ref["x"][0]).max() / max(1.0, np.abs(ref["x"][0]).max()))
+        if "solve_batch_host_us" in res:
+            res["gpu_over_cpu"] = {"structured_seam": res["cpu_port_single_thread_us"] / res["solve_batch_host_us"],
+                                   "dense_seam_vs_eiquadprog_alone": res["cpu_port_eiquadprog_only_us"] / res["solve_dense_host_us"],
+                                   "note": "> 1: one robot's tick is shorter through the GPU seam than on one host core (C clock on both sides)"}
+    h.close()
+    return res
+
+
+def franka_single_tick(local_rank, torch, cpu=True):
+    """The reference's one timing fixture: Franka pos-tracker, 12.6 us per tick INCLUDING kinematics on its authors' machine
+    (tests/ref_test_franka.yaml:11, solver = whole behavior->update(), test_franka.cpp:175-179).  Here: one Franka instance through
+    wbcqp_tick_host (rows from the model, QP, integration; wall time per call) and the device-side tick (event time), the CPU
+    restatement of the same tick on one core beside them."""
+    from inria_wbc_amd import capi, structure
+    from inria_wbc_amd import model as mdl
+    m = mdl.franka_like()
+    st = structure.franka_structure()
+    tm = mdl.build_taskmap(m, st, mdl.franka_stack())
+    h = capi.Handle(device=local_rank, dtype=capi.F64)
+    h.set_structure(0, st)
+    h.set_model(0, m, tm)
+    s = mdl.sample_states(m, tm, 1, 77_000, q_noise=0.01, v_noise=0.05, ref_noise=0.01)
+    w = st.default_weights[None]
+    for _ in range(20):
+        h.tick_host(0, s["q"], s["v"], s["ref"], None, None, w, tm.dt)
+    t0 = time.perf_counter()
+    for _ in range(300):
+        got = h.tick_host(0, s["q"], s["v"], s["ref"], None, None, w, tm.dt)
+    host_us = (time.perf_counter() - t0) / 300 * 1e6
+    dev = torch.device("cuda", local_rank)
+    L = st.field_lengths()
+    state = {k: torch.from_numpy(s[k]).to(dev) for k in ("q", "v", "ref")}
+    rows = {k: torch.zeros(1, L[k], dtype=torch.float64, device=dev) for k in capi.ROW_FIELDS}
+    rows["w"] = torch.from_numpy(w.copy()).to(dev)
+    out = dict(x=torch.zeros(1, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(1, st.na, dtype=torch.float64, device=dev),
+               status=torch.zeros(1, dtype=torch.int32, device=dev), iters=torch.zeros(1, dtype=torch.int32, device=dev))
+    qn, vn = torch.zeros_like(state["q"]), torch.zeros_like(state["v"])
+    sp = torch.cuda.current_stream().cuda_stream
+    for _ in range(10):
+        h.tick(0, 1, state, rows, out, qn, vn, tm.dt, stream=sp)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200):
+        h.tick(0, 1, state, rows, out, qn, vn, tm.dt, stream=sp)
+    e1.record()
+    torch.cuda.synchronize()
+    res = {"reference_anchor_us": 12.6, "reference_anchor": "tests/ref_test_franka.yaml:11 (2021, unknown machine, incl. kinematics, one thread)",
+           "tick_host_us": host_us, "tick_device_us": e0.elapsed_time(e1) / 200 * 1e3, "status": int(got["status"][0]),
+           "note": "one Franka instance (n = 9): a single small QP is launch- and PCIe-latency on a GPU; the batch is what the device is for "
+                   "(Franka B = 8192: other figures of this line)"}
+    if cpu:
+        from oracle import oracle, rbd
+        t0 = time.perf_counter()
+        for _ in range(200):
+            rws = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"])
+        res["cpu_port_rows_us_through_ctypes"] = (time.perf_counter() - t0) / 200 * 1e6
+        s1, _ = oracle.tick_batch_timed(st, dict(rws, tlb=np.zeros((1, 0)), tub=np.zeros((1, 0)), w=w), nthreads=1, reps=2000)
+        res["cpu_port_qp_us"] = s1 / 2000 * 1e6
     h.close()
     return res
 
@@ -894,6 +993,10 @@ def main():
                 result["dense_seam"] = dense_seam(local_rank, st, inputs, not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001
                 result["dense_seam"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                result["franka_single_tick"] = franka_single_tick(local_rank, torch, not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                result["franka_single_tick"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
         if not args.no_cpu_baseline and world == 1:
             # the oracle is the checker here and the reported CPU baseline -- never the thing shipped.  One call per figure:

@@ -3,6 +3,11 @@
 // (open loop) under the "solver" timer.  Differences: B robot instances per tick (from the batch file argv[3]), and the
 // last tick's torques can be written to argv[5] so that a test can compare them with the CPU oracle.
 //   qp_timer_test <controller.yaml> <behavior.yaml> <batch.bin | -> [n_ticks=10] [tau_out.bin] [first_tick=0] [q_out.bin]
+//   qp_timer_test --dense <dense_qp.bin> <batch.bin> <tasks.yaml> <nv> <na> [reps=500]
+//       ONE QP through the two host-pointer seams of the C ABI, timed from C with the same Timer (no Python, no ctypes between two
+//       calls): wbcqp_solve_dense_host on the dense QP of the first file (int64 n, neq, nin, then H, g, CE, ce0, CI, ci0 as doubles:
+//       what tsid's solver stacks from the HQPData, controller.cpp:247) and wbcqp_solve_batch_host on QP 0 of the batch file with the
+//       task stack of tasks.yaml.  The single-robot comparison of bench.py (dense_seam) reads the two "us" lines.
 // With `-` for the batch file the controller must carry its own model (CONTROLLER.model): the rows come from the robot
 // state on the device (ModelSource), the loop is closed through the integrated state, and the final q can be written too.
 #include <algorithm>
@@ -24,9 +29,80 @@
 static volatile sig_atomic_t stop = 0;
 static void stopsig(int) { stop = 1; }
 
+static int dense_mode(int argc, char** argv)
+{
+    using namespace inria_wbc;
+    if (argc < 7) {
+        std::cerr << "usage: " << argv[0] << " --dense <dense_qp.bin> <batch.bin> <tasks.yaml> <nv> <na> [reps]" << std::endl;
+        return 2;
+    }
+    const int nv = std::atoi(argv[5]), na = std::atoi(argv[6]), reps = argc > 7 ? std::atoi(argv[7]) : 500;
+    std::ifstream f(argv[2], std::ios::binary);
+    IWBC_ASSERT(f.good(), "cannot open ", argv[2]);
+    int64_t hdr[3];
+    f.read(reinterpret_cast<char*>(hdr), sizeof hdr);
+    const int n = (int)hdr[0], neq = (int)hdr[1], nin = (int)hdr[2];
+    std::vector<double> H((size_t)n * n), g(n), CE((size_t)neq * n), ce0(neq), CI((size_t)nin * n), ci0(nin);
+    auto rd = [&](std::vector<double>& a) { f.read(reinterpret_cast<char*>(a.data()), (std::streamsize)(a.size() * sizeof(double))); };
+    rd(H); rd(g); rd(CE); rd(ce0); rd(CI); rd(ci0);
+    IWBC_ASSERT(f.good(), "short read in ", argv[2]);
+    tasks::TaskStack stack(IWBC_CHECK(yaml::LoadFile(argv[4])), nv, na);
+    wbcqp_structure st = stack.c_struct();
+    wbcqp_layout L;
+    IWBC_ASSERT(wbcqp_layout_of(&st, &L) == WBCQP_OK, wbcqp_last_error(nullptr));
+    IWBC_ASSERT(L.n == n && L.neq == neq && L.nin2 == nin, "the dense QP and the task stack disagree on the sizes");
+    controllers::FileSource src(argv[3]);
+    controllers::TickInputs in;
+    in.resize(src.batch(), L);
+    src.compute(0.0, controllers::MatrixXd(), controllers::MatrixXd(), stack, L, in);
+    wbcqp_handle* h = nullptr;
+    wbcqp_desc desc = {0, WBCQP_F64, 0};
+    if (wbcqp_create(&desc, &h) != WBCQP_OK) IWBC_ERROR("wbcqp_create: ", wbcqp_last_error(nullptr));
+    IWBC_ASSERT(wbcqp_set_structure(h, 0, &st) == WBCQP_OK, wbcqp_last_error(h));
+    wbcqp_dense_inputs di = {H.data(), g.data(), CE.data(), ce0.data(), CI.data(), ci0.data()};
+    wbcqp_inputs bi = {in.M.data(), in.h.data(), in.A.data(), in.b1.data(), in.Ac.data(), in.bc.data(), in.blb.data(), in.bub.data(),
+                       in.tlb.data(), in.tub.data(), in.w.data(), in.Acop.data()};
+    std::vector<double> x(n), tau(std::max(na, 1)), obj(1);
+    int32_t status = -99, iters = 0;
+    wbcqp_outputs bo = {x.data(), tau.data(), &status, &iters, obj.data(), nullptr, nullptr};
+    const wbcqp_dense_output* res = nullptr;
+    utils::Timer timer;
+    for (int r = 0; r < 20; ++r) { // warm: allocations, page-locked staging, the first launch of each kernel
+        IWBC_ASSERT(wbcqp_solve_dense_host(h, 1, n, neq, nin, 0, &di, &res) == WBCQP_OK, wbcqp_last_error(h));
+        IWBC_ASSERT(wbcqp_solve_batch_host(h, 0, 1, &bi, &bo) == WBCQP_OK, wbcqp_last_error(h));
+    }
+    for (int r = 0; r < reps; ++r) {
+        timer.begin("dense");
+        wbcqp_solve_dense_host(h, 1, n, neq, nin, 0, &di, &res);
+        timer.end("dense");
+    }
+    for (int r = 0; r < reps; ++r) {
+        timer.begin("batch");
+        wbcqp_solve_batch_host(h, 0, 1, &bi, &bo);
+        timer.end("batch");
+    }
+    double dmax = 0.0;
+    for (int i = 0; i < n; ++i) dmax = std::max(dmax, std::fabs(res->x[i] - x[i]));
+    std::cout.precision(6);
+    std::cout << "dense_host_us: " << timer["dense"].time / timer["dense"].iterations << " min " << timer["dense"].min_time << " max "
+              << timer["dense"].max_time << " reps " << reps << std::endl;
+    std::cout << "batch_host_us: " << timer["batch"].time / timer["batch"].iterations << " min " << timer["batch"].min_time << " max "
+              << timer["batch"].max_time << " reps " << reps << std::endl;
+    std::cout << "status " << status << " / " << res->status[0] << " iters " << iters << " / " << res->iters[0] << " max |dx| " << dmax << std::endl;
+    wbcqp_destroy(h);
+    return (status == 0 && res->status[0] == 0) ? 0 : 1;
+}
+
 int main(int argc, char** argv)
 {
     using namespace inria_wbc;
+    if (argc > 1 && std::string(argv[1]) == "--dense") {
+        try { return dense_mode(argc, argv); }
+        catch (std::exception& e) {
+            std::cerr << "Exception (dense):" << e.what() << std::endl;
+            return 1;
+        }
+    }
     if (argc < 4) {
         std::cerr << "usage: " << argv[0] << " <controller.yaml> <behavior.yaml> <batch.bin> [n_ticks] [tau_out.bin] [first_tick]" << std::endl;
         return 2;

@@ -192,6 +192,25 @@ def eiquadprog(H, g, CE, ce0, CI, ci0, max_iter: int = 1000):
     return dict(x=x, u=u[:iq.value].copy(), A=A[:iq.value].copy(), iq=iq.value, iters=it.value, fval=fv.value, status=status)
 
 
+def eiquadprog_timed(H, g, CE, ce0, CI, ci0, reps: int = 200, max_iter: int = 1000, native: bool = False):
+    """(seconds per solve, status, iterations): `reps` solves of one dense QP inside ONE C loop after a warm-up solve
+    (wbco_eiquadprog_timed) -- no Python between two solves."""
+    H = np.ascontiguousarray(H, np.float64); g = np.ascontiguousarray(g, np.float64)
+    n = g.size
+    CE = np.ascontiguousarray(CE, np.float64).reshape(-1, n); ce0 = np.ascontiguousarray(ce0, np.float64).reshape(-1)
+    CI = np.ascontiguousarray(CI, np.float64).reshape(-1, n); ci0 = np.ascontiguousarray(ci0, np.float64).reshape(-1)
+    neq, nin2 = CE.shape[0], CI.shape[0]
+    CEp = CE if neq else np.zeros((1, n)); ce0p = ce0 if neq else np.zeros(1)
+    CIp = CI if nin2 else np.zeros((1, n)); ci0p = ci0 if nin2 else np.zeros(1)
+    st, it = C.c_int(0), C.c_int(0)
+    f = (native_lib() if native else lib()).wbco_eiquadprog_timed
+    f.restype = C.c_double
+    secs = f(n, neq, nin2, _dp(H), _dp(g), _dp(CEp), _dp(ce0p), _dp(CIp), _dp(ci0p), int(max_iter), int(reps), C.byref(st), C.byref(it))
+    if secs < 0.0:
+        raise RuntimeError("wbco_eiquadprog_timed failed")
+    return float(secs) / max(1, reps), st.value, it.value
+
+
 def tick_batch(st, inputs: Dict[str, np.ndarray], nthreads: int = 1):
     """P1..P4 for every QP of a [B, len] input set. Returns dict(x, tau, status, iters)."""
     ost = OracleStructure(st)

@@ -635,6 +635,28 @@ done:
 }
 
 /* ------------------------------------------------------------------------------------------ */
+static double now_s(void);
+
+double wbco_eiquadprog_timed(int n, int neq, int nin2, const double* H, const double* g, const double* CE, const double* ce0,
+                             const double* CI, const double* ci0, int max_iter, int reps, int* status_out, int* iter_out)
+{
+    if (reps < 1) reps = 1;
+    double* ws = (double*)malloc(sizeof(double) * (size_t)wbco_ws_size(n, neq, nin2));
+    double* x = (double*)malloc(sizeof(double) * (size_t)n);
+    double* u = (double*)malloc(sizeof(double) * (size_t)(neq + nin2 + 2));
+    int* A = (int*)malloc(sizeof(int) * (size_t)(neq + nin2 + 2));
+    if (!ws || !x || !u || !A) return -1.0;
+    int iq = 0, iter = 0, st = 0;
+    double fval = 0.0;
+    st = wbco_eiquadprog_fast(n, neq, nin2, H, g, CE, ce0, CI, ci0, x, u, A, &iq, &iter, &fval, max_iter, ws);
+    const double t0 = now_s();
+    for (int r = 0; r < reps; ++r) st = wbco_eiquadprog_fast(n, neq, nin2, H, g, CE, ce0, CI, ci0, x, u, A, &iq, &iter, &fval, max_iter, ws);
+    const double dt = now_s() - t0;
+    if (status_out) *status_out = st;
+    if (iter_out) *iter_out = iter;
+    free(ws); free(x); free(u); free(A);
+    return dt;
+}
 
 long wbco_tick_ws_size(const wbco_structure* st)
 {

@@ -134,6 +134,11 @@ int wbco_eiquadprog_fast(int n, int neq, int nin2,
                          double* x, double* u, int* A, int* iq_out, int* iter_out, double* fval,
                          int max_iter, double* ws);
 
+/* `reps` solves of the same dense QP in one C loop (one warm-up solve first, workspace allocated once): seconds inside the loop,
+ * < 0 on error.  The CPU side of the single-robot comparison (bench.py dense_seam): no Python between two solves. */
+double wbco_eiquadprog_timed(int n, int neq, int nin2, const double* H, const double* g, const double* CE, const double* ce0,
+                             const double* CI, const double* ci0, int max_iter, int reps, int* status_out, int* iter_out);
+
 /* P1+P2+P3+P4 for one QP. ws may be NULL (malloc) or wbco_tick_ws_size(st) doubles. */
 long wbco_tick_ws_size(const wbco_structure* st);
 int wbco_tick(const wbco_structure* st, const wbco_inputs* in, wbco_outputs* out, double* ws);
