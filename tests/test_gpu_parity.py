@@ -31,11 +31,14 @@ def test_golden_fixtures(handle, case):
     assert info["iters_equal"] >= 0.8, (fname, got["iters"], ref["iters"])
 
 
-@pytest.mark.parametrize("name,batch,noise", [
+PARITY_CASES = [
     ("franka", 64, 0.5), ("tiago", 64, 2.0), ("icub", 48, 0.5), ("icub", 32, 5.0),
     ("talos", 64, 0.5), ("talos", 32, 5.0), ("talos_single_support", 32, 2.0),
     # three contacts, 24 equalities: the sequential equality phase and an unpaired contact block
-    ("three_contact", 24, 0.5), ("three_contact", 16, 4.0)])
+    ("three_contact", 24, 0.5), ("three_contact", 16, 4.0)]
+
+
+@pytest.mark.parametrize("name,batch,noise", PARITY_CASES)
 def test_parity_vs_oracle(handle, oracle_mod, name, batch, noise):
     st = structure.STRUCTURES[name]()
     inputs = synth.generate(st, batch, synth.SEED_BASE[name] + 100, task_noise=noise)
