@@ -89,8 +89,9 @@ static int dense_mode(int argc, char** argv)
     std::cout << "batch_host_us: " << timer["batch"].time / timer["batch"].iterations << " min " << timer["batch"].min_time << " max "
               << timer["batch"].max_time << " reps " << reps << std::endl;
     std::cout << "status " << status << " / " << res->status[0] << " iters " << iters << " / " << res->iters[0] << " max |dx| " << dmax << std::endl;
+    const bool ok = status == 0 && res->status[0] == 0; // (res lives in the handle: read it before the handle goes)
     wbcqp_destroy(h);
-    return (status == 0 && res->status[0] == 0) ? 0 : 1;
+    return ok ? 0 : 1;
 }
 
 int main(int argc, char** argv)

@@ -28,9 +28,15 @@ def test_golden_fixtures(handle, case):
     got = handle.solve_batch_host(0, inputs)
     ref = dict(x=z["x"], tau=z["tau"], status=z["status"], iters=z["iters"])
     info = assert_parity(st, got, ref, what=fname)
-    assert info["iters_equal"] >= 0.8, (fname, got["iters"], ref["iters"])
+    # measured (tools/iters_floor.py, profiles/r04/iters_floor.txt): every golden QP takes the oracle's iteration count except one of
+    # the six of talos_n5 (a tie broken by rounding); the bar is the measured count plus one QP
+    differ = int(round(len(ref["iters"]) * (1.0 - info["iters_equal"])))
+    assert differ <= GOLDEN_DIFFER.get(fname, 0) + 1, (fname, got["iters"], ref["iters"])
 
 
+GOLDEN_DIFFER = {"talos_n5.npz": 1}  # QPs whose iteration count differs from the oracle's, measured (everything else: none)
+# (name, batch, task noise) -> measured count of QPs whose iteration count differs from the oracle's (tools/iters_floor.py)
+PARITY_DIFFER = {("icub", 5.0): 3, ("talos", 5.0): 4, ("talos_single_support", 2.0): 2, ("three_contact", 4.0): 2}
 PARITY_CASES = [
     ("franka", 64, 0.5), ("tiago", 64, 2.0), ("icub", 48, 0.5), ("icub", 32, 5.0),
     ("talos", 64, 0.5), ("talos", 32, 5.0), ("talos_single_support", 32, 2.0),
@@ -47,8 +53,10 @@ def test_parity_vs_oracle(handle, oracle_mod, name, batch, noise):
     got = handle.solve_batch_host(1, inputs)
     info = assert_parity(st, got, ref, what=name)
     # ties and near-degenerate pivots can be broken differently by 1-ulp differences (the oracle itself changes
-    # iteration counts on ~6 % of the hard cases under a 1-ulp input perturbation); the solution must still agree
-    assert info["iters_equal"] >= (0.9 if noise < 1.0 else 0.6), (name, got["iters"], ref["iters"])
+    # iteration counts on ~6 % of the hard cases under a 1-ulp input perturbation); the solution must still agree.  The bar per
+    # case is what was measured plus one QP: zero differing QPs wherever the task noise is below 1, 2-4 of 16-32 on the hard cases
+    differ = int(round(batch * (1.0 - info["iters_equal"])))
+    assert differ <= PARITY_DIFFER.get((name, noise), 0) + 1, (name, differ, got["iters"], ref["iters"])
 
 
 def test_determinism_and_batch_permutation(handle):
