@@ -425,13 +425,17 @@ int wbcqp_tick_host(wbcqp_handle* handle, int slot, int batch, const wbcqp_tick_
 /* ---- K ticks of every instance in one call, without the batch barrier ----
  * Instance i's tick t + 1 depends on instance i's tick t only (controller.cpp:254-256), never on the batch; a loop of wbcqp_tick calls
  * makes every tick wait for the slowest QP of the WHOLE batch, and on the squat stream that one QP is 0.29 ms long while the rest of a
- * 1024-QP batch is worth 0.13 ms of the chip.  wbcqp_rollout cuts a batch of 512 instances or more into two sub-batches and enqueues all K
- * ticks of each on a HIP stream of its own (rows -> QP -> integration, the kernels of wbcqp_tick; every sub-batch has its own launch-order state and
- * queue counter): the streams overlap on the device, so the tail of one sub-batch's solve runs beside the bulk of another's, and the
- * host enqueues the whole roll-out without waiting for anything.  What it buys is bounded by the slowest INSTANCE's own chain of K
- * ticks: measured 1.04x of the tick loop at B = 1024 where one instance stays the hard one for the whole roll-out (tools/rollout_bench.py,
- * profiles/r03/rollout_bench.log).  Bit for bit the result of K calls of wbcqp_tick with q_next / v_next fed
- * back.  (A single persistent kernel running the three phases back to back per instance was built and measured first: 0.69x of the tick
+ * 1024-QP batch is worth 0.13 ms of the chip.  wbcqp_rollout enqueues all K ticks up front (rows -> QP -> integration, the kernels of
+ * wbcqp_tick; the host waits for nothing), either as ONE stream of ticks -- what K calls of wbcqp_tick are -- or, for 512 instances and
+ * more, as TWO sub-batches on HIP streams of their own (each with its own launch-order state and queue counter), whose launches overlap
+ * on the device: the tail of one sub-batch's solve runs beside the bulk of the other's.  Which of the two is faster depends on the
+ * workload, measured (tools/rollout_bench.py, profiles/r03/rollout_bench.log, profiles/r04/): two sub-batches 1.04x of the tick loop at
+ * B = 1024 where one instance stays the hard one, but 0.76x where every instance is heavy (nothing idles in a tick's tail) and 0.93x at
+ * B = 4096 (the launch hides its own tail); three sub-batches 1.02x, four 0.57x.  So the library MEASURES: every roll-out is timed on
+ * the device by an event pair that a later call reads without blocking; the first roll-out of a (slot, batch) runs as one stream, the
+ * next one as two, from then on whichever was faster (the other one retried every 64th call while within 20 %).  Never slower than the
+ * tick loop once both are measured; what it buys is bounded by the slowest INSTANCE's own chain of K ticks.  Bit for bit the result of K
+ * calls of wbcqp_tick with q_next / v_next fed back, whatever the choice.  (A single persistent kernel running the three phases back to back per instance was built and measured first: 0.69x of the tick
  * loop -- the three phases together do not fit 256 VGPRs, and an instance's rows phase runs at 8 waves per CU instead of 16;
  * profiles/r03/fused_rollout_kernel_not_kept.log, DESIGN.md.)  Loop shape: qp_timer_test.cpp:55-63.  All pointers are DEVICE pointers.
  * Ordered after everything already on `stream`; everything enqueued on `stream` afterwards sees the results. */
@@ -450,7 +454,8 @@ typedef struct {
     int32_t* ticks_ok;   /* [batch] ticks whose QP was solved (a tick that is not keeps the state, like wbcqp_integrate), may be NULL */
 } wbcqp_rollout_io;
 /* The slot needs a model (wbcqp_set_model).  The first call of a larger shape allocates the record arrays and the state ping-pong (and
- * synchronises the device to do it); WBCQP_ROLLOUT_STREAMS in the environment overrides the number of sub-batches (1: a plain tick loop). */
+ * synchronises the device to do it); WBCQP_ROLLOUT_STREAMS in the environment fixes the number of sub-batches (1 .. 8; 1: a plain tick loop)
+ * instead of the measured choice. */
 int wbcqp_rollout(wbcqp_handle* handle, int slot, int batch, int n_ticks, const wbcqp_rollout_io* io, void* stream);
 
 /* The same sequence captured once into a HIP graph and replayed: one graph launch per tick instead of four kernel

@@ -116,6 +116,20 @@ struct wbcqp_handle {
     std::vector<RollSub> roll_subs;
     hipEvent_t roll_start = nullptr;
     hipEvent_t roll_done = nullptr;  // end of the previous roll-out: the next one (on whatever stream) waits for it before it reuses the buffers
+    // how many sub-batches a roll-out is cut into is MEASURED, per (slot, batch): the device time of every roll-out lies between
+    // roll_start and roll_done (both timed events); the next call reads it without blocking (hipEventQuery) and keeps, per shape, a
+    // running figure of microseconds per tick for one sub-batch (= what K calls of wbcqp_tick do) and for two
+    struct RollStat {
+        int slot = -1, batch = 0, calls = 0;
+        double us[3] = {0.0, 0.0, 0.0}; // [S] running mean, 0: never measured
+    };
+    std::vector<RollStat> roll_stats;
+    struct RollMeas { // one timed event pair around a roll-out, read by a later call once the device has passed it
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        int stat = -1, S = 0, ticks = 0;
+        bool pending = false;
+    };
+    RollMeas roll_meas[4];
     Staging roll_rec, roll_state;
 };
 
@@ -575,6 +589,10 @@ int wbcqp_destroy(wbcqp_handle* h)
     }
     if (h->roll_start) (void)hipEventDestroy(h->roll_start);
     if (h->roll_done) (void)hipEventDestroy(h->roll_done);
+    for (auto& mz : h->roll_meas) {
+        if (mz.t0) (void)hipEventDestroy(mz.t0);
+        if (mz.t1) (void)hipEventDestroy(mz.t1);
+    }
     for (auto& ss : h->streams) {
         if (ss.ord.order) (void)hipFree(ss.ord.order);
         if (ss.ord.queue) (void)hipFree(ss.ord.queue);
@@ -1018,8 +1036,17 @@ int wbcqp_debug_set_stamp_buffer(wbcqp_handle* h, void* dev_ptr)
 #endif
 }
 
+static int integrate_impl(wbcqp_handle* h, int batch, int nv, int floating_base, double dt, const void* q, const void* dq, const void* x,
+                          int ldx, const int32_t* status, void* q_next, void* v_next, void* q_solver, void* stream, const RollAcc& acc);
+
 int wbcqp_integrate(wbcqp_handle* h, int batch, int nv, int floating_base, double dt, const void* q, const void* dq, const void* x,
                     int ldx, const int32_t* status, void* q_next, void* v_next, void* q_solver, void* stream)
+{
+    return integrate_impl(h, batch, nv, floating_base, dt, q, dq, x, ldx, status, q_next, v_next, q_solver, stream, RollAcc{});
+}
+
+static int integrate_impl(wbcqp_handle* h, int batch, int nv, int floating_base, double dt, const void* q, const void* dq, const void* x,
+                          int ldx, const int32_t* status, void* q_next, void* v_next, void* q_solver, void* stream, const RollAcc& acc)
 {
     if (!h) return WBCQP_ERR_INVALID;
     if (batch < 0 || nv <= 0 || ldx < nv) return fail(h, WBCQP_ERR_INVALID, "bad batch / nv / ldx");
@@ -1032,11 +1059,11 @@ int wbcqp_integrate(wbcqp_handle* h, int batch, int nv, int floating_base, doubl
     if (h->dtype == WBCQP_F64)
         hipLaunchKernelGGL(integrate_kernel<double>, grid, block, 0, st, batch, nv, floating_base ? 1 : 0, dt,
                            static_cast<const double*>(q), static_cast<const double*>(dq), static_cast<const double*>(x), ldx, status,
-                           static_cast<double*>(q_next), static_cast<double*>(v_next), static_cast<double*>(q_solver));
+                           static_cast<double*>(q_next), static_cast<double*>(v_next), static_cast<double*>(q_solver), acc);
     else
         hipLaunchKernelGGL(integrate_kernel<float>, grid, block, 0, st, batch, nv, floating_base ? 1 : 0, dt,
                            static_cast<const float*>(q), static_cast<const float*>(dq), static_cast<const float*>(x), ldx, status,
-                           static_cast<float*>(q_next), static_cast<float*>(v_next), static_cast<float*>(q_solver));
+                           static_cast<float*>(q_next), static_cast<float*>(v_next), static_cast<float*>(q_solver), acc);
     HIP_TRY(h, hipGetLastError());
     return WBCQP_OK;
 }
@@ -1397,7 +1424,11 @@ int wbcqp_problem_data_host(wbcqp_handle* h, int slot, int batch, const wbcqp_st
     return WBCQP_OK;
 }
 
-int wbcqp_tick(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io, void* stream)
+static int tick_impl(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io, void* stream, const RollAcc& acc);
+
+int wbcqp_tick(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io, void* stream) { return tick_impl(h, slot, batch, io, stream, RollAcc{}); }
+
+static int tick_impl(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io, void* stream, const RollAcc& acc)
 {
     if (!h) return WBCQP_ERR_INVALID;
     if (!io) return fail(h, WBCQP_ERR_INVALID, "io is NULL");
@@ -1411,8 +1442,8 @@ int wbcqp_tick(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* io, vo
     if (rc != WBCQP_OK) return rc;
     rc = wbcqp_solve_batch(h, slot, batch, &io->rows, &io->out, stream);
     if (rc != WBCQP_OK) return rc;
-    return wbcqp_integrate(h, batch, s.terms.nv, s.terms.floating_base, io->dt, io->state.q, io->state.v, io->out.x, s.host.n,
-                           io->out.status, io->q_next, io->v_next, io->q_solver, stream);
+    return integrate_impl(h, batch, s.terms.nv, s.terms.floating_base, io->dt, io->state.q, io->state.v, io->out.x, s.host.n,
+                          io->out.status, io->q_next, io->v_next, io->q_solver, stream, acc);
 }
 
 int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp_rollout_io* io, void* stream)
@@ -1434,11 +1465,58 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
     hipStream_t sm = static_cast<hipStream_t>(stream);
     const size_t es = (h->dtype == WBCQP_F64) ? 8 : 4;
     const size_t B = (size_t)batch;
-    // two sub-batches from 512 instances on (measured, tools/rollout_bench.py, B = 1024, 64 ticks: 1.04x of the tick loop with two streams,
-    // 1.02x with three, 0.57x with four -- the launches of four streams no longer overlap, they queue behind one another); WBCQP_ROLLOUT_STREAMS
-    // overrides (1 = what K calls of wbcqp_tick do)
-    int S = batch >= 512 ? 2 : 1;
+    // One sub-batch (what K calls of wbcqp_tick do) or two.  Two pay where a tick's solve has a long tail -- one instance far
+    // above the rest, B = 1024: 1.04x -- and cost where it has none (every instance heavy: 0.76x) or where the launch is large
+    // enough to hide its tail by itself (B = 4096: 0.93x); three gain less (1.02x), four queue behind one another (0.57x)
+    // [tools/rollout_bench.py].  Which regime a caller is in is not knowable from the arguments, so it is measured: the first
+    // roll-out of a (slot, batch) runs one sub-batch, the second two, each timed on the device by an event pair the NEXT call
+    // reads without blocking; from then on the faster of the two, the other one tried again every 64th call while it is within
+    // 20 % (a workload drifts).  WBCQP_ROLLOUT_STREAMS overrides (1 .. 8).  The result does not depend on the choice, bit for bit.
+    for (auto& mz : h->roll_meas) {
+        if (!mz.pending || hipEventQuery(mz.t1) != hipSuccess) continue;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, mz.t0, mz.t1) == hipSuccess && mz.ticks > 0 && mz.S >= 1 && mz.S <= 2 && mz.stat >= 0 &&
+            mz.stat < (int)h->roll_stats.size()) {
+            double& slot_us = h->roll_stats[mz.stat].us[mz.S];
+            const double us = (double)ms * 1e3 / mz.ticks;
+            slot_us = slot_us > 0.0 ? 0.5 * (slot_us + us) : us;
+        }
+        mz.pending = false;
+    }
+    (void)hipGetLastError(); // (hipEventQuery's hipErrorNotReady is not an error of this call)
+    int stat_i = -1;
+    for (size_t i = 0; i < h->roll_stats.size(); ++i)
+        if (h->roll_stats[i].slot == slot && h->roll_stats[i].batch == batch) stat_i = (int)i;
+    if (stat_i < 0) {
+        if (h->roll_stats.size() >= 64) { // (an index into the table is kept by the pending measurements: start over)
+            h->roll_stats.clear();
+            for (auto& mz : h->roll_meas) mz.stat = -1;
+        }
+        h->roll_stats.emplace_back();
+        stat_i = (int)h->roll_stats.size() - 1;
+        h->roll_stats[stat_i].slot = slot;
+        h->roll_stats[stat_i].batch = batch;
+    }
+    int S = 1;
+    {
+        auto& stt = h->roll_stats[stat_i];
+        if (batch >= 512) {
+            bool two_in_flight = false; // a roll-out with two sub-batches is on the device and not measured yet
+            for (const auto& mz : h->roll_meas) two_in_flight = two_in_flight || (mz.pending && mz.stat == stat_i && mz.S == 2);
+            if (stt.us[1] <= 0.0) S = 1;
+            else if (stt.us[2] <= 0.0) S = two_in_flight ? 1 : 2;
+            else {
+                S = stt.us[2] < stt.us[1] ? 2 : 1;
+                const int other = 3 - S;
+                if (stt.calls % 64 == 63 && stt.us[other] < 1.2 * stt.us[S]) S = other;
+            }
+        }
+        ++stt.calls;
+    }
     if (const char* ev = std::getenv("WBCQP_ROLLOUT_STREAMS")) S = std::max(1, std::min({std::atoi(ev), 8, batch}));
+    if (std::getenv("WBCQP_ROLLOUT_DEBUG"))
+        std::fprintf(stderr, "wbcqp_rollout: slot %d batch %d ticks %d -> %d sub-batch(es); measured us per tick: one %.1f, two %.1f\n", slot, batch,
+                     n_ticks, S, h->roll_stats[stat_i].us[1], h->roll_stats[stat_i].us[2]);
     for (int k = 0; k < S; ++k) { // the handle owns a sub-batch's stream, event and counters from the moment they exist (a failure half
         // way leaves them to wbcqp_destroy)
         if ((int)h->roll_subs.size() <= k) h->roll_subs.emplace_back();
@@ -1488,6 +1566,14 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
     if (had_roll) HIP_TRY(h, hipStreamWaitEvent(sm, h->roll_done, 0));
     HIP_TRY(h, hipMemcpyAsync(qbuf[0], io->state.q, (size_t)T.nq * B * es, hipMemcpyDeviceToDevice, sm));
     HIP_TRY(h, hipMemcpyAsync(vbuf[0], io->state.v, (size_t)T.nv * B * es, hipMemcpyDeviceToDevice, sm));
+    wbcqp_handle::RollMeas* meas = nullptr; // a free event pair: this roll-out is measured
+    for (auto& mz : h->roll_meas)
+        if (!mz.pending && !meas) meas = &mz;
+    if (meas) {
+        if (!meas->t0) HIP_TRY(h, hipEventCreate(&meas->t0));
+        if (!meas->t1) HIP_TRY(h, hipEventCreate(&meas->t1));
+        HIP_TRY(h, hipEventRecord(meas->t0, sm));
+    }
     HIP_TRY(h, hipEventRecord(h->roll_start, sm));
     auto at = [es](const void* p, size_t elems) -> const void* { return p ? static_cast<const char*>(p) + elems * es : nullptr; };
     auto atw = [es](void* p, size_t elems) -> void* { return p ? static_cast<char*>(p) + elems * es : nullptr; };
@@ -1522,13 +1608,9 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
             d.q_solver = last ? atw(io->q_solver, b0 * T.nv) : nullptr;
             d.dt = io->dt;
             h->graph_ord = &sub.ord; // this sub-batch's own launch-order state and queue counter (as a captured tick has)
-            rc_all = wbcqp_tick(h, slot, nb, &d, sub.stream);
+            const RollAcc acc = {io->out.iters + b0, io->iters_sum ? io->iters_sum + b0 : nullptr, io->ticks_ok ? io->ticks_ok + b0 : nullptr, t == 0 ? 1 : 0};
+            rc_all = tick_impl(h, slot, nb, &d, sub.stream, acc); // (the per-instance totals ride along with the integration)
             h->graph_ord = nullptr;
-            if (rc_all == WBCQP_OK && (io->iters_sum || io->ticks_ok)) {
-                hipLaunchKernelGGL(accumulate_kernel, dim3((nb + 255) / 256), dim3(256), 0, sub.stream, nb, t == 0 ? 1 : 0, io->out.iters + b0, io->out.status + b0,
-                                   io->iters_sum ? io->iters_sum + b0 : nullptr, io->ticks_ok ? io->ticks_ok + b0 : nullptr);
-                HIP_TRY(h, hipGetLastError());
-            }
         }
     }
     for (int k = 0; k < S; ++k) {
@@ -1536,6 +1618,10 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
         HIP_TRY(h, hipStreamWaitEvent(sm, h->roll_subs[k].done, 0));
     }
     HIP_TRY(h, hipEventRecord(h->roll_done, sm));
+    if (meas && rc_all == WBCQP_OK) {
+        HIP_TRY(h, hipEventRecord(meas->t1, sm));
+        meas->stat = stat_i; meas->S = S; meas->ticks = n_ticks; meas->pending = true;
+    }
     return rc_all;
 }
 

@@ -1052,16 +1052,6 @@ __global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<
 // iteration counts change little from one control tick to the next: the counts of the launch just finished order the
 // next launch of the same shape.  One workgroup, counting sort by min(iters, 63), descending.
 // ------------------------------------------------------------------------------------------------
-// wbcqp_rollout's per-instance totals over the ticks of a roll-out: active-set iterations and ticks whose QP was solved
-__global__ __launch_bounds__(256) void accumulate_kernel(int n, int first, const int* __restrict__ iters, const int* __restrict__ status,
-                                                         int* __restrict__ iters_sum, int* __restrict__ ticks_ok)
-{
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= n) return;
-    if (iters_sum) iters_sum[i] = (first ? 0 : iters_sum[i]) + iters[i];
-    if (ticks_ok) ticks_ok[i] = (first ? 0 : ticks_ok[i]) + (status[i] == HQP_OPTIMAL ? 1 : 0);
-}
-
 __global__ __launch_bounds__(1024) void schedule_kernel(const ScheduleArgs sa, int* order, int total)
 {
     __shared__ int hist[64];

@@ -150,14 +150,27 @@ __device__ __forceinline__ void integrate_one(const int nv, const int floating_b
     }
 }
 
+// wbcqp_rollout's per-instance totals over the ticks of a roll-out (active-set iterations, ticks whose QP was solved) ride along with
+// the integration of each tick: a kernel of their own was one more launch on every tick's critical path (2.4 % of a tick)
+struct RollAcc {
+    const int* iters;
+    int* iters_sum;
+    int* ticks_ok;
+    int first; // first tick of the roll-out: the totals start from zero
+};
+
 template <typename TI>
 __global__ __launch_bounds__(256) void integrate_kernel(int batch, int nv, int floating_base, double dt, const TI* __restrict__ q,
                                                         const TI* __restrict__ dq, const TI* __restrict__ x, int ldx,
                                                         const int* __restrict__ status, TI* __restrict__ q_next,
-                                                        TI* __restrict__ v_next, TI* __restrict__ q_solver)
+                                                        TI* __restrict__ v_next, TI* __restrict__ q_solver, const RollAcc acc)
 {
     const int inst = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (inst >= batch) return;
+    if (lane == 0) {
+        if (acc.iters_sum) acc.iters_sum[inst] = (acc.first ? 0 : acc.iters_sum[inst]) + acc.iters[inst];
+        if (acc.ticks_ok) acc.ticks_ok[inst] = (acc.first ? 0 : acc.ticks_ok[inst]) + ((!status || status[inst] == HQP_OPTIMAL) ? 1 : 0);
+    }
     const int nq = floating_base ? nv + 1 : nv;
     integrate_one<TI>(nv, floating_base, dt, q + (size_t)inst * nq, dq + (size_t)inst * nv, x + (size_t)inst * ldx, !status || status[inst] == HQP_OPTIMAL,
                       q_next + (size_t)inst * nq, v_next + (size_t)inst * nv, q_solver ? q_solver + (size_t)inst * nv : nullptr, lane);
