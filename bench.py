@@ -753,13 +753,17 @@ def main():
     tau_gpu = d_out["tau"].cpu().numpy()[:, :st.na].astype(np.float64)
 
     traffic = args.traffic
-    if traffic is None and args.robot == "talos" and not f32:
-        try:  # committed PMC measurement (separate --pmc passes), scaled to this launch's batch
+    pmc = None
+    if args.robot == "talos" and not f32:
+        try:  # committed PMC measurement (separate --pmc passes, tools/profile_round.sh + tools/profile_kernels.sh -> tools/pmc_summary.py)
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)
-            traffic = (2.0 * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024.0 * B / pmc["batch"]
         except Exception:
-            traffic = None
+            pmc = None
+    traffic_src = "--traffic" if traffic is not None else None
+    if traffic is None and pmc is not None:
+        traffic = (2.0 * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024.0 * B / pmc["batch"]  # scaled to this launch's batch
+        traffic_src = "profiles/pmc_latest.json (committed rocprofv3 PMC passes of round %s, not measured by this run)" % pmc.get("round")
 
     result = None
     if rank == 0:
@@ -794,6 +798,7 @@ def main():
                        "qps_resident_per_cu": per_cu},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": kernel, "kernel_ms": kern_avg_s * 1e3,
                          "algorithmic_bytes_per_qp": abytes},
             "active_set": {"iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
@@ -802,6 +807,19 @@ def main():
                            "note": "a launch cannot end before its longest QP does: with 512 resident workgroups a 1024-QP launch of this stream is "
                                    "bounded by the one QP that takes iters_max iterations (DESIGN.md section 4, stragglers)"},
         }
+        if pmc is not None and B == pmc.get("batch") and stream and world == 1:
+            # the two other rooflines SURVEY 8(d) asks for beside HBM, from the COMMITTED counter passes (same workload, same batch): the
+            # counted bytes / flops per launch over THIS run's launch time
+            src = "profiles/pmc_latest.json (committed rocprofv3 PMC passes of round %s; counts per launch from there, time from this run)" % pmc.get("round")
+            if "lds" in pmc and "bytes_per_launch" in pmc["lds"]:
+                a = pmc["lds"]["bytes_per_launch"] / kern_avg_s / 1e12
+                result["roofline"]["lds"] = {"bound": "lds", "achieved": a, "peak": 150.0, "unit": "TB/s", "frac": a / 150.0,
+                                             "bank_conflict_share_of_active": pmc["lds"].get("bank_conflict_share_of_active"), "source": src}
+            if "fp64" in pmc:
+                a = pmc["fp64"]["flops_per_launch_issued"] / kern_avg_s / 1e12
+                result["roofline"]["fp64"] = {"bound": "vector f64", "achieved": a, "peak": 78.6, "unit": "TFLOP/s", "frac": a / 78.6,
+                                              "f64_share_of_valu": pmc["fp64"].get("f64_share_of_valu"), "source": src,
+                                              "note": "issued lane-flops (counted instructions x 64): an upper bound on useful flops"}
         flops = st.flops_estimate(float(iters.mean()))
         result["fp64"] = {"flops_per_qp": flops, "achieved_TFLOPs": flops * B / kern_avg_s / 1e12,
                           "note": "analytic useful flops (Structure.flops_estimate) at the batch's mean iteration count; the path is a "

@@ -1564,8 +1564,7 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
     // the sub-streams of the previous roll-out may still be on the ping-pong buffers and the record when this one comes in on
     // another stream: wait for that roll-out's end first (on the same stream the wait is already implied)
     if (had_roll) HIP_TRY(h, hipStreamWaitEvent(sm, h->roll_done, 0));
-    HIP_TRY(h, hipMemcpyAsync(qbuf[0], io->state.q, (size_t)T.nq * B * es, hipMemcpyDeviceToDevice, sm));
-    HIP_TRY(h, hipMemcpyAsync(vbuf[0], io->state.v, (size_t)T.nv * B * es, hipMemcpyDeviceToDevice, sm));
+    // (the first tick reads the caller's q / v in place: no copy into the ping-pong buffers)
     wbcqp_handle::RollMeas* meas = nullptr; // a free event pair: this roll-out is measured
     for (auto& mz : h->roll_meas)
         if (!mz.pending && !meas) meas = &mz;
@@ -1603,8 +1602,8 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
             d.out.status = io->out.status + b0; d.out.iters = io->out.iters + b0;
             d.out.n_active = io->out.n_active ? io->out.n_active + b0 : nullptr;
             d.out.active_mask = io->out.active_mask ? io->out.active_mask + b0 * 8 : nullptr;
-            d.state.q = qbuf[t & 1] + b0 * T.nq * es;
-            d.state.v = vbuf[t & 1] + b0 * T.nv * es;
+            d.state.q = (t == 0) ? at(io->state.q, b0 * T.nq) : (const void*)(qbuf[t & 1] + b0 * T.nq * es);
+            d.state.v = (t == 0) ? at(io->state.v, b0 * T.nv) : (const void*)(vbuf[t & 1] + b0 * T.nv * es);
             d.state.ref = at(io->state.ref, ((size_t)t * B + b0) * T.nref);
             d.state.momentum = last ? atw(io->state.momentum, b0 * 6) : nullptr;
             d.q_next = last ? atw(io->q_next, b0 * T.nq) : (void*)(qbuf[(t + 1) & 1] + b0 * T.nq * es);

@@ -32,7 +32,10 @@ def main():
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
     keep = ["bench.json", "sweep.json", "kernel_stats.csv", "pmc_fetch_size.csv", "pmc_write_size.csv", "pmc_sq.csv", "phase.txt", "phase_model.txt",
-            "terms_phase.txt", "tick_latency.json", "straggler.txt", "straggler_product.json", "bench_franka_b8192.json", "rollout_bench.json"]
+            "terms_phase.txt", "tick_latency.json", "straggler.txt", "straggler_product.json", "bench_franka_b8192.json", "rollout_bench.json",
+            # tools/profile_kernels.sh: the limiter's counters and a kernel trace for every other kernel a number is quoted for
+            "pmc_lds.csv", "pmc_ldsbw.csv", "pmc_f64.csv", "pmc_issue.csv", "pmc_rows_sq.csv", "kernel_stats_franka_b8192.csv", "kernel_stats_dense.csv",
+            "kernel_stats_rows.csv", "kernel_stats_rollout.csv", "trace_dense.log", "trace_rows.log"]
     for f in keep:
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
@@ -58,6 +61,54 @@ def main():
                            "valu_per_wave": mean(sq, "SQ_INSTS_VALU")[0] / waves, "salu_per_wave": mean(sq, "SQ_INSTS_SALU")[0] / waves,
                            "lds_per_wave": mean(sq, "SQ_INSTS_LDS")[0] / waves,
                            "note": "per wave of a launch; a wave slot of the 512 resident workgroups solves 2 QPs of a 1024-QP launch: halve for per-QP figures"}}
+    # ---- what names the limiter (tools/profile_kernels.sh passes; absent files leave the keys out) ----
+    kern_ms = None
+    try:
+        for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
+            if kern in r["Name"]:
+                kern_ms = float(r["AverageNs"]) * 1e-6
+    except OSError:
+        pass
+    out["kernel_ms_traced"] = kern_ms
+
+    def have(name):
+        return os.path.exists(os.path.join(src, name))
+
+    if have("pmc_f64.csv") and kern_ms:
+        f = per_dispatch(os.path.join(src, "pmc_f64.csv"), kern)
+        fma, add, mul, tr = (mean(f, "SQ_INSTS_VALU_%s_F64" % k)[0] for k in ("FMA", "ADD", "MUL", "TRANS"))
+        valu = mean(f, "SQ_INSTS_VALU")[0]
+        flops = 64.0 * (2.0 * fma + add + mul + tr)
+        out["fp64"] = {"bound": "vector f64", "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                       "frac": flops / (kern_ms * 1e-3) / 1e12 / 78.6, "flops_per_launch_issued": flops,
+                       "insts_per_launch": {"VALU": valu, "FMA_F64": fma, "ADD_F64": add, "MUL_F64": mul, "TRANS_F64": tr,
+                                            "INT32": mean(f, "SQ_INSTS_VALU_INT32")[0], "INT64": mean(f, "SQ_INSTS_VALU_INT64")[0]},
+                       "f64_share_of_valu": (fma + add + mul + tr) / valu,
+                       "note": "counted instructions x 64 lanes (2 flops per FMA): what the SIMDs ISSUED, masked lanes and redundant per-thread copies "
+                               "of wave-uniform arithmetic included -- an upper bound on useful flops (bench.py's analytic figure: Structure.flops_estimate)"}
+    if have("pmc_lds.csv") and kern_ms:
+        l = per_dispatch(os.path.join(src, "pmc_lds.csv"), kern)
+        idx, conf = mean(l, "SQ_LDS_IDX_ACTIVE")[0], mean(l, "SQ_LDS_BANK_CONFLICT")[0]
+        lcyc = mean(l, "SQ_WAVE_CYCLES")[0]
+        out["lds"] = {"idx_active": idx, "bank_conflict": conf, "bank_conflict_share_of_active": conf / idx, "addr_conflict": mean(l, "SQ_LDS_ADDR_CONFLICT")[0],
+                      "insts_per_wave": mean(l, "SQ_INSTS_LDS")[0] / mean(l, "SQ_WAVES")[0],
+                      "wave_cycles_issuing_lds": mean(l, "SQ_ACTIVE_INST_LDS")[0] / lcyc, "wave_cycles_stalled_on_lds_issue": mean(l, "SQ_WAIT_INST_LDS")[0] / lcyc}
+        if have("pmc_ldsbw.csv"):
+            b = per_dispatch(os.path.join(src, "pmc_ldsbw.csv"), kern)
+            ld, stv = mean(b, "SQ_INSTS_LDS_LOAD_BANDWIDTH")[0], mean(b, "SQ_INSTS_LDS_STORE_BANDWIDTH")[0]
+            nbytes = 64.0 * (ld + stv)
+            out["lds"].update({"bound": "lds", "bytes_per_launch": nbytes, "achieved": nbytes / (kern_ms * 1e-3) / 1e12, "peak": 150.0, "unit": "TB/s",
+                               "frac": nbytes / (kern_ms * 1e-3) / 1e12 / 150.0,
+                               "load_insts": mean(b, "SQ_INSTS_LDS_LOAD")[0], "store_insts": mean(b, "SQ_INSTS_LDS_STORE")[0],
+                               "unaligned_stall": mean(b, "SQ_LDS_UNALIGNED_STALL")[0],
+                               "note": "bytes = (SQ_INSTS_LDS_LOAD_BANDWIDTH + SQ_INSTS_LDS_STORE_BANDWIDTH) x 64 B (the counters step once per 64 bytes "
+                                       "moved: 12.7 per load instruction = the mix of 8-byte and 16-byte wave64 reads this kernel issues); peak = the "
+                                       "guide's aggregate for ds_read_b64 / b128 with every CU streaming (MI355X_MICROARCH.md, LDS section)"})
+    if have("pmc_issue.csv"):
+        q = per_dispatch(os.path.join(src, "pmc_issue.csv"), kern)
+        qc = mean(q, "SQ_WAVE_CYCLES")[0]
+        out["issue"] = {"valu": mean(q, "SQ_ACTIVE_INST_VALU")[0] / qc, "scalar": mean(q, "SQ_ACTIVE_INST_SCA")[0] / qc, "lds": mean(q, "SQ_ACTIVE_INST_LDS")[0] / qc,
+                        "vmem": mean(q, "SQ_ACTIVE_INST_VMEM")[0] / qc, "note": "share of a wave's cycles in which it has an instruction of that kind in flight"}
     with open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w") as fh:
         json.dump(out, fh, indent=1)
     with open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w") as fh:
