@@ -1025,16 +1025,16 @@ int wbcqp_launch_order(wbcqp_handle* h, int32_t* order, int32_t capacity, int32_
     return o.total;
 }
 
+#ifdef WBCQP_STAMPS
+// exported by the DIAGNOSTIC library only (libwbcqp_stamps.so, inria_wbc_amd/build.py --stamps): the product library exports exactly
+// what include/wbcqp.h declares
 int wbcqp_debug_set_stamp_buffer(wbcqp_handle* h, void* dev_ptr)
 {
     if (!h) return WBCQP_ERR_INVALID;
     h->dbg = static_cast<long long*>(dev_ptr);
-#ifdef WBCQP_STAMPS
     return WBCQP_OK;
-#else
-    return WBCQP_ERR_UNSUPPORTED;
-#endif
 }
+#endif
 
 static int integrate_impl(wbcqp_handle* h, int batch, int nv, int floating_base, double dt, const void* q, const void* dq, const void* x,
                           int ldx, const int32_t* status, void* q_next, void* v_next, void* q_solver, void* stream, const RollAcc& acc);

@@ -44,6 +44,11 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(built_lib)
     for sym in declared:
         assert hasattr(lib, sym), sym
+    # and nothing else: the product library's dynamic symbol table holds the declared entry points only
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", built_lib], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln and ln.split()[-1].startswith("wbcqp_")}
+    assert exported == declared, exported ^ declared
     assert lib.wbcqp_version() == 150
 
 
