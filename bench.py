@@ -375,7 +375,7 @@ def dense_seam(local_rank, st, inputs, cpu=True):
                 res[key + "_us"] = float(w[1])
                 res[key + "_min_us"] = float(w[3])
             elif w and w[0] == "status":
-                res["iters"] = int(w[4])
+                res["iters"] = int(w[5])
                 res["agree_max_dx"] = float(w[-1])
     except Exception as e:  # noqa: BLE001
         res["from_c_error"] = "%s: %s" % (type(e).__name__, e)

@@ -12,6 +12,10 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, nargs="*", default=[1, 256], help="batch sizes to time (one per rocprofv3 trace keeps their rows apart)")
+    args = ap.parse_args()
     import torch
     from inria_wbc_amd import capi, structure, synth
     from oracle import oracle
@@ -24,7 +28,7 @@ def main():
     full = {k: torch.from_numpy(np.ascontiguousarray(np.stack([m[j] for m in mats]))).to(dev) for j, k in enumerate(names)}
     h = capi.Handle(0, capi.F64)
     sp = torch.cuda.current_stream().cuda_stream
-    for B in (1, 256):
+    for B in args.batch:
         din = {k: v[:B].contiguous() for k, v in full.items()}
         out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), status=torch.full((B,), -99, dtype=torch.int32, device=dev),
                    iters=torch.zeros(B, dtype=torch.int32, device=dev))

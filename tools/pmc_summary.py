@@ -34,8 +34,9 @@ def main():
     keep = ["bench.json", "sweep.json", "kernel_stats.csv", "pmc_fetch_size.csv", "pmc_write_size.csv", "pmc_sq.csv", "phase.txt", "phase_model.txt",
             "terms_phase.txt", "tick_latency.json", "straggler.txt", "straggler_product.json", "bench_franka_b8192.json", "rollout_bench.json",
             # tools/profile_kernels.sh: the limiter's counters and a kernel trace for every other kernel a number is quoted for
-            "pmc_lds.csv", "pmc_ldsbw.csv", "pmc_f64.csv", "pmc_issue.csv", "pmc_rows_sq.csv", "kernel_stats_franka_b8192.csv", "kernel_stats_dense.csv",
-            "kernel_stats_rows.csv", "kernel_stats_rollout.csv", "trace_dense.log", "trace_rows.log"]
+            "pmc_lds.csv", "pmc_ldsbw.csv", "pmc_f64.csv", "pmc_issue.csv", "pmc_rows_sq.csv", "kernel_stats_franka_b8192.csv", "kernel_stats_dense_b1.csv",
+            "kernel_stats_dense_b256.csv", "kernel_stats_rows.csv", "kernel_stats_rollout.csv", "trace_dense_b1.log", "trace_dense_b256.log", "trace_rows.log",
+            "rollout_grid.log"]
     for f in keep:
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))

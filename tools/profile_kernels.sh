@@ -26,7 +26,8 @@ trace() { # name, command...
     rm -rf $OUT/$name
 }
 trace franka_b8192 python3 $ROOT/bench.py --robot franka --batch 8192 --steps 200 --warmup 20 --headline-only
-trace dense python3 $ROOT/tools/dense_time.py
+trace dense_b1 python3 $ROOT/tools/dense_time.py --batch 1
+trace dense_b256 python3 $ROOT/tools/dense_time.py --batch 256
 trace rows python3 $ROOT/tools/terms_profile.py --time $ROOT/inria_wbc_amd/lib/libwbcqp.so
 trace rollout python3 $ROOT/tools/rollout_bench.py
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $OUT/rows_sq -- python3 $ROOT/tools/terms_profile.py --time $ROOT/inria_wbc_amd/lib/libwbcqp.so > $OUT/rows_sq.log 2>&1
@@ -34,4 +35,4 @@ find $OUT/rows_sq -name "*counter_collection.csv" -exec cp {} $OUT/pmc_rows_sq.c
 rm -rf $OUT/rows_sq
 ls -la $OUT | head -40
 for f in $OUT/kernel_stats_*.csv; do echo $f; head -4 $f | cut -c1-200; done
-tail -3 $OUT/trace_dense.log $OUT/trace_rows.log
+grep -h "us per launch" $OUT/trace_dense_b1.log $OUT/trace_dense_b256.log $OUT/trace_rows.log
