@@ -32,10 +32,11 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="wbcqp_desc.flags (16: the full LDS layout of round 1)")
     ap.add_argument("--first", type=int, default=0, help="index of the first instance in the seeded stream (with --squat: its tick)")
     ap.add_argument("--squat", action="store_true", help="CoM rows follow the squat stream (bench.py's workload): heavier tail")
+    ap.add_argument("--lib", default=None, help="a stamped variant (built with -DWBCQP_STAMPS and other switches) instead of libwbcqp_stamps.so")
     args = ap.parse_args()
     import torch
     from inria_wbc_amd import capi, structure, synth
-    capi.LIB_PATH = os.path.join(ROOT, "inria_wbc_amd", "lib", "libwbcqp_stamps.so")
+    capi.LIB_PATH = os.path.abspath(args.lib) if args.lib else os.path.join(ROOT, "inria_wbc_amd", "lib", "libwbcqp_stamps.so")
     lib = capi.load_library(capi.LIB_PATH)
     st = structure.STRUCTURES[args.robot]()
     B = args.batch
