@@ -20,11 +20,14 @@ EPS = np.finfo(float).eps
 OPTIMAL, INFEASIBLE, MAX_ITER, ERROR = 0, 1, 3, 4
 
 
-def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False):
+def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False, store=None):
+    """store=np.float32: SURVEY section 7's "fp32 storage, fp64 accumulate" option, modelled: J and Ri -- the two arrays that live in LDS for
+    the whole loop -- are rounded to `store` after every update, every product and sum stays in f64 (tools/f32_storage_probe.py)."""
     n = g.size
+    rnd = (lambda a: a) if store is None else (lambda a: a.astype(store).astype(np.float64))
     neq, m = CE.shape[0], CI.shape[0]
     U = np.linalg.cholesky(H).T
-    J = np.linalg.inv(U)
+    J = rnd(np.linalg.inv(U))
     c1, c2 = np.trace(H), np.trace(J)
     x = -J @ (J.T @ g)
     iq = 0
@@ -34,7 +37,7 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False):
         Q, Rq = np.linalg.qr(B, mode="complete")
         if np.any(np.abs(np.diag(Rq[:neq])) <= EPS * max(1.0, np.abs(np.diag(Rq[:neq])).max())):
             return dict(x=x, status=ERROR, iters=0)
-        J = J @ Q
+        J = rnd(J @ Q)
         y = np.linalg.solve(Rq[:neq].T, -(CE @ x + ce0))
         x = x + J[:, :neq] @ y
         iq = neq
@@ -118,8 +121,8 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False):
                     cc, ss = b / hh, -a / hh
                     for Mx, c0 in ((Z, p + j), (J, neq + p + j)):
                         t1c, t2c = Mx[:, c0].copy(), Mx[:, c0 + 1].copy()
-                        Mx[:, c0] = cc * t1c + ss * t2c
-                        Mx[:, c0 + 1] = ss * t1c - cc * t2c
+                        Mx[:, c0] = rnd(cc * t1c + ss * t2c)
+                        Mx[:, c0 + 1] = rnd(ss * t1c - cc * t2c)
                     da, db = d[neq + p + j], d[neq + p + j + 1]
                     d[neq + p + j] = cc * da + ss * db
                     d[neq + p + j + 1] = ss * da - cc * db
@@ -154,7 +157,7 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False):
                 v[0] -= alpha
                 tau = 1.0 / (nx * abs(diq) + dn2)
                 w = tau * (z - alpha * J[:, iq])
-                J[:, iq:] -= np.outer(w, v)
+                J[:, iq:] = rnd(J[:, iq:] - np.outer(w, v))
             if abs(alpha) <= EPS * R_norm:  # dependent: back to the saved iterate, pick another
                 excl[ip] = False
                 for i in range(min(iq, len(A_old))):
@@ -168,8 +171,8 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False):
                 x = x_old.copy()
                 continue
             mi = iq - neq
-            Ri[:mi, mi] = -r / alpha
-            Ri[mi, mi] = 1.0 / alpha
+            Ri[:mi, mi] = rnd(-r / alpha)
+            Ri[mi, mi] = rnd(np.array(1.0 / alpha))
             Ri[mi, :mi] = 0.0
             R_norm = max(R_norm, abs(alpha))
             act[ip] = True
