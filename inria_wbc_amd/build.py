@@ -59,6 +59,14 @@ def build_host(verbose: bool = False) -> dict:
     link = ["-L", LIBDIR, "-lwbcqp", "-Wl,-rpath," + LIBDIR]
     lib = os.path.join(LIBDIR, "libinria_wbc_hip.so")
     out = {"lib": lib, "test_facade": os.path.join(LIBDIR, "test_facade"), "qp_timer_test": os.path.join(LIBDIR, "qp_timer_test")}
+    # (nothing to do when the three outputs are newer than every source of the facade, the C ABI header and the library)
+    deps = [LIB, os.path.join(_HERE, "..", "include", "wbcqp.h"), os.path.abspath(__file__)]
+    for root, _, files in os.walk(HOST):
+        deps += [os.path.join(root, f) for f in files if f.endswith((".hpp", ".cpp", ".h"))]
+    if all(os.path.exists(o) for o in out.values()):
+        oldest = min(os.path.getmtime(o) for o in out.values())
+        if all(os.path.getmtime(d) <= oldest for d in deps):
+            return out
     cmds = [
         common + ["-fPIC", "-shared", os.path.join(HOST, "src", "registry.cpp"), "-o", lib] + link,
         common + [os.path.join(HOST, "tests", "test_facade.cpp"), os.path.join(HOST, "src", "registry.cpp"), "-o", out["test_facade"]] + link,
