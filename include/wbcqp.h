@@ -143,7 +143,9 @@ typedef struct {
                                   kernel that WBCQP_FLAG_WORKGROUP_PER_QP selects */
     int32_t dense_h;           /* 1: the stack has a torque or a cop task -- full layout, H factored as one n x n matrix (never compact) */
     int32_t len_Acop;          /* element count of wbcqp_inputs.Acop: 3 * 12 nc with a cop task, else 0 */
-    int32_t reserved_;
+    int32_t specialised;       /* > 0: the library holds an instantiation of the compact kernel with THIS layout's sizes and offsets as literals
+                                  (the shipped stacks: 1 Talos, 2 iCub, 3 Talos in single support); a launch of one such group runs it unless
+                                  WBCQP_FLAG_GENERIC_KERNEL.  Bit for bit the generic kernel's results, about 10 % less time per QP */
 } wbcqp_layout;
 
 /*
@@ -214,6 +216,8 @@ typedef struct {
                                     counts them, tests/test_gpu_warm.py bounds them).  What it buys: the add / drop churn of a cold
                                     start is avoided, iteration counts fall to about the number of constraints active at the solution.
                                     eiquadprog-fast has no such thing: bench.py reports it BESIDE the headline, never as it */
+#define WBCQP_FLAG_GENERIC_KERNEL 128 /* never the shipped stacks' own instantiations of the compact kernel (wbcqp_layout.specialised): the generic
+                                     kernel for every structure (what the specialised ones are tested against, bit for bit) */
 #define WBCQP_FLAG_REFRESH_SHIFT 8
 #define WBCQP_FLAG_REFRESH(n) (((n) & 0xff) << WBCQP_FLAG_REFRESH_SHIFT) /* renew the launch order every n-th launch of a shape
                                     (1: after every launch; 0: the default, 4).  Between renewals the same order is used:

@@ -6,9 +6,11 @@ inria_wbc_amd/lib/ (git-ignored, but shipped to the GPU box with the working tre
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 import sys
+import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -79,12 +81,46 @@ def build_host(verbose: bool = False) -> dict:
     return out
 
 
+DEVICE_ASM = os.path.join(LIBDIR, "wbcqp_device.s")
+_MEM = re.compile(r"^\s*(ds_|s_load|s_buffer_load|s_store|s_atomic|s_dcache|flat_)")  # whatever counts on lgkmcnt (flat: it may)
+
+
+def check_barriers(path: str):
+    """(number of s_barrier, [(function, line)] of those not preceded -- in their own basic block, with no LDS / scalar-memory
+    instruction in between -- by an s_waitcnt carrying lgkmcnt(0)).  tools/check_barriers.py is the command-line form."""
+    bad, total, fn = [], 0, None
+    with open(path) as f:
+        lines = f.read().splitlines()
+    for i, ln in enumerate(lines):
+        s = ln.strip()
+        m = re.match(r"^([A-Za-z_][\w.$]*):\s*;\s*@", s)
+        if m:
+            fn = m.group(1)
+        if not s.startswith("s_barrier"):
+            continue
+        total += 1
+        ok = False
+        for j in range(i - 1, max(i - 400, -1), -1):
+            t = lines[j].strip()
+            if not t or t.startswith(";"):
+                continue
+            if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+                ok = True
+                break
+            if t.startswith(".LBB") or t.endswith(":") or _MEM.match(t) or t.startswith("s_barrier"):
+                break
+        if not ok:
+            bad.append((fn, i + 1))
+    return total, bad
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    tmpdir = tempfile.mkdtemp(prefix="wbcqp_build_")
     cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}",
-           "-fno-gpu-rdc", "-ffp-contract=on", "-Wall", "-Wno-unused-function",
+           "-fno-gpu-rdc", "-ffp-contract=on", "-Wall", "-Wno-unused-function", "-save-temps=cwd",
            *extra_flags,
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp", "-ldl"]
     if verbose:
@@ -95,7 +131,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     # i.e. under a partial EXEC mask -- values came back corrupted in the other lanes (non-deterministic results in the
     # diagnostic build; tools/chk_lib.py, tests/test_gpu_parity.py::test_diagnostic_build_is_a_canary).
     cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=tmpdir)
     usage = _resource_usage(proc.stdout)
     if proc.returncode != 0:
         sys.stderr.write(proc.stdout)
@@ -108,6 +144,17 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         if ("solve_kernel" in name or "solve_queue_kernel" in name or "terms_kernel" in name) and (u.get("AGPRs", 0) != 0 or u.get("ScratchSize [bytes/lane]", 0) != 0 or u.get("VGPRs Spill", 0) != 0):
             raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, VGPR spills %s -- refuse to ship (see the comment in build.py)" %
                                (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("VGPRs Spill")))
+    # The device assembly is part of the build too: every workgroup barrier must wait for the wave's own LDS traffic first
+    # (tools/check_barriers.py says why; bsync() in wbcqp_prims.hpp issues the wait).
+    asm = [f for f in os.listdir(tmpdir) if f.endswith("gfx950.s")]
+    if len(asm) != 1:
+        raise RuntimeError("no device assembly among the build's temporaries: %s" % sorted(os.listdir(tmpdir)))
+    total, bad = check_barriers(os.path.join(tmpdir, asm[0]))
+    if bad or total == 0:
+        shutil.copy(os.path.join(tmpdir, asm[0]), DEVICE_ASM + ".refused")
+        raise RuntimeError("%d of %d s_barrier without a preceding s_waitcnt lgkmcnt(0): %s ... -- refuse to ship (assembly kept as %s.refused)" %
+                           (len(bad), total, bad[:4], DEVICE_ASM))
+    shutil.rmtree(tmpdir, ignore_errors=True)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

@@ -56,7 +56,7 @@ class CStructure(C.Structure):
 class CLayout(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n", "neq", "nin", "nin2", "r1", "len_M", "len_h", "len_A", "len_b1", "len_Ac",
                                          "len_bc", "len_blb", "len_bub", "len_tlb", "len_tub", "len_w", "lds_bytes",
-                                         "waves_per_cu")] + [("algorithmic_bytes", C.c_int64), ("wave_per_qp", C.c_int32), ("dense_h", C.c_int32), ("len_Acop", C.c_int32), ("reserved_", C.c_int32)]
+                                         "waves_per_cu")] + [("algorithmic_bytes", C.c_int64), ("wave_per_qp", C.c_int32), ("dense_h", C.c_int32), ("len_Acop", C.c_int32), ("specialised", C.c_int32)]
 
 
 class CInputs(C.Structure):
@@ -279,6 +279,7 @@ FLAG_QUEUE = 8        # wbcqp_desc.flags: the queue also when several workgroups
 FLAG_FULL_LDS = 16    # wbcqp_desc.flags: keep the one-QP-per-CU LDS layout (default: compact layout, two QPs per CU, where eligible)
 FLAG_WARM_START = 64  # wbcqp_desc.flags: OPT-IN pick priority for the rows of outputs["active_mask"] (not eiquadprog's rule; include/wbcqp.h)
 FLAG_WORKGROUP_PER_QP = 32  # wbcqp_desc.flags: four waves per QP also for n <= 16 (default there: one wavefront per QP, wbcqp_small.hpp)
+FLAG_GENERIC_KERNEL = 128  # wbcqp_desc.flags: the generic compact kernel also for the shipped stacks (default: their own instantiations)
 FLAG_HW_DISPATCH = 2  # wbcqp_desc.flags: one workgroup per QP through the hardware dispatcher (default: resident workgroups + queue)
 
 

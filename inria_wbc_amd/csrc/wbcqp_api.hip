@@ -36,6 +36,7 @@ struct Slot {
     wbcqp_layout layout{};      // what wbcqp_layout_of reports: the compact layout where the structure is eligible
     int lds_full = 0, lds_cp = 0;
     bool small = false;         // eligible for the one-wavefront-per-QP kernel (wbcqp_small.hpp)
+    int spec = 0;               // 1-based index of the compact kernel's instantiation for this very layout (kSpecDims), 0: the generic kernel
     std::vector<int> sel_col_h;       // host copies of what wbcqp_set_model needs of the structure: the posture task's columns
     std::vector<double> force_gen_h;  // and the contacts' force generators (the contact points sit in their skew blocks)
     bool has_model = false;     // wbcqp_set_model: tree + task bindings for wbcqp_problem_data
@@ -84,7 +85,8 @@ struct wbcqp_handle {
     Slot slots[WBCQP_MAX_STRUCTURES];
     Staging stage_in, stage_out;
     Pinned pin_in, pin_out;
-    int max_lds[2] = {0, 0};   // per kernel variant (full, compact): largest dynamic LDS size set so far
+    // per kernel variant (0: full layout, 1: compact, 2 + i: the compact kernel specialised for kSpecDims[i]): largest dynamic LDS size set so far
+    int max_lds[2 + kNumSpecs] = {};
     long long* dbg = nullptr; // diagnostic builds only (wbcqp_debug_set_stamp_buffer)
     // longest-first schedule (schedule_kernel): launch order for the next solve of the same shape on the same stream
     int flags = 0;
@@ -105,7 +107,7 @@ struct wbcqp_handle {
     std::vector<int32_t> dense_status, dense_iters, dense_nact;
     wbcqp_dense_output dense_out{};
     int lds_pad = 0; // diagnostic (env WBCQP_DEBUG_LDS_PAD): extra dynamic LDS per workgroup, to force a lower residency
-    int queue_lds[2] = {-1, -1}, queue_occ[2] = {0, 0}; // occupancy of solve_queue_kernel<., CP> at queue_lds bytes of LDS
+    int queue_lds[2 + kNumSpecs], queue_occ[2 + kNumSpecs] = {}; // occupancy of solve_queue_kernel<., CP, SPEC> at queue_lds bytes of LDS
     // wbcqp_rollout: sub-batches on streams of their own (each with its own launch-order state and queue counter), the record
     // arrays and the state ping-pong of the whole batch
     struct RollSub {
@@ -379,15 +381,16 @@ int check_io(wbcqp_handle* h, const Slot& s, int batch, const wbcqp_inputs* in, 
     return WBCQP_OK;
 }
 
-template <typename TI, bool CP>
+template <typename TI, bool CP, int SPEC = 0>
 int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipStream_t stream)
 {
+    static_assert(SPEC == 0 || CP, "only the compact kernel is specialised");
     if (total == 0) return WBCQP_OK;
-    constexpr int V = CP ? 1 : 0;
+    constexpr int V = SPEC > 0 ? 1 + SPEC : (CP ? 1 : 0);
     if (lds_bytes > h->max_lds[V]) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<TI, CP>),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<TI, CP, SPEC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel<TI, CP>),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel<TI, CP, SPEC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         h->max_lds[V] = lds_bytes;
     }
@@ -427,7 +430,7 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     // against 36 M through the hardware.  WBCQP_FLAG_QUEUE forces the queue, WBCQP_FLAG_HW_DISPATCH the dispatcher.
     if (h->queue_lds[V] != lds_bytes) {
         int occ = 0;
-        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI, CP>, kThreads, (size_t)lds_bytes));
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI, CP, SPEC>, kThreads, (size_t)lds_bytes));
         if (occ < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel: no workgroup fits a CU");
         h->queue_occ[V] = occ;
         h->queue_lds[V] = lds_bytes;
@@ -443,11 +446,11 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     }
     if (queue) {
         const long long resident = (long long)queue_occ * h->n_cu;
-        hipLaunchKernelGGL((solve_queue_kernel<TI, CP>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
+        hipLaunchKernelGGL((solve_queue_kernel<TI, CP, SPEC>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
                            stream, tab, queue, total);
     }
     else
-        hipLaunchKernelGGL((solve_kernel<TI, CP>), dim3(total), dim3(kThreads), lds_bytes, stream, tab);
+        hipLaunchKernelGGL((solve_kernel<TI, CP, SPEC>), dim3(total), dim3(kThreads), lds_bytes, stream, tab);
     HIP_TRY(h, hipGetLastError());
     // the order is renewed every `period` launches: iteration counts drift slowly from tick to tick, the queue absorbs what
     // drift there is, and the two order kernels (4.5 + 15 us) are then a fraction of a launch instead of a twentieth
@@ -538,7 +541,15 @@ int wbcqp_layout_of(const wbcqp_structure* st, wbcqp_layout* out)
     int rc = derive(st, D, HB, L, why);
     if (rc != WBCQP_OK) return fail(nullptr, rc, why);
     DevStruct C;
-    if (derive_compact(D, C)) set_lds(L, C.lds_doubles * 8);
+    if (derive_compact(D, C)) {
+        set_lds(L, C.lds_doubles * 8);
+        L.specialised = spec_of(C);
+    }
+    // how a row of kSpecDims (wbcqp_types.hpp) is made: the derived sizes and offsets of a stack, in the order of struct Dims
+    if (std::getenv("WBCQP_DEBUG_DUMP_STRUCT") && C.compact)
+        std::fprintf(stderr, "compact: nv %d na %d nc %d k %d n %d nu %d n_dense %d n_tasks %d n_sel %d n_bound %d act_bounds %d neq %d nin2 %d r1 %d max_iter %d "
+                     "ldj %d ldb %d o_J %d o_R %d o_vec %d o_int %d o_pan %d act_off %d lds_doubles %d\n", C.nv, C.na, C.nc, C.k, C.n, C.nu, C.n_dense, C.n_tasks,
+                     C.n_sel, C.n_bound, C.act_bounds, C.neq, C.nin2, C.r1, C.max_iter, C.ldj, C.ldb, C.o_J, C.o_R, C.o_vec, C.o_int, C.o_pan, C.act_off, C.lds_doubles);
     L.wave_per_qp = small_ok(D, HB) ? 1 : 0;
     if (out) *out = L;
     return WBCQP_OK;
@@ -565,6 +576,7 @@ int wbcqp_create(const wbcqp_desc* desc, wbcqp_handle** out)
     h->dtype = desc->dtype;
     h->flags = desc->flags;
     h->n_cu = prop.multiProcessorCount;
+    for (int& q : h->queue_lds) q = -1;
     if (const char* pad = std::getenv("WBCQP_DEBUG_LDS_PAD")) h->lds_pad = std::atoi(pad);
     *out = h;
     return WBCQP_OK;
@@ -691,6 +703,8 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     }
     s.small = small_ok(D, HB);
     L.wave_per_qp = s.small ? 1 : 0;
+    s.spec = s.host_cp.compact ? spec_of(s.host_cp) : 0;
+    L.specialised = s.spec;
     s.layout = L;
     s.set = true;
     return WBCQP_OK;
@@ -744,8 +758,28 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
         const int rc = (h->dtype == WBCQP_F64) ? launch_small<double>(h, s64, total_small, hs) : launch_small<float>(h, s32, total_small, hs);
         if (rc != WBCQP_OK) return rc;
     }
-    if (h->dtype == WBCQP_F64) return compact ? launch<double, true>(h, t64, total, lds, hs) : launch<double, false>(h, t64, total, lds, hs);
-    return compact ? launch<float, true>(h, t32, total, lds, hs) : launch<float, false>(h, t32, total, lds, hs);
+    // a launch of ONE group whose structure is a shipped stack takes that stack's instantiation of the compact kernel (sizes and offsets as
+    // literals: wbcqp_types.hpp); anything else -- ragged launches, other structures, WBCQP_FLAG_GENERIC_KERNEL -- the generic one.  Same bits.
+    int spec = 0;
+    if (compact && used == 1 && !(h->flags & WBCQP_FLAG_GENERIC_KERNEL) && h->lds_pad == 0)
+        for (int g = 0; g < n_groups; ++g)
+            if (groups[g].batch > 0 && !(wave_per_qp && h->slots[groups[g].slot].small)) spec = h->slots[groups[g].slot].spec;
+    if (h->dtype == WBCQP_F64) {
+        if (!compact) return launch<double, false>(h, t64, total, lds, hs);
+        switch (spec) {
+        case 1: return launch<double, true, 1>(h, t64, total, lds, hs);
+        case 2: return launch<double, true, 2>(h, t64, total, lds, hs);
+        case 3: return launch<double, true, 3>(h, t64, total, lds, hs);
+        default: return launch<double, true>(h, t64, total, lds, hs);
+        }
+    }
+    if (!compact) return launch<float, false>(h, t32, total, lds, hs);
+    switch (spec) {
+    case 1: return launch<float, true, 1>(h, t32, total, lds, hs);
+    case 2: return launch<float, true, 2>(h, t32, total, lds, hs);
+    case 3: return launch<float, true, 3>(h, t32, total, lds, hs);
+    default: return launch<float, true>(h, t32, total, lds, hs);
+    }
 }
 
 int wbcqp_solve_batch(wbcqp_handle* h, int slot, int batch, const wbcqp_inputs* in, const wbcqp_outputs* out, void* stream)

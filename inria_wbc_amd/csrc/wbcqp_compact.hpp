@@ -226,32 +226,45 @@ struct OwnRow {
     const double* coef; // friction rows only: the row's 12 coefficients (sign folded in) in the LDS table, else null
 };
 
-template <typename TI>
+template <int SPEC> __device__ __forceinline__ Dims dims_of(const DevStruct& S)
+{
+    if constexpr (SPEC > 0) return kSpecDims[SPEC - 1]; // literals (wbcqp_types.hpp); the host has checked that they are this structure's
+    else return dims_from(S);
+}
+
+// SPEC > 0: the instantiation for the shipped stack kSpecDims[SPEC - 1] -- every size and LDS offset below is a literal
+template <typename TI, int SPEC = 0>
 __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const DevStruct& S, const int b, double* lds, const int tid, const int brec = -1)
 {
+    const Dims D = dims_of<SPEC>(S);
+#ifdef WBCQP_POISON_LDS
+    // debugging aid: every LDS word starts as a signalling pattern, so a read of a word nobody wrote shows in the results
+    for (int i = tid; i < S.lds_doubles; i += kThreads) lds[i] = __longlong_as_double(WBCQP_POISON_LDS);
+    bsync();
+#endif
     Ctx c;
     c.S = &S;
     c.tid = tid;
     c.lane = tid & (kWave - 1);
     c.wave = uni(tid >> 6);
     c.rslot = 0;
-    c.nblk = S.nv;
-    c.nv = S.nv; c.na = S.na; c.nc = S.nc; c.k = S.k; c.n = S.n; c.nu = S.nu;
-    c.neq = S.neq; c.nin2 = S.nin2; c.ldj = S.ldj; c.ldm = 0; c.ldc = 0; c.ldb = S.ldb;
-    c.J = lds + S.o_J; c.R = lds + S.o_R;
+    c.nblk = D.nv;
+    c.nv = D.nv; c.na = D.na; c.nc = D.nc; c.k = D.k; c.n = D.n; c.nu = D.nu;
+    c.neq = D.neq; c.nin2 = D.nin2; c.ldj = D.ldj; c.ldm = 0; c.ldc = 0; c.ldb = D.ldb;
+    c.J = lds + D.o_J; c.R = lds + D.o_R;
     c.M = nullptr; c.Jc = nullptr; c.Ac = nullptr; c.h = nullptr; c.q = nullptr; c.wrow = nullptr; c.stash = nullptr;
     c.eqw = nullptr; c.eqt = nullptr; c.bc = nullptr; c.iai = nullptr; c.iaexcl = nullptr;
     {
-        double* vec = lds + S.o_vec;
+        double* vec = lds + D.o_vec;
         c.x = vec + cp::X; c.np = vec + cp::NP; c.d = vec + cp::D; c.z = vec + cp::Z; c.xold = vec + cp::XOLD;
         c.r = vec + cp::R; c.u = vec + cp::U; c.uold = vec + cp::UOLD; c.rdinv = vec + cp::RDINV; c.part = vec + cp::PART;
         c.s = vec + cp::S; c.blb = vec + cp::BLB; c.bub = vec + cp::BUB; c.tl = vec + cp::TL; c.tu = vec + cp::TU;
         c.red = vec + cp::RED; c.g = vec + cp::G; c.dinv = vec + cp::DINV; c.w = vec + cp::W; c.b1 = vec + cp::B1;
         c.prm = vec + cp::PRM;
     }
-    double* const tact = lds + S.o_vec + cp::TACT;
-    double* const ce0v = lds + S.o_vec + cp::CE0; // ce0 of the equalities, then rhs, then y
-    int* ia = reinterpret_cast<int*>(lds + S.o_int);
+    double* const tact = lds + D.o_vec + cp::TACT;
+    double* const ce0v = lds + D.o_vec + cp::CE0; // ce0 of the equalities, then rhs, then y
+    int* ia = reinterpret_cast<int*>(lds + D.o_int);
     c.A = ia + cp::IA; c.Aold = ia + cp::IAOLD; c.gskip = ia + cp::IGSKIP; c.meta = ia + cp::IMETA;
     signed char* const act = reinterpret_cast<signed char*>(ia + cp::IACT);   // 1: row is in the active set (iai == -1)
     signed char* const excl = reinterpret_cast<signed char*>(ia + cp::IEXCL); // 1: row may be picked (iaexcl)
@@ -260,11 +273,11 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     c.iq = 0;
     c.R_norm = 1.0;
 
-    const int n_dense = S.n_dense, n_sel = S.n_sel, n_bound = S.n_bound, r1 = S.r1, n_tasks = S.n_tasks;
+    const int n_dense = D.n_dense, n_sel = D.n_sel, n_bound = D.n_bound, r1 = D.r1, n_tasks = D.n_tasks;
     const size_t qp = (size_t)b;                       // torque limits, weights and every output: the QP's index in the batch
     const size_t qr = (size_t)(brec >= 0 ? brec : b);  // the record (M .. bub): wbcqp_rollout's workgroups keep one record slot each
     double* const As = c.J;                  // dense task rows are staged in the J region (J appears after the elimination)
-    double* const RB = c.J + S.o_pan;        // the elimination's panels, behind the staged rows
+    double* const RB = c.J + D.o_pan;        // the elimination's panels, behind the staged rows
     double* const YB = RB + 512;
     double* const Nm = c.R + 256;            // N = CE' (n x ldb), then B = J0'N: tail of the R region
     const int lenM = nv * (nv + 1) / 2, lenA = n_dense * nv, lenAc = nc * 6 * nv;
@@ -320,7 +333,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             vbl = ga.blb[qr * n_bound + min(tid, n_bound - 1)];
             vbu = ga.bub[qr * n_bound + min(tid, n_bound - 1)];
         }
-        if (S.act_bounds) {
+        if (D.act_bounds) {
             vtl = ga.tlb[qp * na + min(tid, na - 1)];
             vtu = ga.tub[qp * na + min(tid, na - 1)];
             vha = ga.h[qr * nv + nu + min(tid, na - 1)];
@@ -379,7 +392,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             c.blb[tid] = (double)vbl;
             c.bub[tid] = (double)vbu;
         }
-        if (S.act_bounds && tid < na) { // lb - h_a, ub - h_a (computeProblemData, actuation tasks)
+        if (D.act_bounds && tid < na) { // lb - h_a, ub - h_a (computeProblemData, actuation tasks)
             c.tl[tid] = (double)vtl - (double)vha;
             c.tu[tid] = (double)vtu - (double)vha;
         }
@@ -452,16 +465,17 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 for (int w = 0; w < 4; ++w) gacc[w] = fma(ajw[w], wb.y, gacc[w]);
             };
             if (n_dense > 0) {
+                const int nd = opaque_uniform(n_dense); // (a literal in the specialised builds: as a loop bound it would unroll forty row bodies)
                 double2v ai0[2], aj0[2], ai1[2], aj1[2], wb0, wb1;
                 ldrow(0, ai0, aj0, wb0);
                 int r = 0;
-                for (; r + 2 <= n_dense; r += 2) {
+                for (; r + 2 <= nd; r += 2) {
                     ldrow(r + 1, ai1, aj1, wb1);
                     macrow(ai0, aj0, wb0);
-                    ldrow(min(r + 2, n_dense - 1), ai0, aj0, wb0);
+                    ldrow(min(r + 2, nd - 1), ai0, aj0, wb0);
                     macrow(ai1, aj1, wb1);
                 }
-                if (r < n_dense) macrow(ai0, aj0, wb0);
+                if (r < nd) macrow(ai0, aj0, wb0);
             }
             if (ta == 0) {
 #pragma unroll
@@ -506,7 +520,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         }
         // the panels lie behind the staged rows: a fast thread may publish while a slow one still reads its last task row
         publish_panel<4, 4, false, 0>(c, h, y, ta, te, 0, RB, YB);
-        eliminate_block<4, 4, false, 0>(c, h, y, ta, te, (nv + 3) & ~3, RB, YB, c.dinv, tid >= 128 && tid < 132, tid & 3);
+        eliminate_block<4, 4, false, 0>(c, h, y, ta, te, opaque_uniform((nv + 3) & ~3) /* not a constant for the unroller (a specialised build would lay out thirteen panel bodies: 256 VGPRs + 256 AGPRs + scratch) */, RB, YB, c.dinv, tid >= 128 && tid < 132, tid & 3);
         STAMP(2)
         bsync(); // staged rows and panels are dead: the region becomes J
         for (int e = tid; e < n * ldj; e += kThreads) c.J[e] = 0.0;
@@ -729,7 +743,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     // x is then updated in place with a snapshot in the other buffer, and the next pick re-evaluates s from scratch.
     // Row ownership: thread i owns row i of s when it is a bound or friction row; the actuation rows +-[M_a | -J_a'] of
     // joint rr belong to lanes 0 (+) and 1 (-) of quad rr, which hold tau' in a register anyway.
-    const bool act_ineq = S.act_bounds && na > 0; // actuation rows are inequality rows (otherwise tau' is only decoded)
+    const bool act_ineq = D.act_bounds && na > 0; // actuation rows are inequality rows (otherwise tau' is only decoded)
     if (status == -2 && nin2 > 0) {
         if (tid < nin2) {
             act[tid] = 0;
@@ -769,7 +783,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         }
         const int arr = tid >> 2, aq = tid & 3;
         const bool act_owner = act_ineq && arr < na && aq < 2;
-        const int arow = act_owner ? S.act_off + (aq ? na : 0) + arr : -1;
+        const int arow = act_owner ? D.act_off + (aq ? na : 0) + arr : -1;
         const double aci0 = act_owner ? (aq ? c.tu[arr] : -c.tl[arr]) : 0.0;
         const double asg = aq ? -1.0 : 1.0;
         double s_own = 0.0, s_act = 0.0; // s of the owned rows at the iterate of the last evaluation
@@ -891,8 +905,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         bsync();
         double* const Ri = c.R;                                      // inverse of R's inequality block (R itself is dead: solve_y was its last reader)
         double* const prm = c.R + ((roff(n - neq + 1) + 1) & ~1);    // rotation coefficients of a drop, behind the largest Ri
-        double* const dbuf0 = lds + S.o_vec + cp::D;                 // d lives in one of two buffers (a drop writes the other one);
-        double* const dbuf1 = lds + S.o_vec + cp::RDINV;             // 1/R(j,j) of the equality phase is dead by now
+        double* const dbuf0 = lds + D.o_vec + cp::D;                 // d lives in one of two buffers (a drop writes the other one);
+        double* const dbuf1 = lds + D.o_vec + cp::RDINV;             // 1/R(j,j) of the equality phase is dead by now
         const double psi_tol = (double)nin2 * eps * c1 * c2 * 100.0;
         bool redo_l2 = false;
         bool s_ready = false;    // the slot holds psi / the most violated row of the current iterate
@@ -919,7 +933,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
                 slow = false;
                 ++iter;
-                if (iter >= S.max_iter) {
+                if (iter >= D.max_iter) {
                     status = HQP_MAX_ITER;
                     break;
                 }
@@ -1339,7 +1353,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         if (tid < na) to[tid] = (TI)((double)hav + tact[tid]);
     }
     if (ga.amask) { // bit r = one-sided row r is active at the solution (the next tick's hint under WBCQP_FLAG_WARM_START)
-        const signed char* actf = reinterpret_cast<const signed char*>(reinterpret_cast<int*>(lds + S.o_int) + cp::IACT);
+        const signed char* actf = reinterpret_cast<const signed char*>(reinterpret_cast<int*>(lds + D.o_int) + cp::IACT);
         const bool on = (status == HQP_OPTIMAL) && nin2 > 0 && tid < nin2 && actf[tid] != 0;
         const unsigned long long m = __ballot(on);
         if (c.lane == 0) {

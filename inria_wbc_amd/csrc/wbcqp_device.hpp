@@ -985,7 +985,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
 // ------------------------------------------------------------------------------------------------
 // the kernel: grid = total QPs, block = 256 threads = four wavefronts = one QP
 // ------------------------------------------------------------------------------------------------
-template <typename TI, bool CP>
+template <typename TI, bool CP, int SPEC = 0>
 __global__ __launch_bounds__(kThreads) void solve_kernel(const GroupTable<TI> tab)
 {
     extern __shared__ __align__(16) double lds[];
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(kThreads) void solve_kernel(const GroupTable<TI> ta
     }
     const GroupArgs<TI>& ga = tab.g[gi];
     const DevStruct& S = ga.st;
-    if constexpr (CP) solve_one_compact<TI>(ga, S, b, lds, threadIdx.x);
+    if constexpr (CP) solve_one_compact<TI, SPEC>(ga, S, b, lds, threadIdx.x);
     else solve_one<TI>(ga, S, b, lds, threadIdx.x);
 }
 
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(kThreads) void solve_kernel(const GroupTable<TI> ta
 // all 256 CUs.  *queue: positions handed out beyond the first one of each workgroup; the last fetch of a launch zeroes it
 // for the next launch (stream order makes that visible; no memset on the path, and a captured launch replays as it is).
 // ------------------------------------------------------------------------------------------------
-template <typename TI, bool CP>
+template <typename TI, bool CP, int SPEC = 0>
 __global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<TI> tab, int* queue, const int total)
 {
     extern __shared__ __align__(16) double lds[];
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<
             }
             next_qp = pos < total ? (tab.order ? tab.order[pos] : pos) : -1;
         }
-        __syncthreads();
+        bsync();
         int b = uni(next_qp), gi = 0;
         if (b < 0) break;
         while (gi + 1 < tab.n && b >= tab.g[gi].count) {
@@ -1039,9 +1039,9 @@ __global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<
         // this loop and stays live across it (measured: 256 VGPRs + 146 AGPRs instead of 240 + 0; build.py refuses that)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        if constexpr (CP) solve_one_compact<TI>(ga, ga.st, b, lds, tid);
+        if constexpr (CP) solve_one_compact<TI, SPEC>(ga, ga.st, b, lds, tid);
         else solve_one<TI>(ga, ga.st, b, lds, tid);
-        __syncthreads(); // the next QP reuses every byte of LDS, next_qp included
+        bsync(); // the next QP reuses every byte of LDS, next_qp included
     }
 }
 
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(1024) void schedule_kernel(const ScheduleArgs sa, i
     __shared__ int start[64];
     const int tid = threadIdx.x;
     if (tid < 64) hist[tid] = 0;
-    __syncthreads();
+    bsync();
     auto key_of = [&](int i) {
         int gi = 0, b = i;
         while (gi + 1 < sa.n && b >= sa.count[gi]) {
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(1024) void schedule_kernel(const ScheduleArgs sa, i
         return 63 - min(max(it, 0), 63);
     };
     for (int i = tid; i < total; i += 1024) atomicAdd(&hist[key_of(i)], 1);
-    __syncthreads();
+    bsync();
     if (tid == 0) {
         int acc = 0;
         for (int k = 0; k < 64; ++k) {
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(1024) void schedule_kernel(const ScheduleArgs sa, i
             acc += hist[k];
         }
     }
-    __syncthreads();
+    bsync();
     for (int i = tid; i < total; i += 1024) order[atomicAdd(&start[key_of(i)], 1)] = i;
 }
 
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(256) void pack_order_kernel(const PackArgs pa)
         s_job[tid] = job;
         s_cls[tid] = min(max(pa.iters[job], 0), 63);
     }
-    __syncthreads();
+    bsync();
     // class counts in the lanes (lane k: class k), gend(k) = number of entries of class >= k (the entries are sorted)
     int cnt = 0;
     for (int e = 0; e < nw; ++e) cnt += (s_cls[e] == lane);
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256) void pack_order_kernel(const PackArgs pa)
         }
     }
     if (lane == 0) s_ok[trial] = (n == 0);
-    __syncthreads();
+    bsync();
     int win = -1;
     for (int t = kPackTrials - 1; t >= 0; --t)
         if (s_ok[t]) win = t;

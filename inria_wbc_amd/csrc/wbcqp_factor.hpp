@@ -49,7 +49,7 @@ __device__ __forceinline__ void eliminate_block(Ctx& c, double (&h)[NU][NU], dou
     const int jend = min(G * JB + G, npad);
     for (int j0 = G * JB; j0 < jend; j0 += 4) {
         if (WLOCAL) __builtin_amdgcn_wave_barrier();
-        else __syncthreads();
+        else bsync();
         const int par = WLOCAL ? 0 : ((j0 >> 2) & 1);
         const double* rb = RB + par * PS;
         const double* yb = YB + par * PS;

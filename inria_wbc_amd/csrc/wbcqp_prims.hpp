@@ -12,7 +12,18 @@ namespace wbcqp {
 // ------------------------------------------------------------------------------------------------
 // wave64 primitives (DPP row operations + readlane)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bsync() { __syncthreads(); }
+// The workgroup barrier of every kernel here.  __syncthreads() is release fence + s_barrier + acquire fence, and the fence's
+// `s_waitcnt lgkmcnt(0)` is a "soft" wait that ROCm 7.2's waitcnt pass may drop: it did at the header of qr_unified's loop (and in
+// some sixty other places), leaving ds_write_b128s of one wave in flight across the barrier behind which another wave reads them.
+// On MI355X that is a real race: about one Talos QP in 50 000 came back with a stale reflector applied by one wave (found in round 4,
+// when the specialised kernels shifted the timing; the results differed from run to run).  The explicit wait below (vmcnt and expcnt
+// left alone: 0xC07F = lgkmcnt(0) only) cannot be dropped; tools/check_barriers.py reads the build's assembly and refuses a barrier
+// without it.
+__device__ __forceinline__ void bsync()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __syncthreads();
+}
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v)
@@ -227,6 +238,9 @@ __device__ __forceinline__ double fast_rcp(double x)
 // is 0 there for u = 0 and huge otherwise.  That (never observed) case takes the IEEE division, under a branch no lane enters.
 __device__ __forceinline__ double ratio_pos(double u, double r) { return (r >= 0x1p-1020) ? u * fast_rcp(r) : u / r; }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// the same for a value that is the same in every lane, kept in a scalar register: a loop bound made opaque() would turn the loop's branch
+// into a per-lane one (EXEC-masked loop around barriers)
+__device__ __forceinline__ int opaque_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ double2v ld2(const double* p) { return *reinterpret_cast<const double2v*>(__builtin_assume_aligned(p, 16)); }
 __device__ __forceinline__ int wave_min_int(int v) { return -wave_max_int(-v); }
 

@@ -307,7 +307,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         for (int i = tid; i < T.r1; i += kTermsThreads) b1s[i] = 0.0;
         if (tid == 0) __hip_atomic_store(frames_ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    __syncthreads();
+    bsync();
     TSTAMP(0)
     const V3 p0 = T.floating_base ? ld3(q) : V3{0.0, 0.0, 0.0}; // the origin everything below is expressed about
 
@@ -424,7 +424,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         }
         TSTAMP(2)
         // ---- phase 2 on this wave: world inertia about the origin, momentum, bias force; prefix sums ---------------
-        __syncthreads(); // barrier 1: kin is complete
+        bsync(); // barrier 1: kin is complete
         double sc[16];
         double hm[6];
         {
@@ -576,7 +576,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         // ---- phase 2 on this wave: the Jacobian rows of two framed tasks in three (wave 1 takes the others).  The frames come
         //      from wave 1 (round 2 recomputed them here, ~200 instructions on the vector port this kernel saturates): wave 1
         //      publishes them first thing after the barrier and raises a flag; this wave sleeps on the flag, which costs no issue slot
-        __syncthreads(); // barrier 1: kin is complete
+        bsync(); // barrier 1: kin is complete
         {
             const bool colv = lane < nv;
             const ColumnAxis c = column_axis(kin, bj, lastj, kofj, jtypej);
@@ -597,7 +597,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         double l_place[12];
 #pragma unroll
         for (int r = 0; r < 12; ++r) l_place[r] = dp[T.d_law_place + 12 * ll + r];
-        __syncthreads(); // barrier 1: kin is complete
+        bsync(); // barrier 1: kin is complete
         {
             FrameKin f;
             if (lane < T.nlaw) {
@@ -686,7 +686,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
                 for (int r = 0; r < 6; ++r) ppar[r] = dp[T.d_pair_par + 6 * sc_ + r];
             };
             fetch(lane);
-            __syncthreads(); // barrier 1: kin is complete
+            bsync(); // barrier 1: kin is complete
             if (lane < T.nscf) {
                 FrameKin f;
                 frame_kin(kin + kKinStride * f_body, f_place, f);
@@ -744,7 +744,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
             TSTAMP(5)
         }
     }
-    __syncthreads(); // barrier 2: scan table, task frames, pairs, right-hand sides of the framed tasks
+    bsync(); // barrier 2: scan table, task frames, pairs, right-hand sides of the framed tasks
     TSTAMP(6)
 
     // ---- phase 3: lanes = velocity coordinates, on every wave -----------------------------------------------------------
@@ -854,7 +854,7 @@ __device__ __forceinline__ void terms_one(const TermsArgs<TI>& args, const TI* g
         }
     }
     TSTAMP(10)
-    __syncthreads();
+    bsync();
     for (int i = tid; i < T.r1; i += kTermsThreads) args.b1[(size_t)rinst * T.r1 + i] = (TI)b1s[i];
     for (int i = tid; i < 6 * T.nc; i += kTermsThreads) args.bc[(size_t)rinst * 6 * T.nc + i] = (TI)bcs[i];
 #ifdef WBCQP_STAMPS

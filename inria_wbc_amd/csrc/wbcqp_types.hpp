@@ -72,6 +72,26 @@ struct DevStruct {
     const double* acteq_scale;
 };
 
+// The integer sizes and LDS offsets of a structure on the compact layout as the kernel sees them.  The compact kernels exist once for ANY
+// structure (these read from the DevStruct at run time) and once per SHIPPED stack with all of them as literals: every address then folds
+// into an immediate, clamps and loop bounds are constants, and some forty wave-uniform values leave the SGPRs (the generic kernel spills
+// 147 of them into VGPR lanes, a specialised one 101).  Measured on Talos (tools/throughput_time.py): median QP alone 61.3 -> 55.2 us, B = 8192
+// 6.24 -> 6.56 M QP/s, config 2 replayed 5.72 -> 6.12 M.  Same source, same arithmetic order: bit for bit the generic kernel's results
+// (tests/test_gpu_specialised.py).  The host picks an instantiation only when the structure's derived layout EQUALS the literals.
+struct Dims {
+    int nv, na, nc, k, n, nu, n_dense, n_tasks, n_sel, n_bound, act_bounds, neq, nin2, r1, max_iter, ldj, ldb, o_J, o_R, o_vec, o_int, o_pan, act_off;
+};
+constexpr int kNumSpecs = 3;
+constexpr Dims kSpecDims[kNumSpecs] = {
+    // 1: etc/talos/tasks.yaml on talos.urdf (nv 50, two foot contacts, bounds + actuation bounds): n 74, nEq 18, 244 one-sided rows
+    {50, 44, 2, 24, 74, 6, 41, 19, 44, 44, 1, 18, 244, 97, 1000, 75, 22, 0, 5550, 8402, 9842, 2714, 88},
+    // 2: etc/icub/tasks.yaml (nv 38, two contacts, no actuation bounds): n 62, nEq 18, 132 one-sided rows
+    {38, 32, 2, 24, 62, 6, 39, 13, 32, 32, 0, 18, 132, 83, 1000, 63, 22, 0, 3906, 5924, 7364, 2582, -1},
+    // 3: Talos in single support (walk / walk-on-spot between a lift-off and a touch-down): n 62, nEq 12, 210 one-sided rows
+    {50, 44, 1, 12, 62, 6, 41, 18, 44, 44, 1, 12, 210, 91, 1000, 63, 14, 0, 3906, 5924, 7364, 2714, 88},
+};
+__host__ __device__ inline Dims dims_from(const struct DevStruct& S);
+
 template <typename TI>
 struct GroupArgs {
     DevStruct st; // by value: the sizes, offsets and table pointers arrive with the kernel arguments, not behind a pointer
@@ -90,6 +110,27 @@ struct GroupTable {
     const int* order; // launch order -> QP index (longest-first schedule of the previous launch of this shape), or null
     GroupArgs<TI> g[kMaxGroups];
 };
+
+__host__ __device__ inline Dims dims_from(const DevStruct& S)
+{
+    return Dims{S.nv, S.na, S.nc, S.k, S.n, S.nu, S.n_dense, S.n_tasks, S.n_sel, S.n_bound, S.act_bounds, S.neq, S.nin2, S.r1, S.max_iter,
+                S.ldj, S.ldb, S.o_J, S.o_R, S.o_vec, S.o_int, S.o_pan, S.act_off};
+}
+// 1-based index into kSpecDims of the specialisation whose literals equal this compact layout, 0: none
+inline int spec_of(const DevStruct& C)
+{
+    if (!C.compact) return 0;
+    const Dims d = dims_from(C);
+    for (int i = 0; i < kNumSpecs; ++i) {
+        const Dims& s = kSpecDims[i];
+        if (d.nv == s.nv && d.na == s.na && d.nc == s.nc && d.k == s.k && d.n == s.n && d.nu == s.nu && d.n_dense == s.n_dense && d.n_tasks == s.n_tasks &&
+            d.n_sel == s.n_sel && d.n_bound == s.n_bound && d.act_bounds == s.act_bounds && d.neq == s.neq && d.nin2 == s.nin2 && d.r1 == s.r1 &&
+            d.max_iter == s.max_iter && d.ldj == s.ldj && d.ldb == s.ldb && d.o_J == s.o_J && d.o_R == s.o_R && d.o_vec == s.o_vec && d.o_int == s.o_int &&
+            d.o_pan == s.o_pan && d.act_off == s.act_off)
+            return i + 1;
+    }
+    return 0;
+}
 
 static_assert(sizeof(GroupTable<double>) <= 4000, "the group table travels as a kernel argument: the kernarg segment is 4 KiB");
 

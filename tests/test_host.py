@@ -63,6 +63,9 @@ def test_layout_without_gpu(built_lib):
             assert L["len_" + k] == fl[k], (name, k)
         assert 0 < L["lds_bytes"] <= 160 * 1024 and L["waves_per_cu"] >= 1
         assert L["algorithmic_bytes"] == st.algorithmic_bytes()
+        # the shipped humanoid stacks have an instantiation of the compact kernel of their own (csrc/wbcqp_types.hpp: kSpecDims): its
+        # literals must equal what the host derives for the stack -- a layout change that forgets the table shows up here
+        assert L["specialised"] == {"talos": 1, "icub": 2, "talos_single_support": 3}.get(name, 0), (name, L["specialised"])
 
 
 def test_invalid_structures_are_rejected(built_lib):
@@ -175,3 +178,38 @@ def test_bench_accepts_the_drivers_command_line_and_counts_usable_cores(monkeypa
     n, note = bench.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1) and "os.cpu_count()" in note
     assert bench.ALGORITHMIC_BYTES["talos"] == 35152
+
+
+def test_the_build_refuses_a_barrier_without_the_lds_wait(tmp_path):
+    """inria_wbc_amd/build.py reads the device assembly of the compilation that makes the library: an s_barrier that is not preceded, in
+    its basic block and before any LDS instruction, by `s_waitcnt ... lgkmcnt(0)` is refused (round 4's race: tools/check_barriers.py)."""
+    from inria_wbc_amd.build import check_barriers
+    good = """
+_ZN5wbcqp1kEv:                          ; @_ZN5wbcqp1kEv
+	ds_write_b128 v1, v[2:5]
+	s_waitcnt vmcnt(3) lgkmcnt(0)
+	v_mov_b32_e32 v0, s1
+	s_barrier
+	ds_read_b128 v[2:5], v1
+.LBB0_1:
+	s_waitcnt lgkmcnt(0)
+	s_barrier
+"""
+    bad = """
+_ZN5wbcqp1kEv:                          ; @_ZN5wbcqp1kEv
+	s_waitcnt lgkmcnt(0)
+	ds_write_b128 v1, v[2:5]
+	s_barrier
+	s_waitcnt lgkmcnt(0)
+.LBB0_1:                                ; the wait is in the predecessor: some other path may reach the label without it
+	v_mov_b32_e32 v0, s1
+	s_barrier
+	s_waitcnt lgkmcnt(1)
+	s_barrier
+"""
+    p = tmp_path / "k.s"
+    p.write_text(good)
+    assert check_barriers(str(p)) == (2, [])
+    p.write_text(bad)
+    total, flagged = check_barriers(str(p))
+    assert total == 3 and [ln for _, ln in flagged] == [5, 9, 11] and flagged[0][0] == "_ZN5wbcqp1kEv"

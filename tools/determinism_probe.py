@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Same records, many launches, every dispatch: are the bits the same every time?
+
+Round 4's specialised kernels came back with about one Talos QP in 50 000 different from run to run (a stale Householder reflector
+applied by one wave: the waitcnt pass had dropped the `s_waitcnt lgkmcnt(0)` of a __syncthreads(), wbcqp_prims.hpp bsync()).  This is
+the probe that showed it and that shows it gone: the reference is one launch of the generic kernel in index order, then `--launches`
+launches of the generic and the specialised kernel under queue / hardware dispatch / index order are compared with it bit by bit.
+Prints one line per launch that differs and a JSON summary; exit status 1 if any launch differed.
+
+python tools/determinism_probe.py [--batch 2048] [--launches 60] [--robot talos] [--lib path]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(batch=2048, launches=60, robot="talos", lib=None, verbose=True):
+    import torch
+    from inria_wbc_amd import capi, structure, synth
+    if lib:
+        capi.load_library(os.path.abspath(lib))
+    st = structure.STRUCTURES[robot]()
+    dev = torch.device("cuda", 0)
+    B = batch
+    inp = synth.generate(st, B, synth.SEED_BASE.get(robot, synth.SEED_BASE["talos"]) + 31 * B)
+    d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items() if v.size}
+
+    def go(flags, n):
+        h = capi.Handle(0, capi.F64, flags=flags)
+        h.set_structure(0, st)
+        outs = []
+        for _ in range(n):
+            o = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
+                     status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+            h.solve_batch(0, B, d, o, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs.append({k: v.cpu().numpy() for k, v in o.items()})
+        h.close()
+        return outs
+
+    G, IO, HW = capi.FLAG_GENERIC_KERNEL, capi.FLAG_INDEX_ORDER, capi.FLAG_HW_DISPATCH
+    ref = go(G | IO | HW, 1)[0]
+    summary = {"robot": robot, "batch": B, "launches": launches, "differing_launches": {}, "differing_qps": {}}
+    for name, fl in (("generic, queue", G), ("generic, hardware dispatch", G | HW), ("specialised, hardware dispatch, index order", IO | HW),
+                     ("specialised, queue", 0), ("specialised, hardware dispatch", HW)):
+        nl = nq = 0
+        for i, o in enumerate(go(fl, launches)):
+            bad = np.where((o["x"] != ref["x"]).any(axis=1) | (o["tau"] != ref["tau"]).any(axis=1) | (o["iters"] != ref["iters"]) | (o["status"] != ref["status"]))[0]
+            if bad.size:
+                nl += 1
+                nq += int(bad.size)
+                q = int(bad[0])
+                dd = np.abs(o["x"][q] - ref["x"][q])
+                if verbose:
+                    print("%s: launch %d differs in %d QPs; QP %d: max |dx| %.3g in components %s, iters %d (reference %d)" %
+                          (name, i, bad.size, q, dd.max(), np.where(dd > 0)[0].tolist(), o["iters"][q], ref["iters"][q]))
+        summary["differing_launches"][name] = nl
+        summary["differing_qps"][name] = nq
+    summary["qps_compared"] = 5 * launches * B
+    summary["deterministic"] = not any(summary["differing_launches"].values())
+    return summary
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--launches", type=int, default=60)
+    ap.add_argument("--robot", default="talos")
+    ap.add_argument("--lib", default=None)
+    a = ap.parse_args()
+    s = run(a.batch, a.launches, a.robot, a.lib)
+    print(json.dumps(s))
+    sys.exit(0 if s["deterministic"] else 1)
