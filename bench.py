@@ -168,7 +168,7 @@ def before_path(h, st, dev, B, torch, cpu_baseline=True):
         torch.cuda.synchronize()
         got = {k: rows[k][:ns].cpu().numpy() for k in capi.ROW_FIELDS}
         res["cpu_port"] = {"instances_per_s": ns / dt1, "cores": 1, "sample": "%d instances, oracle/rbd_oracle.c" % ns}
-        res["parity"] = {k: float(np.abs(got[k] - ora[k]).max() / max(1.0, np.abs(ora[k]).max())) for k in capi.ROW_FIELDS}
+        res["parity"] = {k: float(np.abs(got[k] - ora[k]).max() / max(1.0, np.abs(ora[k]).max())) for k in capi.ROW_FIELDS if ora[k].size}  # (Acop: empty without a cop task)
     return res
 
 
@@ -776,7 +776,10 @@ def main():
         queued = (layout["lds_bytes"] >= 48 * 1024 or (base_flags & capi.FLAG_QUEUE)) and not (base_flags & capi.FLAG_HW_DISPATCH)
         compact = per_cu >= 2 or layout["lds_bytes"] <= 80 * 1024
         tname = "float" if f32 else "double"
-        kernel = "wbcqp::%s<%s, %s>" % ("solve_queue_kernel" if queued else "solve_kernel", tname, "true" if compact and not (base_flags & capi.FLAG_FULL_LDS) else "false")
+        is_cp = compact and not (base_flags & capi.FLAG_FULL_LDS)
+        # the name rocprofv3 prints: <boundary type, compact layout, specialisation index (0 = generic; wbcqp_layout.specialised)>
+        spec = layout.get("specialised", 0) if is_cp and not (base_flags & capi.FLAG_GENERIC_KERNEL) else 0
+        kernel = "wbcqp::%s<%s, %s, %d>" % ("solve_queue_kernel" if queued else "solve_kernel", tname, "true" if is_cp else "false", spec)
         if layout.get("wave_per_qp") and not (base_flags & capi.FLAG_WORKGROUP_PER_QP):
             kernel = "wbcqp::solve_small_kernel<%s>" % tname  # one wavefront per QP (csrc/wbcqp_small.hpp)
         result = {

@@ -39,7 +39,7 @@ def test_gpus_2_typed_without_a_launcher_prints_one_line_with_n_gpus_2(built_lib
 
 
 def test_n1_line_has_the_contract_keys(built_lib):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-compare",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
                         "--no-sweep", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900, env=_env())
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)
@@ -51,3 +51,20 @@ def test_n1_line_has_the_contract_keys(built_lib):
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["parity"]["status_equal"] and d["parity"]["max_rel_dx"] <= 1e-8
+    # no leg of the line may have failed quietly: a leg that raises leaves {"error": ...} in its place (round 4: `before_path` did, for
+    # three profile passes, over an empty record field)
+    def errors(node, path=""):
+        found = []
+        if isinstance(node, dict):
+            for k, v in node.items():
+                if k == "error":
+                    found.append((path, v))
+                found += errors(v, path + "/" + k)
+        elif isinstance(node, list):
+            for i, v in enumerate(node):
+                found += errors(v, "%s[%d]" % (path, i))
+        return found
+    assert errors(d) == []
+    assert d["roofline"]["kernel"] == "wbcqp::solve_queue_kernel<double, true, 1>"
+    bp = d["before_path"]
+    assert bp["parity"] and max(bp["parity"].values()) <= 1e-9 and bp["whole_tick"]["status_optimal"] == 1024

@@ -1,3 +1,5 @@
+#!/bin/bash
+# sclk / power read by rocm-smi while the solve kernel runs back to back (B = 8192, 8 s): is the chip at its rated clock under this load?
 cd $GRAFT_REPO_ROOT
 python - <<'PY' &
 import time, numpy as np, torch, sys

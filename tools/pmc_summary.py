@@ -36,7 +36,7 @@ def main():
             # tools/profile_kernels.sh: the limiter's counters and a kernel trace for every other kernel a number is quoted for
             "pmc_lds.csv", "pmc_ldsbw.csv", "pmc_f64.csv", "pmc_issue.csv", "pmc_rows_sq.csv", "kernel_stats_franka_b8192.csv", "kernel_stats_dense_b1.csv",
             "kernel_stats_dense_b256.csv", "kernel_stats_rows.csv", "kernel_stats_rollout.csv", "trace_dense_b1.log", "trace_dense_b256.log", "trace_rows.log",
-            "rollout_grid.log"]
+            "rollout_grid.log", "throughput.json", "determinism_probe.txt"]
     for f in keep:
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
@@ -48,7 +48,7 @@ def main():
     w_kb, nw = mean(wr, "WRITE_SIZE")
     waves, _ = mean(sq, "SQ_WAVES")
     cyc, _ = mean(sq, "SQ_WAVE_CYCLES")
-    out = {"round": int(rnd.lstrip("r")), "kernel": "wbcqp::solve_queue_kernel<double, true>", "workload": "talos_pos_tracker_b1024_fp64_squat_tick_stream",
+    out = {"round": int(rnd.lstrip("r")), "kernel": "wbcqp::solve_queue_kernel<double, true, 1>", "workload": "talos_pos_tracker_b1024_fp64_squat_tick_stream",
            "batch": 1024, "fetch_size_kb": round(f_kb, 2), "write_size_kb": round(w_kb, 2), "launches_fetch_pass": nf, "launches_write_pass": nw,
            "traffic_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0, "traffic_over_algorithmic": (2.0 * f_kb + w_kb) * 1024.0 / (35152.0 * 1024),
            "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, then the SQ counters) over `bench.py --steps 20 --warmup 4 --headline-only` "
