@@ -19,3 +19,14 @@ def test_every_launch_gives_the_same_bits(robot, batch, launches):
     import determinism_probe
     s = determinism_probe.run(batch=batch, launches=launches, robot=robot, verbose=True)
     assert s["deterministic"], s
+
+
+@pytest.mark.parametrize("robot,batch,launches,full", [("talos", 1024, 10, True), ("talos_torque_cop", 512, 8, False), ("franka", 8192, 8, False),
+                                                       ("tiago", 4096, 8, False)])
+def test_the_other_kernels_too(robot, batch, launches, full):
+    """The full LDS layout (round 1's kernel), a stack with a torque and a cop task (H as one matrix, full layout) and the one-wavefront
+    kernel: every workgroup barrier of every kernel is bsync() now, so they are held to the same bar."""
+    import determinism_probe
+    from inria_wbc_amd import capi
+    s = determinism_probe.run(batch=batch, launches=launches, robot=robot, verbose=True, extra_flags=capi.FLAG_FULL_LDS if full else 0)
+    assert s["deterministic"], s

@@ -7,7 +7,7 @@ the probe that showed it and that shows it gone: the reference is one launch of 
 launches of the generic and the specialised kernel under queue / hardware dispatch / index order are compared with it bit by bit.
 Prints one line per launch that differs and a JSON summary; exit status 1 if any launch differed.
 
-python tools/determinism_probe.py [--batch 2048] [--launches 60] [--robot talos] [--lib path]"""
+python tools/determinism_probe.py [--batch 2048] [--launches 60] [--robot talos] [--full-lds] [--lib path]"""
 import argparse
 import json
 import os
@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(batch=2048, launches=60, robot="talos", lib=None, verbose=True):
+def run(batch=2048, launches=60, robot="talos", lib=None, verbose=True, extra_flags=0):
     import torch
     from inria_wbc_amd import capi, structure, synth
     if lib:
@@ -44,12 +44,12 @@ def run(batch=2048, launches=60, robot="talos", lib=None, verbose=True):
         return outs
 
     G, IO, HW = capi.FLAG_GENERIC_KERNEL, capi.FLAG_INDEX_ORDER, capi.FLAG_HW_DISPATCH
-    ref = go(G | IO | HW, 1)[0]
+    ref = go(G | IO | HW | extra_flags, 1)[0]
     summary = {"robot": robot, "batch": B, "launches": launches, "differing_launches": {}, "differing_qps": {}}
     for name, fl in (("generic, queue", G), ("generic, hardware dispatch", G | HW), ("specialised, hardware dispatch, index order", IO | HW),
                      ("specialised, queue", 0), ("specialised, hardware dispatch", HW)):
         nl = nq = 0
-        for i, o in enumerate(go(fl, launches)):
+        for i, o in enumerate(go(fl | extra_flags, launches)):
             bad = np.where((o["x"] != ref["x"]).any(axis=1) | (o["tau"] != ref["tau"]).any(axis=1) | (o["iters"] != ref["iters"]) | (o["status"] != ref["status"]))[0]
             if bad.size:
                 nl += 1
@@ -72,7 +72,9 @@ if __name__ == "__main__":
     ap.add_argument("--launches", type=int, default=60)
     ap.add_argument("--robot", default="talos")
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--full-lds", action="store_true", help="round 1's layout (one QP per CU) instead of the compact one")
     a = ap.parse_args()
-    s = run(a.batch, a.launches, a.robot, a.lib)
+    from inria_wbc_amd import capi as _capi
+    s = run(a.batch, a.launches, a.robot, a.lib, extra_flags=_capi.FLAG_FULL_LDS if a.full_lds else 0)
     print(json.dumps(s))
     sys.exit(0 if s["deterministic"] else 1)
