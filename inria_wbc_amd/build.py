@@ -119,43 +119,47 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     tmpdir = tempfile.mkdtemp(prefix="wbcqp_build_")
-    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}",
-           "-fno-gpu-rdc", "-ffp-contract=on", "-Wall", "-Wno-unused-function", "-save-temps=cwd",
-           *extra_flags,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp", "-ldl"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    # The kernel-resource remarks are part of the build: a solve kernel that parks live registers in AGPRs or spills to
-    # scratch is refused.  Measured reason: with more than 256 live VGPRs the allocator split live ranges into AGPRs and
-    # ROCm 7.2's clang placed such copies at the head of a join block BEFORE the `s_or_b64 exec` that restores the lanes,
-    # i.e. under a partial EXEC mask -- values came back corrupted in the other lanes (non-deterministic results in the
-    # diagnostic build; tools/chk_lib.py, tests/test_gpu_parity.py::test_diagnostic_build_is_a_canary).
-    cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=tmpdir)
-    usage = _resource_usage(proc.stdout)
-    if proc.returncode != 0:
-        sys.stderr.write(proc.stdout)
-        raise subprocess.CalledProcessError(proc.returncode, cmd)
-    for line in proc.stdout.splitlines():
-        if "remark:" not in line and "kernel-resource-usage" not in line and line.strip() and not line.lstrip().startswith(("|", "^")) \
-                and not line.strip()[:5].strip().isdigit():
-            print(line, file=sys.stderr)
-    for name, u in usage.items():
-        if ("solve_kernel" in name or "solve_queue_kernel" in name or "terms_kernel" in name) and (u.get("AGPRs", 0) != 0 or u.get("ScratchSize [bytes/lane]", 0) != 0 or u.get("VGPRs Spill", 0) != 0):
-            raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, VGPR spills %s -- refuse to ship (see the comment in build.py)" %
-                               (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("VGPRs Spill")))
-    # The device assembly is part of the build too: every workgroup barrier must wait for the wave's own LDS traffic first
-    # (tools/check_barriers.py says why; bsync() in wbcqp_prims.hpp issues the wait).
-    asm = [f for f in os.listdir(tmpdir) if f.endswith("gfx950.s")]
-    if len(asm) != 1:
-        raise RuntimeError("no device assembly among the build's temporaries: %s" % sorted(os.listdir(tmpdir)))
-    total, bad = check_barriers(os.path.join(tmpdir, asm[0]))
-    if bad or total == 0:
-        shutil.copy(os.path.join(tmpdir, asm[0]), DEVICE_ASM + ".refused")
-        raise RuntimeError("%d of %d s_barrier without a preceding s_waitcnt lgkmcnt(0): %s ... -- refuse to ship (assembly kept as %s.refused)" %
-                           (len(bad), total, bad[:4], DEVICE_ASM))
-    shutil.rmtree(tmpdir, ignore_errors=True)
-    os.replace(LIB + ".tmp", LIB)
+    try:
+        cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}",
+               "-fno-gpu-rdc", "-ffp-contract=on", "-Wall", "-Wno-unused-function", "-save-temps=cwd",
+               *extra_flags,
+               *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp", "-ldl"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        # The kernel-resource remarks are part of the build: a solve kernel that parks live registers in AGPRs or spills to
+        # scratch is refused.  Measured reason: with more than 256 live VGPRs the allocator split live ranges into AGPRs and
+        # ROCm 7.2's clang placed such copies at the head of a join block BEFORE the `s_or_b64 exec` that restores the lanes,
+        # i.e. under a partial EXEC mask -- values came back corrupted in the other lanes (non-deterministic results in the
+        # diagnostic build; tools/chk_lib.py, tests/test_gpu_parity.py::test_diagnostic_build_is_a_canary).
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=tmpdir)
+        usage = _resource_usage(proc.stdout)
+        if proc.returncode != 0:
+            sys.stderr.write(proc.stdout)
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        for line in proc.stdout.splitlines():
+            if "remark:" not in line and "kernel-resource-usage" not in line and line.strip() and not line.lstrip().startswith(("|", "^")) \
+                    and not line.strip()[:5].strip().isdigit():
+                print(line, file=sys.stderr)
+        for name, u in usage.items():
+            if ("solve_kernel" in name or "solve_queue_kernel" in name or "terms_kernel" in name) and (u.get("AGPRs", 0) != 0 or u.get("ScratchSize [bytes/lane]", 0) != 0 or u.get("VGPRs Spill", 0) != 0):
+                raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, VGPR spills %s -- refuse to ship (see the comment in build.py)" %
+                                   (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("VGPRs Spill")))
+        # The device assembly is part of the build too: every workgroup barrier must wait for the wave's own LDS traffic first
+        # (tools/check_barriers.py says why; bsync() in wbcqp_prims.hpp issues the wait).
+        asm = [f for f in os.listdir(tmpdir) if f.endswith("gfx950.s")]
+        if len(asm) != 1:
+            raise RuntimeError("no device assembly among the build's temporaries: %s" % sorted(os.listdir(tmpdir)))
+        total, bad = check_barriers(os.path.join(tmpdir, asm[0]))
+        if bad or total == 0:
+            shutil.copy(os.path.join(tmpdir, asm[0]), DEVICE_ASM + ".refused")
+            raise RuntimeError("%d of %d s_barrier without a preceding s_waitcnt lgkmcnt(0): %s ... -- refuse to ship (assembly kept as %s.refused)" %
+                               (len(bad), total, bad[:4], DEVICE_ASM))
+        os.replace(LIB + ".tmp", LIB)
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)  # (-save-temps leaves some 40 MB there)
+        if os.path.exists(LIB + ".tmp"):
+            os.remove(LIB + ".tmp")
     return LIB
 
 
