@@ -715,3 +715,42 @@ def test_two_runs_are_bitwise_equal(host_build, tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr
         outs.append((open(q_path, "rb").read(), open(tau_path, "rb").read()))
     assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_task_file_key_order_does_not_change_the_trajectory(host_build, tmp_path):
+    """The other half of the reference's determinism test (tests/test_determinism.cpp:118-138): tasks.yaml re-emitted with its keys in a
+    random order must give the same joint trajectory below 1e-8 (there over 50 000 ticks of two behaviours; here 300 closed-loop ticks
+    of the squat through the facade, model -> rows kernel -> solve -> integration on the device, three shuffles)."""
+    import random
+    import shutil
+    src = os.path.join(ROOT, "configs", "talos")
+    text = open(os.path.join(src, "tasks.yaml")).read().splitlines()
+    head = [ln for ln in text[:1] if ln.startswith("#")]
+    blocks, cur = [], []
+    for ln in text[len(head):]:
+        if ln and not ln.startswith((" ", "#")) and cur:
+            blocks.append(cur)
+            cur = []
+        cur.append(ln)
+    if cur:
+        blocks.append(cur)
+    assert len(blocks) >= 8
+    runs = []
+    for k in range(4):
+        d = tmp_path / ("talos%d" % k)
+        shutil.copytree(src, d)
+        order = list(blocks)
+        if k:
+            random.Random(100 + k).shuffle(order)
+            assert [b[0] for b in order] != [b[0] for b in blocks]
+        (d / "tasks.yaml").write_text("\n".join(head + [ln for b in order for ln in b]) + "\n")
+        q_path, tau_path = str(tmp_path / ("q%d.bin" % k)), str(tmp_path / ("tau%d.bin" % k))
+        r = subprocess.run([host_build["qp_timer_test"], str(d / "pos_tracker_model.yaml"), str(d / "squat.yaml"), "-", "300", tau_path, "0", q_path],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+        runs.append(np.frombuffer(open(q_path, "rb").read(), dtype=np.float64))
+    assert runs[0].size > 0 and np.isfinite(runs[0]).all() and np.abs(runs[0]).max() > 0.1
+    for k in range(1, 4):
+        assert runs[k].shape == runs[0].shape
+        assert np.abs(runs[k] - runs[0]).max() < 1e-8, (k, float(np.abs(runs[k] - runs[0]).max()))
