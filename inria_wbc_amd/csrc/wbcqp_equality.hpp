@@ -134,21 +134,27 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
         }
     };
     if (e == 0) prepare(0);
+    // A (numerically) dependent column does not leave the loop: it is remembered and reported at the end.  With an early return in the
+    // loop every step began with an LDS round trip of its own for (tau, alpha) before the reflector's ten reads were issued; without it
+    // alpha is off the critical path altogether and tau travels with the reflector.  What the remaining steps compute after a bad pivot
+    // (infinities, NaNs) is never used -- the caller gives up on the QP -- and no address depends on it.
+    bool bad = false;
     for (int j = 0; j < m; ++j) {
         bsync();
-        const double tj = sc[(j & 1) * 2], alpha = sc[(j & 1) * 2 + 1];
-        if (!(fabs(alpha) > 2.220446049250313e-16 * c.R_norm)) return false; // also catches a NaN pivot
-        c.R_norm = fmax(c.R_norm, fabs(alpha));
         const double* vb = vbuf + (j & 1) * 80 + 2 * kc;
         double2v v[10];
 #pragma unroll
         for (int t = 0; t < 10; ++t) v[t] = ld2(vb + 8 * t);
+        const double tj = sc[(j & 1) * 2], alpha = sc[(j & 1) * 2 + 1];
+        bad = bad || !(fabs(alpha) > 2.220446049250313e-16 * c.R_norm); // also catches a NaN pivot
+        c.R_norm = fmax(c.R_norm, fabs(alpha));
         if ((col1 && e > j) || row1) {
             apply(b, v, tj);
             if (e == j + 1 && j + 1 < m) prepare(j + 1);
         }
         if (has2) apply(b2, v, tj);
     }
+    if (bad) return false;
     // R packed, 1/R(j,j); J rows back to LDS
     if (col1) {
         double* Rc = c.R + roff(e);
