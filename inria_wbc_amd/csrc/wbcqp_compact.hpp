@@ -547,6 +547,18 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             eliminate_block<3, 2, true, 0>(c, hF, yF, la, le, 12, RBf, YBf, c.dinv + fb, c.lane < 4, c.lane & 3);
         }
         bsync(); // J is zero, every 1/sqrt(pivot) is published
+        // tr(H) and sum 1/sqrt(pivot) (the stopping rule's c1, c2): the waves' partial sums ride on the barrier that ends the J writes below
+        // (block_sum()'s arithmetic, without its two barriers)
+        {
+            double tr2 = 0.0;
+            for (int i = tid; i < n; i += kThreads) tr2 += c.dinv[i];
+            const double tw = wave_sum(trace), dw = wave_sum(tr2);
+            double* slot = c.red + c.rslot * 16;
+            if (c.lane == 0) {
+                slot[c.wave] = tw;
+                slot[4 + c.wave] = dw;
+            }
+        }
         // final: J(r,q) = Y(r,q) dinv[q], J(r,r) = dinv[r]
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -567,10 +579,12 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
         }
         bsync();
-        c1 = block_sum(c, trace);
-        double tr2 = 0.0;
-        for (int i = tid; i < n; i += kThreads) tr2 += c.dinv[i];
-        c2 = block_sum(c, tr2);
+        {
+            const double* slot = c.red + c.rslot * 16;
+            c1 = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+            c2 = (slot[4] + slot[5]) + (slot[6] + slot[7]);
+            c.rslot ^= 1;
+        }
     }
     STAMP(3)
 
@@ -604,7 +618,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 part = 0.5 * c.g[idx] * (-zv);
             }
         }
-        f_value = block_sum(c, part);
+        f_value = block_sum(c, part); // (its barrier also publishes x0 to the equality phase)
     }
     STAMP(4)
 
@@ -612,6 +626,15 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     const double inf = __builtin_huge_val();
     int status = -2; // running
     int iter = 0;
+    // the loop's flags, set here so that the equality phase's barriers make them visible (other threads read them in the first evaluation
+    // of s): with equalities the loop then needs no barrier of its own before it starts
+    if (nin2 > 0) {
+        if (tid < nin2) {
+            act[tid] = 0;
+            excl[tid] = 1;
+        }
+        if (tid >= n && tid < 80) c.xold[tid] = 0.0; // the second x buffer gets the same finite padding as the first (g, its tenant so far, ends at n)
+    }
 
     // ---------------- phase 3: equality constraints, blocked (equality_phase_blocked with N already in place) ----------------
     if (neq > 0) {
@@ -678,10 +701,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 for (int e = 0; e < m; ++e) acc = fma(Jr[e], rhs[e], acc);
                 c.x[kk] += acc;
             }
-            yy = block_sum(c, yy);
+            yy = block_sum(c, yy); // (its barrier is also the one the loop's set-up waits for: every read of J, R and y is behind it)
             f_value += 0.5 * yy;
             c.iq = m;
-            bsync();
         }
         STAMP(8)
     }
@@ -745,11 +767,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     // joint rr belong to lanes 0 (+) and 1 (-) of quad rr, which hold tau' in a register anyway.
     const bool act_ineq = D.act_bounds && na > 0; // actuation rows are inequality rows (otherwise tau' is only decoded)
     if (status == -2 && nin2 > 0) {
-        if (tid < nin2) {
-            act[tid] = 0;
-            excl[tid] = 1;
-        }
-        if (tid >= n && tid < 80) c.xold[tid] = 0.0; // the second x buffer gets the same finite padding as the first
+        // (the flags act[] / excl[] and the padding of the second x buffer were set ahead of the equality phase: see there)
         // friction rows as they are used: 12 coefficients per one-sided row, sign folded in, in LDS behind Ri and the rotation
         // coefficients (row (ct, sign, rr) at ((2 ct + sign) 17 + rr) 12).  Registers held them in round 2: 24 VGPRs of every thread
         // for the whole loop; and whoever needs the row of a picked friction constraint reads it here, nothing is published.
@@ -902,7 +920,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
             }
         };
-        bsync();
+        if (neq == 0) bsync(); // (with equalities: the barrier of the equality phase's last reduction)
         double* const Ri = c.R;                                      // inverse of R's inequality block (R itself is dead: solve_y was its last reader)
         double* const prm = c.R + ((roff(n - neq + 1) + 1) & ~1);    // rotation coefficients of a drop, behind the largest Ri
         double* const dbuf0 = lds + D.o_vec + cp::D;                 // d lives in one of two buffers (a drop writes the other one);
