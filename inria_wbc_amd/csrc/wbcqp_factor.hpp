@@ -54,12 +54,16 @@ __device__ __forceinline__ void eliminate_block(Ctx& c, double (&h)[NU][NU], dou
         const double* rb = RB + par * PS;
         const double* yb = YB + par * PS;
         // operands: pivot block, this thread's row-role and column-role slices, its rows of Y
+        // the pivot block: only its upper triangle is read (H(p,q) = hq[q][p>>1][p&1], p <= q), each piece with a load of exactly its width.
+        // (Whole 16-byte pairs for all four columns left half-dead destination registers, which the allocator reused for the next pair:
+        // a write-after-write hazard the compiler guards with `s_waitcnt lgkmcnt(0)` right behind the first load of every panel step.)
         double2v hq[4][2], fa[NU][2], fe[NU][2], fr[NU][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            hq[q][0] = ld2(rb + (j0 + q) * 4);
-            hq[q][1] = ld2(rb + (j0 + q) * 4 + 2);
-        }
+        hq[0][0].x = rb[j0 * 4];
+        hq[1][0] = ld2(rb + (j0 + 1) * 4);
+        hq[2][0] = ld2(rb + (j0 + 2) * 4);
+        hq[2][1].x = rb[(j0 + 2) * 4 + 2];
+        hq[3][0] = ld2(rb + (j0 + 3) * 4);
+        hq[3][1] = ld2(rb + (j0 + 3) * 4 + 2);
 #pragma unroll
         for (int u = JB; u < NU; ++u) {
             fe[u][0] = ld2(rb + (te + G * u) * 4);
