@@ -753,6 +753,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         for (int u = 0; u < cp::KQ; ++u) ar.aj[u] = 0.0;
     }
 
+    STAMP(7)
+
     // ---------------- phase 4: inequality loop (GI steps 1, 2, 2a-2c) ----------------
     // The common iteration (full step, constraint accepted) takes THREE barriers (two when the row is a bound):
     //   A  d = J'n from the published row (bounds: d is a row of J, formed inside B)                                  | bar

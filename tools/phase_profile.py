@@ -16,7 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-NAMES = ["load", "assemble_Hg", "cholesky", "J=U^-1", "x0", "eq:N,rhs,B=J0'N", "eq:QR", "eq:(unused)", "eq:solve x,u (+Givens path)",
+NAMES = ["load", "assemble_Hg", "cholesky", "J=U^-1", "x0", "eq:N,rhs,B=J0'N", "eq:QR", "actuation rows -> registers", "eq:solve x,u (+Givens path)",
          "in:s+psi+save", "in:argmin+build", "in:d", "in:z+r", "in:steplen+step", "in:add", "in:delete",
          "loop-exit", "decode+store", "in:B z dot (compact)", "eq:W<-WT || y,u", "in:C scalars (compact)", "in:C J update (compact) | eq:N build (full)", "eq:rhs", "in:C next s (compact)"]
 
