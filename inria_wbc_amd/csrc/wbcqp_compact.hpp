@@ -801,6 +801,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
             }
         }
+#ifdef WBCQP_STAMP_FIRST_PICK
+        STAMP(22)
+#endif
         const int arr = tid >> 2, aq = tid & 3;
         const bool act_owner = act_ineq && arr < na && aq < 2;
         const int arow = act_owner ? D.act_off + (aq ? na : 0) + arr : -1;
@@ -947,8 +950,16 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         c.Aold[i] = c.A[i];
                     }
                     ValIdx bw;
+#ifdef WBCQP_STAMP_FIRST_PICK // (tools/phase_profile.py --lib: the way to the first pick split four ways, under the names of phases 22, 5, 19 and 6)
+                    STAMP(5)
+                    eval_rows(c.x, c.z, 0.0, -1, best, bw);
+                    STAMP(19)
+                    publish_best(best, bw);
+                    STAMP(6)
+#else
                     eval_rows(c.x, c.z, 0.0, -1, best, bw);
                     publish_best(best, bw);
+#endif
                     bsync(); // B1
                 }
                 slow = false;
@@ -1389,7 +1400,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     }
 #ifdef WBCQP_STAMPS
     STAMP(17)
-    if (tid == 0 && ga.dbg)
+    if (tid == WBCQP_STAMP_TID && ga.dbg) // (the stamps are per wave: -DWBCQP_STAMP_TID=192 shows wave 3's view of the phases)
         for (int i = 0; i < kStamps; ++i) ga.dbg[qp * kStamps + i] = c.st_acc_[i];
 #endif
 }

@@ -977,7 +977,7 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
     }
 #ifdef WBCQP_STAMPS
     STAMP(17)
-    if (tid == 0 && ga.dbg)
+    if (tid == WBCQP_STAMP_TID && ga.dbg) // (the stamps are per wave: -DWBCQP_STAMP_TID=192 shows wave 3's view of the phases)
         for (int i = 0; i < kStamps; ++i) ga.dbg[qp * kStamps + i] = c.st_acc_[i];
 #endif
 }

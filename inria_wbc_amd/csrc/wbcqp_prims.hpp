@@ -134,6 +134,9 @@ __device__ __forceinline__ double gi_distance(double a, double b)
 
 // In-kernel phase stamps (diagnostic build only: -DWBCQP_STAMPS). Never compiled into the product library.
 #ifdef WBCQP_STAMPS
+#ifndef WBCQP_STAMP_TID
+#define WBCQP_STAMP_TID 0
+#endif
 constexpr int kStamps = 24;
 #define STAMP_DECL c.st_prev_ = clock64(); for (int i_ = 0; i_ < kStamps; ++i_) c.st_acc_[i_] = 0;
 #define STAMP(i) { long long now_ = clock64(); c.st_acc_[i] += now_ - c.st_prev_; c.st_prev_ = now_; }
