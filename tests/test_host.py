@@ -213,3 +213,19 @@ _ZN5wbcqp1kEv:                          ; @_ZN5wbcqp1kEv
     p.write_text(bad)
     total, flagged = check_barriers(str(p))
     assert total == 3 and [ln for _, ln in flagged] == [5, 9, 11] and flagged[0][0] == "_ZN5wbcqp1kEv"
+
+
+def test_every_workgroup_barrier_in_the_sources_is_bsync():
+    """Source-level half of the barrier rule (the build checks the assembly): __syncthreads() appears once, inside bsync(), which issues the
+    LDS wait the compiler may drop (csrc/wbcqp_prims.hpp)."""
+    import re
+    csrc = os.path.join(ROOT, "inria_wbc_amd", "csrc")
+    hits = []
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hpp", ".hip")):
+            continue
+        for i, ln in enumerate(open(os.path.join(csrc, fn)).read().splitlines(), 1):
+            code = ln.split("//")[0]
+            if re.search(r"__syncthreads\s*\(|__builtin_amdgcn_s_barrier\s*\(", code):
+                hits.append((fn, i))
+    assert len(hits) == 1 and hits[0][0] == "wbcqp_prims.hpp", hits
