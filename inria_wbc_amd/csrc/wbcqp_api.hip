@@ -681,7 +681,7 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     {
         std::vector<unsigned> ap((size_t)D.n_dense * D.nv + 1, 0u);
         for (int r = 0; r < D.n_dense; ++r)
-            for (int col = 0; col < D.nv; ++col) ap[(size_t)r * D.nv + col] = (unsigned)(r * 64 + (col & 15) * 4 + (col >> 4));
+            for (int col = 0; col < D.nv; ++col) ap[(size_t)r * D.nv + col] = (unsigned)(r * 64 + ((col >> 5) & 1) * 32 + (col & 15) * 2 + ((col >> 4) & 1)); // see wbcqp_types.hpp, apack
         UP(apack, ap.data(), D.n_dense * D.nv);
     }
     {

@@ -444,14 +444,14 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
 #pragma unroll
                 for (int w = 0; w < 4; ++w) h[u][w] = 0.0;
             double gacc[4] = {0.0, 0.0, 0.0, 0.0};
-            const double* Ai = As + ta * 4;
-            const double* Aj = As + te * 4;
+            const double* Ai = As + ta * 2; // (layout of a staged row: wbcqp_types.hpp, apack)
+            const double* Aj = As + te * 2;
             const double* WB = As + n_dense * 64;
             auto ldrow = [&](int r, double2v (&ai)[2], double2v (&aj)[2], double2v& wb) __attribute__((always_inline)) {
                 ai[0] = ld2(Ai + r * 64);
-                ai[1] = ld2(Ai + r * 64 + 2);
+                ai[1] = ld2(Ai + r * 64 + 32);
                 aj[0] = ld2(Aj + r * 64);
-                aj[1] = ld2(Aj + r * 64 + 2);
+                aj[1] = ld2(Aj + r * 64 + 32);
                 wb = ld2(WB + 2 * r);
             };
             auto macrow = [&](const double2v (&ai)[2], const double2v (&aj)[2], const double2v& wb) __attribute__((always_inline)) {

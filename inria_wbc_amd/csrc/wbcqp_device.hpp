@@ -59,8 +59,8 @@ __device__ __forceinline__ void assemble_eliminate_dense(Ctx& c, const DevStruct
     {
         const double* WB = As + n_dense * 64;
         for (int r = 0; r < n_dense; ++r) {
-            const double2v ai0 = ld2(As + r * 64 + ta * 4), ai1 = ld2(As + r * 64 + ta * 4 + 2);
-            const double2v aj0 = ld2(As + r * 64 + te * 4), aj1 = ld2(As + r * 64 + te * 4 + 2);
+            const double2v ai0 = ld2(As + r * 64 + ta * 2), ai1 = ld2(As + r * 64 + ta * 2 + 32);
+            const double2v aj0 = ld2(As + r * 64 + te * 2), aj1 = ld2(As + r * 64 + te * 2 + 32);
             const double2v wb = ld2(WB + 2 * r);
             const double a[4] = {ai0.x, ai0.y, ai1.x, ai1.y};
             const double b[4] = {aj0.x, aj0.y, aj1.x, aj1.y};
@@ -389,14 +389,14 @@ __device__ __forceinline__ void solve_one(const GroupArgs<TI>& ga, const DevStru
                 for (int w = 0; w < 4; ++w) h[u][w] = 0.0;
             // rows of the next task line are in flight while this one multiplies; g_j = -sum_r w_r A(r,j) b(r) rides along
             double gacc[4] = {0.0, 0.0, 0.0, 0.0};
-            const double* Ai = As + ta * 4;
-            const double* Aj = As + te * 4;
+            const double* Ai = As + ta * 2; // (layout of a staged row: wbcqp_types.hpp, apack)
+            const double* Aj = As + te * 2;
             const double* WB = As + n_dense * 64;
             auto ldrow = [&](int r, double2v (&ai)[2], double2v (&aj)[2], double2v& wb) __attribute__((always_inline)) {
                 ai[0] = ld2(Ai + r * 64);
-                ai[1] = ld2(Ai + r * 64 + 2);
+                ai[1] = ld2(Ai + r * 64 + 32);
                 aj[0] = ld2(Aj + r * 64);
-                aj[1] = ld2(Aj + r * 64 + 2);
+                aj[1] = ld2(Aj + r * 64 + 32);
                 wb = ld2(WB + 2 * r);
             };
             auto macrow = [&](const double2v (&ai)[2], const double2v (&aj)[2], const double2v& wb) __attribute__((always_inline)) {

@@ -53,7 +53,11 @@ struct DevStruct {
     const double *fric_mat, *fric_lb, *fric_ub;
     const int* rowmeta;      // [nin2] packed descriptor of every one-sided inequality row (see row_meta_*)
     const unsigned* mpack;   // [nv(nv+1)/2] packed-M element e=(i,j) -> LDS offsets (i ldm + j) | (j ldm + i) << 16
-    const unsigned* apack;   // [n_dense nv] task-row element (r, col) -> offset r 64 + (col & 15) 4 + (col >> 4) in the staged rows
+    const unsigned* apack;   // [n_dense nv] task-row element (r, col) -> offset in the staged rows: with t = col & 15, u = col >> 4 (thread (ta, te) of the
+                             // 16 x 16 grid reads columns t + 16 u, u < 4, as two 16-byte pairs) r 64 + (u >> 1) 32 + 2 t + (u & 1): the sixteen
+                             // pairs (u = 0, 1) of a row are contiguous, then the sixteen pairs (u = 2, 3) -- a 16-byte read by sixteen lanes with
+                             // consecutive t covers 256 contiguous bytes.  (Until round 4: r 64 + 4 t + u, the two pairs of a lane side by side:
+                             // lanes t and t + 8 then met in the same banks, and the H loop is bound by the LDS pipe.)
     // LDS layout: leading dimensions and element offsets (in doubles)
     int ldj, ldm, ldc, ldb;
     int o_J, o_R, o_M, o_Jc, o_Ac, o_vec, o_eqw, o_eqt;
