@@ -22,21 +22,25 @@ template <int LG, int NU, bool WLOCAL, int UU>
 __device__ __forceinline__ void publish_panel(Ctx& c, double (&h)[NU][NU], double (&y)[NU][NU], int ta, int te, int j0n,
                                               double* RB, double* YB)
 {
-    constexpr int G = 1 << LG, PS = NU * G * 4;
+    // A panel buffer holds four values per index k (the four pivot rows of column k of H; the four pivot columns of row k of Y) in two planes:
+    // value p of index k at (p >> 1) HP + 2 k + (p & 1).  A thread reads them as two 16-byte pairs; sixteen lanes with consecutive k then
+    // cover 256 contiguous bytes per read, and the 8-byte stores of a publishing row land in distinct banks.  (Until round 4: 4 k + p, the
+    // two pairs side by side -- lanes k and k + 8 in the same banks.)
+    constexpr int G = 1 << LG, PS = NU * G * 4, HP = PS / 2;
     const int par = WLOCAL ? 0 : ((j0n >> 2) & 1);
     const int grp = (j0n & (G - 1)) >> 2;
     if ((ta >> 2) == grp) { // rows j0n + p, p = ta & 3
-        double* dst = RB + par * PS + (ta & 3);
+        double* dst = RB + par * PS + ((ta >> 1) & 1) * HP + (ta & 1);
 #pragma unroll
-        for (int w = UU; w < NU; ++w) dst[(te + G * w) * 4] = h[UU][w];
+        for (int w = UU; w < NU; ++w) dst[(te + G * w) * 2] = h[UU][w];
     }
     if ((te >> 2) == grp) { // columns j0n + p of Y, p = te & 3
         const int pp = te & 3;
-        double* dst = YB + par * PS + pp;
+        double* dst = YB + par * PS + ((te >> 1) & 1) * HP + (te & 1);
 #pragma unroll
-        for (int u = 0; u < UU; ++u) dst[(ta + G * u) * 4] = y[u][UU];
+        for (int u = 0; u < UU; ++u) dst[(ta + G * u) * 2] = y[u][UU];
         const int r = ta + G * UU;
-        dst[r * 4] = (r < j0n) ? y[UU][UU] : ((r == j0n + pp) ? 1.0 : 0.0);
+        dst[r * 2] = (r < j0n) ? y[UU][UU] : ((r == j0n + pp) ? 1.0 : 0.0);
     }
 }
 
@@ -44,7 +48,7 @@ template <int LG, int NU, bool WLOCAL, int JB>
 __device__ __forceinline__ void eliminate_block(Ctx& c, double (&h)[NU][NU], double (&y)[NU][NU], int ta, int te, int npad,
                                                 double* RB, double* YB, double* dinv, bool dwriter, int dp)
 {
-    constexpr int G = 1 << LG, PS = NU * G * 4;
+    constexpr int G = 1 << LG, PS = NU * G * 4, HP = PS / 2;
     constexpr int JN = (JB + 1 < NU) ? JB + 1 : JB;
     const int jend = min(G * JB + G, npad);
     for (int j0 = G * JB; j0 < jend; j0 += 4) {
@@ -58,23 +62,23 @@ __device__ __forceinline__ void eliminate_block(Ctx& c, double (&h)[NU][NU], dou
         // (Whole 16-byte pairs for all four columns left half-dead destination registers, which the allocator reused for the next pair:
         // a write-after-write hazard the compiler guards with `s_waitcnt lgkmcnt(0)` right behind the first load of every panel step.)
         double2v hq[4][2], fa[NU][2], fe[NU][2], fr[NU][2];
-        hq[0][0].x = rb[j0 * 4];
-        hq[1][0] = ld2(rb + (j0 + 1) * 4);
-        hq[2][0] = ld2(rb + (j0 + 2) * 4);
-        hq[2][1].x = rb[(j0 + 2) * 4 + 2];
-        hq[3][0] = ld2(rb + (j0 + 3) * 4);
-        hq[3][1] = ld2(rb + (j0 + 3) * 4 + 2);
+        hq[0][0].x = rb[j0 * 2];
+        hq[1][0] = ld2(rb + (j0 + 1) * 2);
+        hq[2][0] = ld2(rb + (j0 + 2) * 2);
+        hq[2][1].x = rb[HP + (j0 + 2) * 2];
+        hq[3][0] = ld2(rb + (j0 + 3) * 2);
+        hq[3][1] = ld2(rb + HP + (j0 + 3) * 2);
 #pragma unroll
         for (int u = JB; u < NU; ++u) {
-            fe[u][0] = ld2(rb + (te + G * u) * 4);
-            fe[u][1] = ld2(rb + (te + G * u) * 4 + 2);
-            fa[u][0] = ld2(rb + (ta + G * u) * 4);
-            fa[u][1] = ld2(rb + (ta + G * u) * 4 + 2);
+            fe[u][0] = ld2(rb + (te + G * u) * 2);
+            fe[u][1] = ld2(rb + HP + (te + G * u) * 2);
+            fa[u][0] = ld2(rb + (ta + G * u) * 2);
+            fa[u][1] = ld2(rb + HP + (ta + G * u) * 2);
         }
 #pragma unroll
         for (int u = 0; u <= JB; ++u) {
-            fr[u][0] = ld2(yb + (ta + G * u) * 4);
-            fr[u][1] = ld2(yb + (ta + G * u) * 4 + 2);
+            fr[u][0] = ld2(yb + (ta + G * u) * 2);
+            fr[u][1] = ld2(yb + HP + (ta + G * u) * 2);
         }
         // H_PP = U~' D U~ : H(p,q) = hq[q][p>>1][p&1] for p <= q
         const double a0 = hq[0][0].x, i0 = fast_rcp(a0);
