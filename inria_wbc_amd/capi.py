@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwbcqp.so")
 WBCQP_OK = 0
 ERR_NAMES = {0: "OK", 1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "NO_DEVICE", 5: "RCCL"}
 F64, F32 = 0, 1
+K_STAMPS = 32  # phase stamps per QP of the -DWBCQP_STAMPS diagnostic build (kStamps, csrc/wbcqp_prims.hpp)
 FIELDS = ("M", "h", "A", "b1", "Ac", "bc", "blb", "bub", "tlb", "tub", "w", "Acop")
 
 # every symbol include/wbcqp.h declares

@@ -282,21 +282,30 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
     D.compact = 0;
     if (F.dense_h) return false; // a torque / cop task: H is one n x n matrix, the compact kernel factors a dv block and 12 x 12 blocks
     const int n = F.n, nv = F.nv;
-    if (!(n <= 80 && F.neq <= 22 && nv <= 52 && F.nc <= 2 && F.nu <= 8 && F.na <= 64 && F.n_bound <= 64 && F.nin2 <= 256 &&
+    // (n <= 78: the 80-entry vector slots hold a zero pad pair behind column n for the loop's 16-byte row passes)
+    if (!(n <= 78 && F.neq <= 22 && nv <= 52 && F.nc <= 2 && F.nu <= 8 && F.na <= 64 && F.n_bound <= 64 && F.nin2 <= 256 &&
           F.r1 <= 128 && F.n_tasks <= 64 && (!F.act_bounds || F.act_off >= 0) && n - F.neq <= 64))
         return false;
     int o = 0;
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; };
+    // rows of J: 16-byte aligned with at least one zero pad pair behind column n, and 2 x odd long -- sixteen rows then start in sixteen
+    // different bank groups for 8-byte and for 16-byte accesses alike
+    {
+        int l = ((n + 1) & ~1) + 2;
+        while ((l & 3) != 2) l += 2;
+        D.ldj = l;
+    }
     const int as_size = (F.n_dense * 66 + 8 + 1) & ~1;   // staged task rows: 64 columns + (w, b) pairs
-    int jsize = n * F.ldj;
+    int jsize = n * D.ldj;
     if (as_size + 1024 > jsize) jsize = as_size + 1024;  // + the elimination's panels (2 x 2 x 256)
     D.o_pan = as_size;
     D.o_J = take(jsize);
-    int rs = n * (n + 3) / 2 + 2;
+    int rs = 512;                                        // packed R of the equalities (neq <= 22 columns)
     if (F.neq > 0 && 256 + (n + 4) * F.ldb + 8 > rs) rs = 256 + (n + 4) * F.ldb + 8; // N = CE', then B = J0'N
-    {   // the inequality loop keeps Ri (packed, n - neq columns) and the 2 (n - neq) rotation coefficients of a drop there
+    {   // the inequality loop: Ri (row-packed, n - neq rows, one spare element per row, 64 doubles of over-read behind it), four doubles per
+        // rotation of a drop, the friction rows' table
         const int mmax = n - F.neq;
-        const int need = (((mmax + 1) * (mmax + 4) / 2 + 1) & ~1) + 2 * mmax + 16 + F.nc * 34 * 12 + 2; // + the friction rows' table
+        const int need = ((mmax * (mmax + 3) / 2 + 64 + 1) & ~1) + 4 * (mmax + 2) + F.nc * 34 * 12 + 2;
         if (need > rs) rs = need;
     }
     D.o_R = take(rs);

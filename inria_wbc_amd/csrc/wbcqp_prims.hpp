@@ -137,7 +137,7 @@ __device__ __forceinline__ double gi_distance(double a, double b)
 #ifndef WBCQP_STAMP_TID
 #define WBCQP_STAMP_TID 0
 #endif
-constexpr int kStamps = 24;
+constexpr int kStamps = 32;
 #define STAMP_DECL c.st_prev_ = clock64(); for (int i_ = 0; i_ < kStamps; ++i_) c.st_acc_[i_] = 0;
 #define STAMP(i) { long long now_ = clock64(); c.st_acc_[i] += now_ - c.st_prev_; c.st_prev_ = now_; }
 #else
@@ -227,6 +227,7 @@ __device__ __forceinline__ int block_max_int(Ctx& c, int v)
 // LDS table) -- it matters in the loops that are LDS-bound.  opaque() hides how a pointer was derived, so the load/store
 // optimizer cannot pair its accesses with a neighbour's; ld2() is the 16-byte-aligned pair read.
 typedef double double2v __attribute__((ext_vector_type(2)));
+typedef int int4v __attribute__((ext_vector_type(4)));
 // 1/x to full precision without the IEEE division's scaling and fix-up: v_rcp_f64 and two Newton steps
 __device__ __forceinline__ double fast_rcp(double x)
 {

@@ -95,7 +95,7 @@ def test_every_kernel_writes_the_active_mask():
     B = 64
     inp = synth.generate(st, B, synth.SEED_BASE["talos"] + 5, task_noise=2.0)
     d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items() if v.size}
-    masks = {}
+    masks, xs = {}, {}
     for name, flags in (("compact", 0), ("full", capi.FLAG_FULL_LDS)):
         h = capi.Handle(0, capi.F64, flags=flags)
         h.set_structure(0, st)
@@ -103,12 +103,18 @@ def test_every_kernel_writes_the_active_mask():
         h.solve_batch(0, B, d_in, o, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         masks[name] = o["active_mask"].cpu().numpy().view(np.uint32)
+        xs[name] = o["x"].cpu().numpy()
         nact = np.array([bin(int(w)).count("1") for w in masks[name].ravel()]).reshape(B, 8).sum(axis=1)
         assert (o["status"].cpu().numpy() == 0).all()
         assert nact.max() > 0 and (nact <= o["iters"].cpu().numpy()).all()  # a row enters the active set in an iteration of its own
         h.close()
     same = (masks["compact"] == masks["full"]).all(axis=1).mean()
-    assert same >= 0.95, same  # the two layouts agree on the active set wherever no tie is broken by rounding
+    # The two layouts run the same algorithm with different arithmetic (round 5: the compact loop applies a constraint's reflector one pick
+    # late, folded into the next d and z); where they end on different active sets they still end on the same point -- the rows that differ
+    # carry multipliers at rounding level (measured: 58 of 64 masks equal, x of the other six within 3e-11 of each other)
+    assert same >= 0.85, same
+    scale = np.maximum(1.0, np.abs(xs["full"]).max(axis=1))
+    assert (np.abs(xs["compact"] - xs["full"]).max(axis=1) / scale).max() <= 1e-9
     # Tiago: bounds only, one wavefront per QP
     stt = structure.STRUCTURES["tiago"]()
     inp = synth.generate(stt, 256, synth.SEED_BASE["tiago"] + 3, task_noise=30.0)

@@ -30,7 +30,7 @@ def main():
         h = capi.Handle(0, capi.F64, flags=capi.FLAG_INDEX_ORDER)
         h.set_structure(0, st)
         if "stamps" in which:
-            dbg = torch.zeros(B, 24, dtype=torch.int64, device=dev)
+            dbg = torch.zeros(B, capi.K_STAMPS, dtype=torch.int64, device=dev)
             lib.wbcqp_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
             assert lib.wbcqp_debug_set_stamp_buffer(h._h, C.c_void_p(dbg.data_ptr())) == 0
         h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)

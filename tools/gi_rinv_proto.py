@@ -73,6 +73,8 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False, st
                 break
             npv = CI[ip]
             sip = s[ip]
+            if trace is not None:
+                trace.setdefault("events", []).append(("pick", ip, iq - neq))
             u[iq] = 0.0
             A = A[:iq] + [ip]
             d = J.T @ npv
@@ -110,6 +112,8 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False, st
                 partial_steps += 1
                 # ---- drop position lpos: rotations from the prefix sum over row p of Ri
                 p = lpos
+                if trace is not None:
+                    trace.setdefault("events", []).append(("drop", p, iq - neq))
                 act[A[neq + p]] = False
                 rho = Ri[p, p:mi].copy()
                 S = np.cumsum(rho * rho)

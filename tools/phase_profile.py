@@ -18,7 +18,8 @@ sys.path.insert(0, ROOT)
 
 NAMES = ["load", "assemble_Hg", "cholesky", "J=U^-1", "x0", "eq:N,rhs,B=J0'N", "eq:QR", "actuation rows -> registers", "eq:solve x,u (+Givens path)",
          "in:s+psi+save", "in:argmin+build", "in:d", "in:z+r", "in:steplen+step", "in:add", "in:delete",
-         "loop-exit", "decode+store", "in:B z dot (compact)", "eq:W<-WT || y,u", "in:C scalars (compact)", "in:C J update (compact) | eq:N build (full)", "eq:rhs", "in:C next s (compact)"]
+         "loop-exit", "decode+store", "in:B z dot (compact)", "eq:W<-WT || y,u", "in:C scalars (compact)", "in:C J update (compact) | eq:N build (full)", "eq:rhs", "in:C next s (compact)",
+         "in:A d (work, before its barrier)", "in:B tail (reductions; wave 3: r, t1, scalars)", "in:C publish", "in:D1 (work)", "in:D2 (work)", "", "", ""]
 
 
 def main():
@@ -61,7 +62,7 @@ def main():
         d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
     d_out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
                  status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
-    dbg = torch.zeros(B, 24, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(B, capi.K_STAMPS, dtype=torch.int64, device=dev)
     h = capi.Handle(0, capi.F64, flags=args.flags | capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH)
     h.set_structure(0, st)
     lib.wbcqp_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]

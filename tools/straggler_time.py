@@ -79,7 +79,7 @@ def main():
         from tools.phase_profile import NAMES
         lib = capi.load_library()
         lib.wbcqp_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
-        dbg = torch.zeros(1, 24, dtype=torch.int64, device=dev)
+        dbg = torch.zeros(1, capi.K_STAMPS, dtype=torch.int64, device=dev)
         assert lib.wbcqp_debug_set_stamp_buffer(h._h, C.c_void_p(dbg.data_ptr())) == 0
         for r in (rows[0], rows[4]):
             one = {k: v[r[0]:r[0] + 1].contiguous() for k, v in d_in.items()}
