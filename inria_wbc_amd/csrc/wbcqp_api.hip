@@ -305,7 +305,7 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
     {   // the inequality loop: Ri (row-packed, n - neq rows, one spare element per row, 64 doubles of over-read behind it), four doubles per
         // rotation of a drop, the friction rows' table
         const int mmax = n - F.neq;
-        const int need = ((mmax * (mmax + 3) / 2 + 64 + 1) & ~1) + 4 * (mmax + 2) + F.nc * 34 * 12 + 2;
+        const int need = ((2 + mmax * (mmax + 3) / 2 + 64 + 1) & ~1) + 4 * (mmax + 2) + F.nc * 34 * 12 + 2;
         if (need > rs) rs = need;
     }
     D.o_R = take(rs);

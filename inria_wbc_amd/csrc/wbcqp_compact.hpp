@@ -41,7 +41,7 @@ constexpr int X = 0, NP = 80, D = 160, Z = 240, XOLD = 320, R = 400, U = 480 /* 
 // dead-time aliases: g and 1/sqrt(pivot) die with x0, the weights with the force blocks, b1 with the assembly.  The S slot (b1, the force
 // blocks' panels, the equality QR's reflector) is free in the inequality loop: the pending update's w, d of the active positions and the
 // block-reduction scratch of the loop's rare paths live there; the loop's own slots (lp::) take RED and CE0.
-constexpr int G = XOLD, DINV = UOLD, W = R, B1 = S, PRM = D, PW = S, DI = S + 80 /* 128 */, LRED = S + 208 /* 32 */;
+constexpr int G = XOLD, DINV = UOLD, W = R, B1 = S, PRM = D, PW = S, DI = S + 80 /* 128 */, LRED = S + 208 /* 32 */, EL = S + 240 /* 8 */;
 // int region (ints)
 constexpr int IA = 0 /* n + 2 <= 84 */, IAOLD = 84, IACT = 164 /* 256 bytes */, IEXCL = 228, ICOUNT = 292;
 constexpr int NVQ = 13; // ceil(52 / 4): M_a coefficients per lane of a row's quad
@@ -225,20 +225,14 @@ namespace lp {
 // at least one barrier lies between its readers and the next write -- no double buffering.  The phase-B / drop fields sit where the set-up's
 // block reductions had their slots (first written two barriers into the loop); the pick's fields, which are written before the loop's first
 // barrier, in CE0 (y of the equality phase: read for the last time before the set-up's final barrier).
-constexpr int BZ = 0 /* z'z per wave (3); 3: */, BT1 = 3, BDN2 = 4, BALPHA = 5, BV0 = 6, BTAU = 7, BLPOS = 8 /* int at 2 BLPOS */, NPW = 9, DDELTA = 10, DCL = 11,
-              DRHO0 = 12;
-constexpr int PKV = 32 /* most violated row per wave: value (4) */, PKI = 2 * 36 /* row (4 ints) */, PKM = 2 * 38 /* descriptor (4 ints) */,
-              PWV = 40 /* the same among the warm start's hinted rows */, PWI = 2 * 44, PWM = 2 * 46;
+constexpr int BZF = 0 /* 3 ints (doubles 0, 1): a wave's rows hold a z_k^2 > eps */, BDN2 = 2, BALPHA = 3, BV0 = 4, BTAU = 5, BT2C = 6, NPW = 7, DDELTA = 8, DCL = 9,
+              DRHO0 = 10;
+// election slots (doubles from cp::EL; `u` entries index the same area as unsigned): two generations of the pick's (minimum, word), the same for
+// the warm start's hinted rows, one of the step length's (minimum, position)
+constexpr int EMIN = 0 /* 2 */, EKEY = 2 * 2 /* 2 u */, EWMIN = 3 /* 2 */, EWKEY = 2 * 5 /* 2 u */, ET1 = 6, ET1POS = 2 * 7 /* u */;
+constexpr double kNone = 1e300; // "nobody stood": any candidate (s < 0) is below it
 // row i of the row-packed inverse: elements (i, j), i <= j <= MM (one spare, always zero), at rio(i, MM) + j - i
 __device__ __forceinline__ int rio(int i, int MM) { return i * (MM + 1) - ((i * (i - 1)) >> 1); }
-// lexicographic minimum of (value, row) that carries the row's descriptor along
-__device__ __forceinline__ void take_min(ValIdx& a, int& am, double v, int i, int m)
-{
-    const bool tb = (v < a.v) || (v == a.v && i < a.i);
-    a.v = tb ? v : a.v;
-    a.i = tb ? i : a.i;
-    am = tb ? m : am;
-}
 // One row (J's or Ri's) through the L rotations of a drop in their closed form: with P_l = sum_{i <= l} rho_i x_i the element of the new
 // column l is a_l P_l + b_l x_{l+1} (prm[4 l], [4 l + 1]; rho_{l+1} at [4 l + 2]).  P enters as rho_0 x_0 and returns as P_L, whose multiple
 // -P_L / sqrt(S_L) is the element that leaves the active block.  get(jj) loads x_jj (the caller masks what does not exist), put(jj, v) stores
@@ -680,6 +674,12 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             excl[tid] = 1;
         }
         if (tid >= n && tid < 80) c.xold[tid] = 0.0; // the second x buffer gets the same finite padding as the first (g, its tenant so far, ends at n)
+        if (tid == 0) { // the loop's election slots (lp::E*), both generations armed
+            double* EL0 = lds + D.o_vec + cp::EL;
+            unsigned* EL0u = reinterpret_cast<unsigned*>(EL0);
+            EL0[lp::EMIN] = lp::kNone; EL0[lp::EMIN + 1] = lp::kNone; EL0[lp::EWMIN] = lp::kNone; EL0[lp::EWMIN + 1] = lp::kNone;
+            EL0u[lp::EKEY] = 0xffffffffu; EL0u[lp::EKEY + 1] = 0xffffffffu; EL0u[lp::EWKEY] = 0xffffffffu; EL0u[lp::EWKEY + 1] = 0xffffffffu;
+        }
     }
 
     // ---------------- phase 3: equality constraints, blocked (equality_phase_blocked with N already in place) ----------------
@@ -802,19 +802,28 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     STAMP(7)
 
     // ---------------- phase 4: inequality loop (GI steps 1, 2, 2a-2c) ----------------
-    // One pick, constraint accepted with a full step, is THREE barriers (four when the row is an actuation row, whose coefficients live in
-    // the registers of one quad and have to be published first):
-    //   P  every thread reads the four waves' candidates (value, row, row descriptor) and knows the pick
+    // What the loop is built from costs, measured on one wave of this kernel's shape (tools/ubench/chain_lat.hip, lds_atomics.hip): a dependent
+    // f64 FMA 4 cycles; one DPP reduction step on a double 24-38 (a wave-wide sum about 250, a two-pass argmin 500-700); a vector compare
+    // feeding a scalar branch 33-44; an LDS round trip 50-65; an LDS atomic to one address 50 + about 10 per participating lane.  So the
+    // loop avoids wave-wide reductions and uniform branches, not arithmetic:
+    //   * the most violated row is ELECTED through LDS atomics: the few lanes whose row is violated (at most some twenty, usually under
+    //     ten) do ds_min_f64 on one slot | barrier | the lanes that hold the minimum do ds_min_u32 with (row << 23 | row descriptor) --
+    //     smallest row first, eiquadprog's rule -- | barrier | every thread reads the pick and its descriptor in one word.  The step
+    //     length t1 is elected the same way inside wave 3 (no barrier: one wave's LDS operations execute in order);
+    //   * z'z is only ever compared with eps: a wave whose rows hold one z_k^2 > eps says so by ballot, and the sum is formed only when no
+    //     wave does (never observed outside degenerate picks);
+    //   * the common iteration -- full step, constraint accepted -- is decided by ONE branch.
+    // One pick with a full step:
+    //   P  decode the elected word                                                                                              (E2)
     //   A  d = J'n for the columns from neq on -- from J as it stands plus the PENDING rank-one update of the last accepted
     //      constraint, d = J_old'n - v (w'n): a bound's d is a corrected row of J (one wave, one round trip), a friction row's a
-    //      twelve-term sum per column on a quad, an actuation row's a quad per column over the published row.  V = d from iq on
-    //      (zero below), dI = d of the active inequality positions (zero from mi on)                                              | bar
+    //      twelve-term sum per column on a quad, an actuation row's a quad per column over the row its owners publish (one more
+    //      barrier).  V = d from iq on (zero below), dI = d of the active inequality positions (zero from mi on)                   | bar A
     //   B  waves 0-2, a lane pair per row of J: the pending update J <- J - w v' and z = J2 d2 in ONE pass over the row (16-byte
-    //      reads and writes; the update used to be a pass of its own in phase C); wave 3: r = Ri d_I (Ri row-packed, zero from mi
-    //      on: no masks), the step length t1, |d2|^2 and everything that follows from it (t2, alpha, v0, tau, 1/alpha)            | bar
-    //   C  t, then per row k: w_k = tau (z_k - alpha J(k, iq)) becomes the next pending update, x_next into the other x buffer,
-    //      u and the new column of Ri on wave 3's lanes (which hold r), s of the next iterate by increments on the lanes that own
-    //      the rows, the most violated row reduced and published with its descriptor                                             | bar
+    //      accesses); wave 3: r = Ri d_I (Ri row-packed, zero from mi on: no masks), t1 elected, |d2|^2, the reflector, t2           | bar B
+    //   C  per row k: w_k = tau (z_k - alpha J(k, iq)) becomes the next pending update, x_next into the other x buffer, u and the
+    //      new column of Ri on wave 3's lanes (which hold r), s of the next iterate by increments on the lanes that own the rows,
+    //      then the election of the next pick                                                                                    | bar E1 | bar E2
     // Partial steps, dual steps and rejected (dependent) constraints leave this path (by then the pending update has been applied:
     // phase B comes first).  A drop is two barriers: D1 move x and u, wave 1 turns row p of Ri into the L rotations' coefficients --
     // rotation l of the pair (p + l, p + l + 1) follows from the running sums S_l = sum_{i<=l} rho_i^2 alone, so a row's new
@@ -826,20 +835,23 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     if (status == -2 && nin2 > 0) {
         const int MM = n - neq;                       // the most inequality constraints that can be active (<= 64, host check)
         const int ne = (n + 1) & ~1;                  // first pad pair of a row of J, of V and of the pending v (ldj >= ne + 2; zero for good)
-        double* const Ri = c.R;                       // inverse of R's inequality block, ROW-packed: (i, j), i <= j, at rio(i) + j - i (R is dead)
+        double* const Ri = c.R + 2;                   // inverse of R's inequality block, ROW-packed: (i, j), i <= j, at rio(i) + j - i (R is dead);
+                                                      // one zero in front of it: what a row's rotation reads left of its diagonal
         const int ri_size = lp::rio(MM, MM);
-        double* const prm = c.R + ((ri_size + 64 + 1) & ~1);  // drop: 4 doubles per rotation (a_l, b_l, rho_{l+1}, -), behind Ri's over-read pad
+        double* const prm = c.R + ((2 + ri_size + 64 + 1) & ~1);  // drop: 4 doubles per rotation (a_l, b_l, rho_{l+1}, -), behind Ri's over-read pad
         double* const fct = prm + 4 * (MM + 2);       // friction rows: 12 coefficients per one-sided row, sign folded in
         double* const Wp = lds + D.o_vec + cp::PW;    // pending update: J(:, pc:) <- J(:, pc:) - w v(pc:)'; w = 0 when there is none
         double* const dI = lds + D.o_vec + cp::DI;    // d at the active inequality positions, zero from mi on (read up to 2 x 64)
         double* const LS = lds + D.o_vec + cp::RED;   // the loop's slots (lp::)
         int* const LSi = reinterpret_cast<int*>(LS);
+        double* const EL = lds + D.o_vec + cp::EL;    // election slots (lp::E*; initialised ahead of the equality phase)
+        unsigned* const ELu = reinterpret_cast<unsigned*>(EL);
         double* const dbuf0 = lds + D.o_vec + cp::D;      // V of the current pick in one, the pending v in the other
         double* const dbuf1 = lds + D.o_vec + cp::RDINV;  // (1/R(j,j) of the equality phase is dead by now)
-        c.red = lds + D.o_vec + cp::LRED;             // block_sum / block_argmin of the rare paths (the set-up's slot is part of LS now)
+        c.red = lds + D.o_vec + cp::LRED;             // block_sum of the rare paths (the set-up's slot is part of LS now)
         c.rslot = 0;
         // ---- loop-time arrays start from zero (every region here was last read behind the equality phase's final barrier)
-        for (int e = tid; e < ri_size + 64; e += kThreads) Ri[e] = 0.0;
+        for (int e = tid; e < ri_size + 64 + 2; e += kThreads) c.R[e] = 0.0;
         if (tid < 128) dI[tid] = 0.0;
         if (tid < 80) {
             Wp[tid] = 0.0;
@@ -879,7 +891,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         const int arr = tid >> 2, aq = tid & 3;
         const bool act_owner = act_ineq && arr < na && aq < 2;
         const int arow = act_owner ? D.act_off + (aq ? na : 0) + arr : -1;
-        const int ameta = act_owner ? row_meta_pack(INEQ_ACTUATION, aq ? 1 : 0, arr, 0, 0) : 0;
+        // the word a row is elected with: row << 23 | descriptor (23 bits: row_meta_pack) -- the smallest word is the smallest row
+        const unsigned okey = (own.meta >= 0) ? ((unsigned)tid << 23) | (unsigned)own.meta : 0xffffffffu;
+        const unsigned akey = act_owner ? ((unsigned)arow << 23) | (unsigned)row_meta_pack(INEQ_ACTUATION, aq ? 1 : 0, arr, 0, 0) : 0xffffffffu;
         const double aci0 = act_owner ? (aq ? c.tu[arr] : -c.tl[arr]) : 0.0;
         const double asg = aq ? -1.0 : 1.0;
         double s_own = 0.0, s_act = 0.0; // s of the owned rows at the iterate of the last evaluation
@@ -894,12 +908,38 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             if (act_owner) warm_act = (am[arow >> 5] >> (arow & 31)) & 1u;
         }
 
-        // s = CI (xp + t zp) + ci0 for the rows this thread owns (kept in s_own / s_act); returns its most violated eligible row
-        // (row ipx counts as active: its flag is being set while this runs).  tau' of that iterate lands in tact[] and tau_q.
+        // a thread's candidate for the next pick: the more violated of its (at most two) eligible rows, as (s, word); {0, ~0}: none
+        struct Cand {
+            double v, wv;      // most violated eligible row; the same among the warm start's hinted rows
+            unsigned key, wkey;
+        };
+        auto cand_of = [&](bool oka, bool oko) __attribute__((always_inline)) {
+            Cand k{0.0, 0.0, 0xffffffffu, 0xffffffffu};
+            if (oka) {
+                k.v = s_act;
+                k.key = akey;
+                if (warm_act) {
+                    k.wv = s_act;
+                    k.wkey = akey;
+                }
+            }
+            if (oko) {
+                if (s_own < k.v || (s_own == k.v && okey < k.key)) {
+                    k.v = s_own;
+                    k.key = okey;
+                }
+                if (warm_own && (s_own < k.wv || (s_own == k.wv && okey < k.wkey))) {
+                    k.wv = s_own;
+                    k.wkey = okey;
+                }
+            }
+            return k;
+        };
+        // s = CI (xp + t zp) + ci0 for the rows this thread owns (kept in s_own / s_act); returns its candidate (row ipx counts as active: its
+        // flag is being set while this runs).  tau' of that iterate lands in tact[] and tau_q.
         double tau_q = 0.0; // tau' of the quad's actuation row at the iterate of the last evaluation (all four lanes)
-        auto eval_rows = [&](const double* xp, const double* zp, double t, int ipx, ValIdx& best, ValIdx& bestw) __attribute__((always_inline)) {
-            best = ValIdx{0.0, 0x7fffffff};
-            bestw = ValIdx{0.0, 0x7fffffff};
+        auto eval_rows = [&](const double* xp, const double* zp, double t, int ipx) __attribute__((always_inline)) {
+            bool oka = false, oko = false;
             if (act_ineq) {
                 const double acc = act_dot(c, ar, xp, zp, t);
                 tau_q = acc;
@@ -907,10 +947,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 if (act_owner) {
                     const double v = fma(asg, acc, aci0);
                     s_act = v;
-                    if (v < 0.0 && !act[arow] && arow != ipx) {
-                        best = ValIdx{v, arow};
-                        if (warm_act) bestw = best;
-                    }
+                    oka = v < 0.0 && !act[arow] && arow != ipx;
                 }
             }
             const int mt = own.meta;
@@ -932,28 +969,22 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
                 v += own.ci0;
                 s_own = v;
-                if (v < 0.0 && !act[tid] && tid != ipx) {
-                    best = vi_min(best, ValIdx{v, tid});
-                    if (warm_own) bestw = vi_min(bestw, ValIdx{v, tid});
-                }
+                oko = v < 0.0 && !act[tid] && tid != ipx;
             }
+            return cand_of(oka, oko);
         };
         // the same for the iterate x + t z when s_own / s_act / tau_q hold the values AT x (the common, fused step): only the
         // increments t (CI z) are formed -- half the LDS reads and a third of the arithmetic of the evaluation from scratch.
         // tau' of the final iterate is evaluated from scratch in the decode, so the output never carries the accumulated sum.
-        auto eval_rows_inc = [&](const double* zp, double t, int ipx, ValIdx& best, ValIdx& bestw) __attribute__((always_inline)) {
-            best = ValIdx{0.0, 0x7fffffff};
-            bestw = ValIdx{0.0, 0x7fffffff};
+        auto eval_rows_inc = [&](const double* zp, double t, int ipx) __attribute__((always_inline)) {
+            bool oka = false, oko = false;
             if (act_ineq) {
                 const double acc = fma(t, act_dot1(c, ar, zp), tau_q);
                 tau_q = acc;
                 if (act_owner) {
                     const double v = fma(asg, acc, aci0);
                     s_act = v;
-                    if (v < 0.0 && !act[arow] && arow != ipx) {
-                        best = ValIdx{v, arow};
-                        if (warm_act) bestw = best;
-                    }
+                    oka = v < 0.0 && !act[arow] && arow != ipx;
                 }
             }
             const int mt = own.meta;
@@ -977,149 +1008,114 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
                 const double v = fma(t, dz, s_own);
                 s_own = v;
-                if (v < 0.0 && !act[tid] && tid != ipx) {
-                    best = vi_min(best, ValIdx{v, tid});
-                    if (warm_own) bestw = vi_min(bestw, ValIdx{v, tid});
-                }
+                oko = v < 0.0 && !act[tid] && tid != ipx;
             }
+            return cand_of(oka, oko);
         };
-        // a wave's candidate goes out WITH its row descriptor: the lane that owns the row writes it, so the pick costs no table look-up
-        // behind the barrier.  psi = sum min(s, 0) decides the termination only when it is small: |psi| >= |s(most violated row)|, so
-        // the sum is formed (one more reduction) only when that row alone does not already exceed the tolerance
-        auto publish_best = [&](ValIdx best, ValIdx bestw) __attribute__((always_inline)) {
-            best = wave_argmin(best);
-            if (use_warm) bestw = wave_argmin(bestw);
-            if (c.lane == 0) {
-                LS[lp::PKV + c.wave] = best.v;
-                LSi[lp::PKI + c.wave] = best.i;
+        // The election (two barriers): on return every thread holds the most violated candidate's (s, word) -- word ~0: nobody stood --
+        // and the same for the hinted rows.  The slots alternate; the one not in use is re-armed behind the second barrier (its last
+        // readers passed the first one, its next atomics lie behind at least one more barrier).
+        int par = 0;
+        double el_v = 0.0, el_wv = 0.0;
+        unsigned el_key = 0xffffffffu, el_wkey = 0xffffffffu;
+        auto elect = [&](const Cand& k) __attribute__((always_inline)) {
+            if (k.v < 0.0) lds_min_f64(EL + lp::EMIN + par, k.v);
+            if (use_warm && k.wv < 0.0) lds_min_f64(EL + lp::EWMIN + par, k.wv);
+            bsync(); // E1
+            STAMP(29)
+            const double m = EL[lp::EMIN + par];
+            if (k.v == m && k.v < 0.0) lds_min_u32(ELu + lp::EKEY + par, k.key);
+            double mw = 0.0;
+            if (use_warm) {
+                mw = EL[lp::EWMIN + par];
+                if (k.wv == mw && k.wv < 0.0) lds_min_u32(ELu + lp::EWKEY + par, k.wkey);
+            }
+            bsync(); // E2
+            STAMP(30)
+            el_v = m;
+            el_key = ELu[lp::EKEY + par];
+            if (use_warm) {
+                el_wv = mw;
+                el_wkey = ELu[lp::EWKEY + par];
+            }
+            par ^= 1;
+            if (tid == kThreads - 1) {
+                EL[lp::EMIN + par] = lp::kNone;
+                ELu[lp::EKEY + par] = 0xffffffffu;
                 if (use_warm) {
-                    LS[lp::PWV + c.wave] = bestw.v;
-                    LSi[lp::PWI + c.wave] = bestw.i;
+                    EL[lp::EWMIN + par] = lp::kNone;
+                    ELu[lp::EWKEY + par] = 0xffffffffu;
                 }
-            }
-            if (own.meta >= 0) {
-                if (tid == best.i) LSi[lp::PKM + c.wave] = own.meta;
-                if (use_warm && tid == bestw.i) LSi[lp::PWM + c.wave] = own.meta;
-            }
-            if (act_owner) {
-                if (arow == best.i) LSi[lp::PKM + c.wave] = ameta;
-                if (use_warm && arow == bestw.i) LSi[lp::PWM + c.wave] = ameta;
             }
         };
         if (neq == 0) bsync(); // (with equalities: the barrier of the equality phase's last reduction)
         const double psi_tol = (double)nin2 * eps * c1 * c2 * 100.0;
-        bool redo_l2 = false;
-        bool s_ready = false;    // the slot holds the most violated row of the current iterate
+        bool redo = false;       // the election in hand follows a rejected constraint (eiquadprog's l2 again): same outer iteration
         bool excl_dirty = false; // some excl[] entry is 0
         bool slow = false;       // this pick has left the common path: x is updated in place, its snapshot is in c.xold
         double sip = 0.0;        // s(ip) of the constraint being added
         int pc = neq;            // first column of the pending update (w = 0: none)
         double* Vp = dbuf0;      // the pending v (zero below pc, v0 at pc)
         double* Vn = dbuf1;      // V of the pick in hand
-        while (status == -2) {
-            ValIdx best;
-            int mt = 0;
-            if (!redo_l2) {
-                // l1
-                if (!s_ready) {
-                    if (excl_dirty) {
-                        if (tid < nin2) excl[tid] = 1;
-                        excl_dirty = false;
-                    }
-                    for (int i = tid; i < c.iq; i += kThreads) {
-                        c.uold[i] = c.u[i];
-                        c.Aold[i] = c.A[i];
-                    }
-                    ValIdx bw;
-#ifdef WBCQP_STAMP_FIRST_PICK // (tools/phase_profile.py --lib: the way to the first pick split four ways, under the names of phases 22, 5, 19 and 6)
-                    STAMP(5)
-                    eval_rows(c.x, c.z, 0.0, -1, best, bw);
-                    STAMP(19)
-                    publish_best(best, bw);
-                    STAMP(6)
+        // ---- l1 of the first iteration: s from scratch
+        for (int i = tid; i < c.iq; i += kThreads) {
+            c.uold[i] = c.u[i];
+            c.Aold[i] = c.A[i];
+        }
+        {
+#ifdef WBCQP_STAMP_FIRST_PICK // (tools/phase_profile.py --lib: the way to the first pick split, under the names of phases 5, 19 and 6)
+            STAMP(5)
+            const Cand k0 = eval_rows(c.x, c.z, 0.0, -1);
+            STAMP(19)
+            elect(k0);
+            STAMP(6)
 #else
-                    eval_rows(c.x, c.z, 0.0, -1, best, bw);
-                    publish_best(best, bw);
+            elect(eval_rows(c.x, c.z, 0.0, -1));
 #endif
-                    bsync(); // B1
-                }
+        }
+        while (true) {
+            if (!redo) {
+                // l1: a new outer iteration
                 slow = false;
                 ++iter;
                 if (iter >= D.max_iter) {
                     status = HQP_MAX_ITER;
                     break;
                 }
-                ValIdx bw_pick{0.0, 0x7fffffff};
-                int mt_w = 0;
-                STAMP(29)
-                {
-                    const double2v v01 = ld2(LS + lp::PKV), v23 = ld2(LS + lp::PKV + 2);
-                    const int4v bi = *reinterpret_cast<const int4v*>(__builtin_assume_aligned(LSi + lp::PKI, 16));
-                    const int4v bm = *reinterpret_cast<const int4v*>(__builtin_assume_aligned(LSi + lp::PKM, 16));
-                    best = ValIdx{v01.x, bi.x};
-                    mt = bm.x;
-                    lp::take_min(best, mt, v01.y, bi.y, bm.y);
-                    lp::take_min(best, mt, v23.x, bi.z, bm.z);
-                    lp::take_min(best, mt, v23.y, bi.w, bm.w);
-                    if (use_warm) {
-                        const double2v w01 = ld2(LS + lp::PWV), w23 = ld2(LS + lp::PWV + 2);
-                        const int4v wi = *reinterpret_cast<const int4v*>(__builtin_assume_aligned(LSi + lp::PWI, 16));
-                        const int4v wm = *reinterpret_cast<const int4v*>(__builtin_assume_aligned(LSi + lp::PWM, 16));
-                        ValIdx bestw{w01.x, wi.x};
-                        int mtw = wm.x;
-                        lp::take_min(bestw, mtw, w01.y, wi.y, wm.y);
-                        lp::take_min(bestw, mtw, w23.x, wi.z, wm.z);
-                        lp::take_min(bestw, mtw, w23.y, wi.w, wm.w);
-                        bw_pick = bestw;
-                        mt_w = mtw;
-                    }
+                if (excl_dirty) { // (its readers -- a rejection's second election -- lie behind the rejection's barriers)
+                    if (tid < nin2) excl[tid] = 1;
+                    excl_dirty = false;
                 }
-                STAMP(30)
-                s_ready = false;
-                if (!(best.v < 0.0)) { // nothing violated (psi = 0)
+                if (!(el_v < 0.0)) { // nothing violated (psi = 0)
                     status = HQP_OPTIMAL;
                     break;
                 }
-                if (-best.v <= psi_tol) { // rare: the sum itself decides
+                // psi = sum min(s, 0) decides the termination only when it is small: |psi| >= |s(most violated row)|, so the sum is
+                // formed (one more reduction) only when that row alone does not already exceed the tolerance
+                if (-el_v <= psi_tol) { // rare: the sum itself decides
                     const double psi = block_sum(c, fmin(0.0, s_own) + fmin(0.0, s_act));
                     if (fabs(psi) <= psi_tol) {
                         status = HQP_OPTIMAL;
                         break;
                     }
                 }
-                if (use_warm && bw_pick.v < 0.0) { // a hinted row is violated: it goes first
-                    best = bw_pick;
-                    mt = mt_w;
-                }
-                STAMP(9)
             }
             else {
-                // l2 again after a rejected constraint: the owners still hold s of the (restored) iterate, the rejected row is excluded
-                best = ValIdx{0.0, 0x7fffffff};
-                ValIdx bw{0.0, 0x7fffffff};
-                if (act_owner && s_act < 0.0 && !act[arow] && excl[arow]) {
-                    best = ValIdx{s_act, arow};
-                    if (warm_act) bw = best;
-                }
-                if (own.meta >= 0 && s_own < 0.0 && !act[tid] && excl[tid]) {
-                    best = vi_min(best, ValIdx{s_own, tid});
-                    if (warm_own) bw = vi_min(bw, ValIdx{s_own, tid});
-                }
-                best = block_argmin(c, best);
-                if (use_warm) {
-                    bw = block_argmin(c, bw);
-                    if (bw.v < 0.0) best = bw;
-                }
-                redo_l2 = false;
-                if (best.v >= 0.0) {
+                redo = false;
+                if (!(el_v < 0.0)) {
                     status = HQP_OPTIMAL;
                     break;
                 }
-                mt = S.rowmeta[best.i]; // (rare path: the descriptor from the structure's table)
             }
-            const int ip = best.i;
-            sip = best.v;
-            // the row n of constraint ip: kind, first column k0 of its support, sign
+            unsigned key = el_key;
+            sip = el_v;
+            if (use_warm && el_wv < 0.0) { // a hinted row is violated: it goes first
+                key = el_wkey;
+                sip = el_wv;
+            }
+            STAMP(9)
+            // the row n of constraint ip: kind, first column of its support, sign
+            const int ip = (int)(key >> 23), mt = (int)(key & 0x7fffffu);
             const int kind = mt & 3, rr = (mt >> 3) & 255, ct = (mt >> 11) & 15, col = (mt >> 15) & 255;
             const bool negrow = (mt >> 2) & 1;
             const double sg = negrow ? -1.0 : 1.0;
@@ -1215,8 +1211,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     const int idx = tid >> 1, hf = tid & 1; // lane pair per row
                     const int cs = pc & ~1;
                     const int P = (ne - cs) >> 1;           // 16-byte pairs of a row from cs on
-                    const int T = max(3, ((P + 1) >> 1) | 1); // per lane, odd: the two halves of a row then sit in different bank groups
-                    double zz = 0.0;
+                    const int T = max(3, (P + 1) >> 1);     // per lane
+                    bool zbig = false;
                     if (idx < n) {
                         double* Jk = c.J + idx * ldj;
                         const double wk = Wp[idx];
@@ -1254,15 +1250,19 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         if (hf == 0) {
                             c.z[idx] = zv;
                             c.part[idx] = stash; // column iq of J, for the w of phase C
-                            zz = zv * zv;
                         }
+                        zbig = zv * zv > eps;
                     }
                     STAMP(18)
-                    zz = wave_sum(zz);
-                    if (c.lane == 0) LS[lp::BZ + c.wave] = zz;
+                    const unsigned long long any = __ballot(zbig);
+                    if (c.lane == 0) LSi[lp::BZF + c.wave] = (any != 0ull) ? 1 : 0;
                 }
                 else {
                     const int i = c.lane;
+                    if (i == 0) { // the step length's election slots (their last readers are two barriers back)
+                        EL[lp::ET1] = inf;
+                        ELu[lp::ET1POS] = 0x7fffffffu;
+                    }
                     const double* Rr = Ri + lp::rio(min(i, MM - 1), MM);
                     const double* dq = dI + i;
                     double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
@@ -1280,11 +1280,14 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     const double vq = Vn[neq + min(i, MM - 1)];
                     const double diq = Vn[iq0 < n ? iq0 : n - 1];
                     if (i < mi) c.r[neq + i] = rl;
-                    // step 2b's partial step length t1 (dual feasibility) from the lane's own r
-                    ValIdx bt{inf, 0x7fffffff};
-                    if (rl > 0.0) bt = ValIdx{ratio_pos(c.u[neq + i], rl), neq + i};
-                    bt = wave_argmin(bt);
+                    // step 2b's partial step length t1 (dual feasibility): elected among the lanes with r > 0, first position on ties
+                    double ratio = inf;
+                    if (rl > 0.0) {
+                        ratio = ratio_pos(c.u[neq + i], rl);
+                        lds_min_f64(EL + lp::ET1, ratio);
+                    }
                     const double dn2 = wave_sum((i < MM) ? vq * vq : 0.0); // |d2|^2 = z'n (V is zero below iq)
+                    if (rl > 0.0 && ratio == EL[lp::ET1]) lds_min_u32(ELu + lp::ET1POS, (unsigned)(neq + i));
                     // the reflector of a full step, H = I - tau v v' with v = d[iq:] - alpha e_0, and the step length t2
                     double alpha = (iq0 < n) ? diq : 0.0, v0 = 0.0, tau = 0.0;
                     if (iq0 + 1 < n && dn2 > 0.0) {
@@ -1295,76 +1298,54 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         tau = fast_rcp(fma(nx, fabs(diq), dn2));
                     }
                     if (c.lane == 0) {
-                        LS[lp::BT1] = bt.v;
-                        LSi[2 * lp::BLPOS] = bt.i;
                         LS[lp::BDN2] = dn2;
                         LS[lp::BALPHA] = alpha;
                         LS[lp::BV0] = v0;
                         LS[lp::BTAU] = tau;
+                        LS[lp::BT2C] = ratio_pos(-sip, dn2);
                     }
                 }
                 STAMP(25)
                 bsync(); // B
             }
             STAMP(12)
-            double zz, znp, dn2, t1, alpha, v0, tau;
+            double znp, dn2, t1, alpha, v0, tau, t2;
             int lpos;
+            bool zok;
             {
-                const double2v z01 = ld2(LS + lp::BZ);
-                const double2v z2t = ld2(LS + lp::BZ + 2);  // zz of wave 2, t1
-                const double2v da = ld2(LS + lp::BDN2);     // |d2|^2, alpha
-                const double2v vt = ld2(LS + lp::BV0);      // v0, tau
-                lpos = LSi[2 * lp::BLPOS];
-                zz = (z01.x + z01.y) + z2t.x;
-                t1 = z2t.y;
+                const double2 da = *reinterpret_cast<const double2*>(LS + lp::BDN2); // |d2|^2, alpha
+                const double2 vt = *reinterpret_cast<const double2*>(LS + lp::BV0);  // v0, tau
+                const double t2c = LS[lp::BT2C];
+                const int zf = LSi[lp::BZF] | LSi[lp::BZF + 1] | LSi[lp::BZF + 2];
+                t1 = EL[lp::ET1];
+                lpos = (int)ELu[lp::ET1POS];
                 dn2 = da.x;
                 alpha = da.y;
                 v0 = vt.x;
                 tau = vt.y;
                 znp = dn2; // z'n = (J2 d2)'n = d2'(J2'n) = |d2|^2: the second reduction eiquadprog spends on it is the first one again
+                zok = zf != 0;
+#ifdef WBCQP_DBG_ZSUM
+                zok = false;
+#endif
+                if (!zok) { // no row's z_k^2 alone exceeds eps: the sum decides (degenerate picks only)
+                    const double zk = (tid < n) ? c.z[tid] : 0.0;
+                    zok = fabs(block_sum(c, zk * zk)) > eps;
+                }
+                t2 = zok ? t2c : inf;
             }
             double uiq = 0.0; // u[iq] of the candidate: every thread carries it, LDS sees it when the constraint is added
             int drops = 0;
             while (true) {
                 const int iq = c.iq;
-                if (++drops > n + 2) { // a pick drops at most its active set: anything beyond is a NaN's doing -- give up on the QP instead of spinning
-                    status = HQP_ERROR;
-                    break;
-                }
-                // ---- step lengths
-                const double t2 = (fabs(zz) > eps) ? ratio_pos(-sip, znp) : inf;
-                const double t = fmin(t1, t2);
-                if (t >= inf) {
-                    status = HQP_INFEASIBLE; // eiquadprog UNBOUNDED (dual) -> tsid INFEASIBLE
-                    break;
-                }
-                if (t2 < inf) f_value += t * znp * (0.5 * t + uiq);
-                if (t2 < inf && t == t2) {
+                // ---- the common case in one branch: a full step (t2 <= t1, finite) with a constraint that is not (numerically) dependent
+                const bool full = (t2 <= t1) & (t2 < inf);
+                if (full & (fabs(alpha) > eps * c.R_norm)) {
                     // (iii) full step: add ip to the active set with one reflector H = I - tau v v' (v = d[iq:] - alpha e_0)
-                    const bool reflect = (iq + 1 < n && dn2 > 0.0);
+                    const double t = t2;
+                    const bool reflect = (iq + 1 < n) & (dn2 > 0.0);
+                    f_value += t * znp * (0.5 * t + uiq);
                     STAMP(20)
-                    if (!(fabs(alpha) > eps * c.R_norm)) {
-                        // numerically dependent on the active set: eiquadprog adds it, takes it out again (the last position:
-                        // no rotation), returns to the saved iterate and picks another.  Nothing has been written yet, so the
-                        // reflector is not applied at all (it would only turn the basis of the null space).
-                        if (tid == 0) excl[ip] = 0;
-                        excl_dirty = true;
-                        if (tid < nin2) act[tid] = 0;
-                        if (tid < 80) Wp[tid] = 0.0; // no pending update either
-                        bsync();
-                        for (int i = tid; i < iq; i += kThreads) {
-                            const int av = c.Aold[i];
-                            c.A[i] = av;
-                            if (av >= 0) act[av] = 1;
-                            c.u[i] = c.uold[i];
-                        }
-                        if (slow && tid < n) c.x[tid] = c.xold[tid];
-                        pc = iq;
-                        bsync();
-                        redo_l2 = true;
-                        break; // -> l2 again
-                    }
-                    STAMP(21)
                     // ---- C: the step, the next pending update and the next iterate's s in one phase
                     const double ralpha = fast_rcp(alpha);
                     const int mi = iq - neq;
@@ -1397,11 +1378,10 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         c.Aold[tid] = c.A[tid];
                         if (tid < neq) c.uold[tid] = c.u[tid];
                     }
-                    ValIdx nb, nbw;
-                    if (slow) eval_rows(c.x, c.z, t, ip, nb, nbw); // drops moved x since the last evaluation: from scratch
-                    else eval_rows_inc(c.z, t, ip, nb, nbw);
+                    Cand nk;
+                    if (slow) nk = eval_rows(c.x, c.z, t, ip); // drops moved x since the last evaluation: from scratch
+                    else nk = eval_rows_inc(c.z, t, ip);
                     STAMP(23)
-                    publish_best(nb, nbw);
                     c.iq = iq + 1;
                     c.R_norm = fmax(c.R_norm, fabs(alpha));
                     pc = iq;
@@ -1411,13 +1391,45 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         Vn = vt;
                     }
                     STAMP(26)
-                    bsync(); // C = B1 of the next iteration
+                    elect(nk); // its first barrier ends phase C
                     double* xt = c.x;
                     c.x = c.xold;
                     c.xold = xt;
-                    s_ready = true;
                     STAMP(14)
                     break; // -> l1
+                }
+                const double t = fmin(t1, t2);
+                if (++drops > n + 2) { // a pick drops at most its active set: anything beyond is a NaN's doing -- give up on the QP instead of spinning
+                    status = HQP_ERROR;
+                    break;
+                }
+                if (t >= inf) {
+                    status = HQP_INFEASIBLE; // eiquadprog UNBOUNDED (dual) -> tsid INFEASIBLE
+                    break;
+                }
+                if (t2 < inf) f_value += t * znp * (0.5 * t + uiq);
+                if (full) {
+                    // the constraint is numerically dependent on the active set: eiquadprog adds it, takes it out again (the last position:
+                    // no rotation), returns to the saved iterate and picks another.  Nothing has been written yet, so the
+                    // reflector is not applied at all (it would only turn the basis of the null space).
+                    if (tid == 0) excl[ip] = 0;
+                    excl_dirty = true;
+                    if (tid < nin2) act[tid] = 0;
+                    if (tid < 80) Wp[tid] = 0.0; // no pending update either
+                    bsync();
+                    for (int i = tid; i < iq; i += kThreads) {
+                        const int av = c.Aold[i];
+                        c.A[i] = av;
+                        if (av >= 0) act[av] = 1;
+                        c.u[i] = c.uold[i];
+                    }
+                    if (slow && tid < n) c.x[tid] = c.xold[tid];
+                    pc = iq;
+                    bsync();
+                    // l2 again: the owners still hold s of the (restored) iterate; the rejected row is excluded
+                    elect(cand_of(act_owner && s_act < 0.0 && !act[arow] && excl[arow], own.meta >= 0 && s_own < 0.0 && !act[tid] && excl[tid]));
+                    redo = true;
+                    break;
                 }
                 // ---- (ii) dual step / (iii) partial step: move, then drop l.  Two barriers; d, z, r, z'n, |d2|^2, s(ip) follow
                 //      the drop by rank-one updates (delta = the entry of d that leaves the active block):
@@ -1483,36 +1495,49 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         double* Jk = c.J + kr * ldj + qq;
                         double Pk = rho0 * Jk[0];
                         lp::rotate_row_ps(prm, L, Pk, [&](int jj) { return Jk[jj]; }, [&](int jj, double v) { if (live) Jk[jj] = v; });
-                        double zq = 0.0;
+                        bool zbig = false;
                         if (live) {
                             const double tj = cl * Pk;
                             Jk[L] = tj;
                             const double zn = fma(delta, tj, c.z[kr]);
                             c.z[kr] = zn;
                             c.part[kr] = tj; // column iq' of J, for the w of phase C
-                            zq = zn * zn;
+                            zbig = zn * zn > eps;
                         }
-                        zq = wave_sum(zq);
-                        if (c.lane == 0) LS[lp::BZ + c.wave] = zq;
+                        const unsigned long long any = __ballot(zbig);
+                        if (c.lane == 0) LSi[lp::BZF + c.wave] = (any != 0ull) ? 1 : 0;
                     }
                     else if (c.wave == 3) {
-                        // rows of Ri, r, u, A, t1.  Row i <= p has all its elements from column p on; row i > p begins at column i
-                        // (zeros before), moves up one row, and its first new element (column i - 1) is the fill-in of rotation i - p - 1.
+                        // rows of Ri, r, u, A, t1.  Row i <= p has all its elements from column p on; row i > p begins at column i (left of it
+                        // the clamped address reads a zero: the spare element that ends the row before), moves up one row, and its first new
+                        // element (column i - 1) is the fill-in of rotation i - p - 1.  What a row's rotation produces left of its new diagonal is an
+                        // exact zero (no element of the row has entered the running sum yet): those stores land on the same spare element.
                         const int i = c.lane;
                         const bool row = i < mi;
                         const bool has = row && i != p;
                         const int i2 = i - ((i > p) ? 1 : 0);
-                        const int ic = min(i, MM - 1);
-                        const double* Rsrc = Ri + lp::rio(ic, MM) - ic + p;        // element (i, p + jj) at Rsrc[jj], valid for p + jj >= i
-                        double* Rdst = Ri + lp::rio(min(i2, MM - 1), MM) - i2 + p;  // element (i2, p + jj) at Rdst[jj], stored for p + jj >= i2
-                        const int first = i - p;                                    // first rotation-column index jj that exists in row i (<= 0: all)
-                        const double x0 = (row && first <= 0) ? Rsrc[0] : 0.0;
-                        double Pk = rho0 * x0;
+                        const int ic = min(i, MM - 1), i2c = min(i2, MM - 1);
+                        const double* Rrow = Ri + lp::rio(ic, MM);              // (i, i): the row's first element; Rrow[-1] reads zero
+                        double* Rnew = Ri + lp::rio(i2c, MM);                   // (i2, i2)
+                        const int sh = p - ic, sh2 = p - i2c;                   // element (i, p + jj) at Rrow[sh + jj]
+                        if (i == 0) {
+                            EL[lp::ET1] = inf;
+                            ELu[lp::ET1POS] = 0x7fffffffu;
+                        }
+#ifdef WBCQP_DBG_MASKED_ROT
+                        const int first = i - p;
+                        double Pk = rho0 * ((row && first <= 0) ? Rrow[max(sh, -1)] : 0.0);
                         lp::rotate_row_ps(prm, L, Pk,
-                                          [&](int jj) { const double v = Rsrc[jj]; return (row && jj >= first) ? v : 0.0; },
-                                          [&](int jj, double v) { if (has && jj >= first - 1) Rdst[jj] = v; });
-                        const double tj = cl * Pk; // Z(i, last): leaves the matrix
-                        if (has) Rdst[L] = 0.0;    // the last column is gone (row i2 keeps its zeros from the new mi on)
+                                          [&](int jj) { const double v = Rrow[max(sh + jj, -1)]; return (row && jj >= first) ? v : 0.0; },
+                                          [&](int jj, double v) { if (has && jj >= first - 1) Rnew[sh2 + jj] = v; });
+#else
+                        double Pk = rho0 * Rrow[max(sh, -1)];
+                        lp::rotate_row_ps(prm, L, Pk,
+                                          [&](int jj) { return Rrow[max(sh + jj, -1)]; },
+                                          [&](int jj, double v) { if (has) Rnew[max(sh2 + jj, -1)] = v; });
+#endif
+                        const double tj = row ? cl * Pk : 0.0; // Z(i, last): leaves the matrix
+                        if (has) Rnew[sh2 + L] = 0.0;          // the last column is gone (row i2 keeps its zeros from the new mi on)
                         if (i == mi - 1) Ri[lp::rio(i, MM)] = 0.0; // ... and so is row mi - 1 (it moved up, or it was row p): its storage reads zero again
                         const double rn = row ? fma(-delta, tj, c.r[neq + min(i, mi - 1)]) : 0.0;
                         const double uu = c.u[neq + min(i, mi - 1)];
@@ -1523,25 +1548,33 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                             c.A[neq + i2] = aa;
                         }
                         if (i == mi) c.A[iq - 1] = ip; // the candidate moves with its position
-                        ValIdx bt{inf, 0x7fffffff};
-                        if (has && rn > 0.0) bt = ValIdx{ratio_pos(uu, rn), neq + i2};
-                        bt = wave_argmin(bt);
-                        if (c.lane == 0) {
-                            LS[lp::BT1] = bt.v;
-                            LSi[2 * lp::BLPOS] = bt.i;
+                        double ratio = inf;
+                        if (has && rn > 0.0) {
+                            ratio = ratio_pos(uu, rn);
+                            lds_min_f64(EL + lp::ET1, ratio);
                         }
+                        if (has && rn > 0.0 && ratio == EL[lp::ET1]) lds_min_u32(ELu + lp::ET1POS, (unsigned)(neq + i2));
                     }
                 }
                 STAMP(28)
                 bsync();
                 STAMP(15)
                 {
-                    zz = LS[lp::BZ] + LS[lp::BZ + 1];
+                    const int zf = LSi[lp::BZF] | LSi[lp::BZF + 1];
+                    t1 = EL[lp::ET1];
+                    lpos = (int)ELu[lp::ET1POS];
                     znp = fma(delta, delta, znp);
                     dn2 = fma(delta, delta, dn2);
-                    t1 = LS[lp::BT1];
-                    lpos = LSi[2 * lp::BLPOS];
                     c.iq = iq - 1;
+                    zok = zf != 0;
+#ifdef WBCQP_DBG_ZSUM
+                    zok = false;
+#endif
+                    if (!zok) {
+                        const double zk = (tid < n) ? c.z[tid] : 0.0;
+                        zok = fabs(block_sum(c, zk * zk)) > eps;
+                    }
+                    t2 = zok ? ratio_pos(-sip, znp) : inf;
                     // the reflector of the shorter active set: d[iq'] = delta heads the null-space part now
                     alpha = delta;
                     v0 = 0.0;
@@ -1555,6 +1588,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     }
                 }
             }
+            if (status != -2) break;
         }
     }
     else if (status == -2) {

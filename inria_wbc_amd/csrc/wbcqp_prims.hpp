@@ -138,8 +138,16 @@ __device__ __forceinline__ double gi_distance(double a, double b)
 #define WBCQP_STAMP_TID 0
 #endif
 constexpr int kStamps = 32;
-#define STAMP_DECL c.st_prev_ = clock64(); for (int i_ = 0; i_ < kStamps; ++i_) c.st_acc_[i_] = 0;
-#define STAMP(i) { long long now_ = clock64(); c.st_acc_[i] += now_ - c.st_prev_; c.st_prev_ = now_; }
+#define STAMP_DECL c.st_prev_ = stamp_now(); for (int i_ = 0; i_ < kStamps; ++i_) c.st_acc_[i_] = 0;
+// (the counter is read by an asm volatile with a memory clobber: the compiler may not move it across LDS operations, barriers or the loop's other asm
+//  statements -- clock64() was seen hoisted above the code it was meant to time)
+__device__ __forceinline__ long long stamp_now()
+{
+    long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#define STAMP(i) { long long now_ = stamp_now(); c.st_acc_[i] += now_ - c.st_prev_; c.st_prev_ = now_; }
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -247,6 +255,18 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 __device__ __forceinline__ int opaque_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ double2v ld2(const double* p) { return *reinterpret_cast<const double2v*>(__builtin_assume_aligned(p, 16)); }
 __device__ __forceinline__ int wave_min_int(int v) { return -wave_max_int(-v); }
+
+// LDS atomics as cross-lane reductions where only a few lanes take part (tools/ubench/lds_atomics.hip: about 50 cycles + 10 per participating lane,
+// against 500-700 for a wave-wide argmin by DPP).  No return value; the issuing wave sees the result with its next LDS read (one wave's LDS
+// operations execute in order), other waves behind a barrier.  (The low half of a generic pointer into LDS is the LDS address.)
+__device__ __forceinline__ void lds_min_f64(double* p, double v)
+{
+    asm volatile("ds_min_f64 %0, %1" : : "v"((unsigned)(unsigned long long)p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_min_u32(unsigned* p, unsigned v)
+{
+    asm volatile("ds_min_u32 %0, %1" : : "v"((unsigned)(unsigned long long)p), "v"(v) : "memory");
+}
 
 // acc[2][4] += sum_k a_i(k) * b(k, 0..3) over the wave-uniform range [k0, k1): element k of operand i is at
 // base_a[oa_i + k sa], the four b's at pb[k sb .. + 3] (16-byte aligned).  Four k-steps per trip; the operands of the

@@ -18,9 +18,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-ROWS = [(29, "P  loop back-edge (first pick: evaluation of s)"), (30, "P  read the candidates, minimum"), (9, "P  decide"), (10, "P  row constants"), (24, "A  d = J'n (work)"), (11, "A  barrier wait"),
-        (18, "B  pending update + z (waves 0-2)"), (25, "B  reductions | wave 3: r, t1, scalars"), (12, "B  barrier wait"),
-        (20, "C  step lengths"), (21, "C  (reject test)"), (23, "C  w, x, u, Ri column, next s"), (26, "C  argmin + publish"), (14, "C  barrier wait"),
+ROWS = [(9, "P  decide (new outer iteration: optimal? psi?)"), (10, "P  row constants"), (24, "A  d = J'n (work)"), (11, "A  barrier wait"),
+        (18, "B  pending update + z (waves 0-2)"), (25, "B  ballot | wave 3: r, t1, |d2|^2, reflector"), (12, "B  barrier wait"),
+        (20, "C  read B's results, decide"), (23, "C  w, x, u, Ri column, next s"), (26, "C  bookkeeping"),
+        (29, "E  minimum: atomics, barrier E1"), (30, "E  word: read, atomic, barrier E2"), (14, "E  read the word, re-arm, x swap"),
         (27, "D1 move, coefficients (work)"), (13, "D1 barrier wait"), (28, "D2 rows of J / Ri (work)"), (15, "D2 barrier wait")]
 
 
