@@ -142,7 +142,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
                     and not line.strip()[:5].strip().isdigit():
                 print(line, file=sys.stderr)
         for name, u in usage.items():
-            if ("solve_kernel" in name or "solve_queue_kernel" in name or "terms_kernel" in name) and (u.get("AGPRs", 0) != 0 or u.get("ScratchSize [bytes/lane]", 0) != 0 or u.get("VGPRs Spill", 0) != 0):
+            if ("solve_kernel" in name or "solve_queue_kernel" in name or "terms_kernel" in name or "integrate_kernel" in name) and (u.get("AGPRs", 0) != 0 or u.get("ScratchSize [bytes/lane]", 0) != 0 or u.get("VGPRs Spill", 0) != 0):
                 raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, VGPR spills %s -- refuse to ship (see the comment in build.py)" %
                                    (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("VGPRs Spill")))
         # The device assembly is part of the build too: every workgroup barrier must wait for the wave's own LDS traffic first

@@ -360,6 +360,7 @@ namespace inria_wbc {
             double t_ = 0.0, dt_ = 0.001;
             bool floating_base_ = true;
             bool closed_loop_ = false;
+            int solver_max_iter_ = 1000; // eiquadprog-fast DEFAULT_MAX_ITER
             std::string base_path_, behavior_type_, solver_to_use_;
             int batch_ = 0;
 

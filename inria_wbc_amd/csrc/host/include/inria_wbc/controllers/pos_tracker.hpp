@@ -44,6 +44,11 @@ namespace inria_wbc {
                     IWBC_ASSERT(mimic_dof_names_.empty(), "mimic_dof_names needs the joint names of a model (CONTROLLER.model)");
                 }
                 closed_loop_ = c["closed_loop"] ? c["closed_loop"].as<bool>() : false;
+                // eiquadprog-fast's iteration bound (DEFAULT_MAX_ITER = 1000; upstream: tsid SolverHQuadProgFast::setMaximumIterations).  The
+                // reference never sets it; the key exists so that a caller who bounds tick time gets the reference's own failure,
+                // "Status : 3 => Max iter reached" (controller.cpp:297-299), instead of a late tick
+                solver_max_iter_ = c["solver_max_iter"] ? c["solver_max_iter"].as<int>() : 1000;
+                IWBC_ASSERT(solver_max_iter_ >= 1, "solver_max_iter must be positive");
 
                 // qp solver to be used: the reference accepts 'eiquadprog' or 'qpmad' (pos_tracker.cpp:88-100)
                 if (solver_to_use_ == "hip-batched") {
@@ -202,6 +207,7 @@ namespace inria_wbc {
                     const int slot = (int)slots_.size();
                     IWBC_ASSERT(slot < WBCQP_MAX_STRUCTURES, "more contact sets than the library has slots");
                     wbcqp_structure s = stack_.c_struct();
+                    s.max_iter = solver_max_iter_;
                     int rc = wbcqp_set_structure(handle_, slot, &s);
                     if (rc != WBCQP_OK) IWBC_ERROR("wbcqp_set_structure failed: ", wbcqp_last_error(handle_));
                     wbcqp_layout L;

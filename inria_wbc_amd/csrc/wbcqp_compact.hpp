@@ -1325,9 +1325,6 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 tau = vt.y;
                 znp = dn2; // z'n = (J2 d2)'n = d2'(J2'n) = |d2|^2: the second reduction eiquadprog spends on it is the first one again
                 zok = zf != 0;
-#ifdef WBCQP_DBG_ZSUM
-                zok = false;
-#endif
                 if (!zok) { // no row's z_k^2 alone exceeds eps: the sum decides (degenerate picks only)
                     const double zk = (tid < n) ? c.z[tid] : 0.0;
                     zok = fabs(block_sum(c, zk * zk)) > eps;
@@ -1524,18 +1521,10 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                             EL[lp::ET1] = inf;
                             ELu[lp::ET1POS] = 0x7fffffffu;
                         }
-#ifdef WBCQP_DBG_MASKED_ROT
-                        const int first = i - p;
-                        double Pk = rho0 * ((row && first <= 0) ? Rrow[max(sh, -1)] : 0.0);
-                        lp::rotate_row_ps(prm, L, Pk,
-                                          [&](int jj) { const double v = Rrow[max(sh + jj, -1)]; return (row && jj >= first) ? v : 0.0; },
-                                          [&](int jj, double v) { if (has && jj >= first - 1) Rnew[sh2 + jj] = v; });
-#else
                         double Pk = rho0 * Rrow[max(sh, -1)];
                         lp::rotate_row_ps(prm, L, Pk,
                                           [&](int jj) { return Rrow[max(sh + jj, -1)]; },
                                           [&](int jj, double v) { if (has) Rnew[max(sh2 + jj, -1)] = v; });
-#endif
                         const double tj = row ? cl * Pk : 0.0; // Z(i, last): leaves the matrix
                         if (has) Rnew[sh2 + L] = 0.0;          // the last column is gone (row i2 keeps its zeros from the new mi on)
                         if (i == mi - 1) Ri[lp::rio(i, MM)] = 0.0; // ... and so is row mi - 1 (it moved up, or it was row p): its storage reads zero again
@@ -1567,9 +1556,6 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     dn2 = fma(delta, delta, dn2);
                     c.iq = iq - 1;
                     zok = zf != 0;
-#ifdef WBCQP_DBG_ZSUM
-                    zok = false;
-#endif
                     if (!zok) {
                         const double zk = (tid < n) ? c.z[tid] : 0.0;
                         zok = fabs(block_sum(c, zk * zk)) > eps;

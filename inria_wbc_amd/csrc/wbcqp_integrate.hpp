@@ -117,18 +117,22 @@ __device__ __forceinline__ void integrate_one(const int nv, const int floating_b
             qt[2] = (R1[3] - R1[1]) * tt;
         }
         else {
-            int i = 0;
-            if (R1[4] > R1[0]) i = 1;
-            if (R1[8] > R1[4 * i]) i = 2;
-            const int jx = (i + 1) % 3, kx = (jx + 1) % 3;
-            tt = sqrt(R1[4 * i] - R1[4 * jx] - R1[4 * kx] + 1.0);
-            double qv[3];
-            qv[i] = 0.5 * tt;
-            tt = 0.5 / tt;
-            qt[3] = (R1[3 * kx + jx] - R1[3 * jx + kx]) * tt;
-            qv[jx] = (R1[3 * jx + i] + R1[3 * i + jx]) * tt;
-            qv[kx] = (R1[3 * kx + i] + R1[3 * i + kx]) * tt;
-            qt[0] = qv[0]; qt[1] = qv[1]; qt[2] = qv[2];
+            // Eigen's branch for a rotation by more than 120 degrees: the largest diagonal element picks the axis.  Three explicit cases with
+            // compile-time indices: an index computed at run time (R1[4 * i], qv[i]) sent both arrays to scratch memory (80 B per lane)
+            auto from_axis = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value, jx = (i + 1) % 3, kx = (jx + 1) % 3;
+                double t3 = sqrt(R1[4 * i] - R1[4 * jx] - R1[4 * kx] + 1.0);
+                qt[i] = 0.5 * t3;
+                t3 = 0.5 / t3;
+                qt[3] = (R1[3 * kx + jx] - R1[3 * jx + kx]) * t3;
+                qt[jx] = (R1[3 * jx + i] + R1[3 * i + jx]) * t3;
+                qt[kx] = (R1[3 * kx + i] + R1[3 * i + kx]) * t3;
+            };
+            const bool one = R1[4] > R1[0];
+            const bool two = R1[8] > (one ? R1[4] : R1[0]);
+            if (two) from_axis(std::integral_constant<int, 2>{});
+            else if (one) from_axis(std::integral_constant<int, 1>{});
+            else from_axis(std::integral_constant<int, 0>{});
         }
         const double dotp = qt[0] * qx + qt[1] * qy + qt[2] * qz + qt[3] * qw;
         const double sgn = (dotp < 0.0) ? -1.0 : 1.0;

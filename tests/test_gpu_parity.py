@@ -264,6 +264,8 @@ def test_integrate_parity(floating_base):
         dq[:16, 3:6] = 0.0
         x[:16, 3:6] = 0.0
         q[16:24, 3:7] = np.array([1.0, 0.0, 0.0, 0.0])  # half turn: the trace <= 0 branch of rotation -> quaternion
+        q[24:32, 3:7] = np.array([0.0, 1.0, 0.0, 0.0])  # ... about y and about z: the branch's other two axes (three explicit cases in the kernel)
+        q[32:40, 3:7] = np.array([0.0, 0.0, 1.0, 0.0])
     status = np.zeros(B, np.int32)
     status[5::17] = 1
     ref = oracle.integrate(floating_base, dt, q, dq, x[:, :nv])

@@ -754,3 +754,40 @@ def test_task_file_key_order_does_not_change_the_trajectory(host_build, tmp_path
     for k in range(1, 4):
         assert runs[k].shape == runs[0].shape
         assert np.abs(runs[k] - runs[0]).max() < 1e-8, (k, float(np.abs(runs[k] - runs[0]).max()))
+
+
+@pytest.mark.gpu
+def test_a_bounded_solver_fails_with_the_references_text(host_build, oracle_mod, tmp_path):
+    """controller.cpp:285-307: a QP that does not end OPTIMAL throws "Controller failed, can't solve problem. Status : N => ...".  With
+    CONTROLLER.solver_max_iter (eiquadprog-fast's maxIter, 1000 when absent) below what a tick needs, the first instance whose QP is
+    stopped must come back as status 3, "Max iter reached" -- and the same batch must run clean under the default bound."""
+    from tools import dump_batch
+    from inria_wbc_amd import structure, synth
+    st = structure.talos_structure()
+    B = 24
+    inputs = synth.generate(st, B, synth.SEED_BASE["talos_squat"] + 5, task_noise=2.0)
+    first_tick = 700
+    rows = np.where(st.dense_row_task == st.task_names.index("com"))[0]
+    ref_in = {k: v.copy() for k, v in inputs.items()}
+    ref_in["b1"][:, rows] += synth.squat_com_rhs(st, first_tick, 30.0)  # what move_com adds at that tick (as in the squat test above)
+    ref = oracle_mod.tick_batch(st, ref_in, nthreads=4)
+    assert (ref["status"] == 0).all() and ref["iters"].max() > 6
+    first = int(np.argmax(ref["iters"] >= 4))  # eiquadprog stops when its counter REACHES maxIter
+    path = str(tmp_path / "b.bin")
+    dump_batch.dump(path, st, inputs)
+    base = open(os.path.join(ROOT, "configs/talos/pos_tracker.yaml")).read()
+    bounded = str(tmp_path / "pos_tracker_bounded.yaml")
+    with open(bounded, "w") as f:
+        f.write(base.rstrip("\n") + "\n  solver_max_iter: 4\n")
+    for name in ("tasks.yaml",):
+        with open(str(tmp_path / name), "w") as f:
+            f.write(open(os.path.join(ROOT, "configs/talos", name)).read())
+    squat = os.path.join(ROOT, "configs/talos/squat.yaml")
+    tau_path = str(tmp_path / "tau.bin")
+    r = subprocess.run([host_build["qp_timer_test"], bounded, squat, path, "1", tau_path, str(first_tick)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "Controller failed, can't solve problem. Status : 3 => Max iter reached" in r.stderr, r.stderr
+    assert "[instance %d]" % first in r.stderr, (first, r.stderr)
+    r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/talos/pos_tracker.yaml"), squat, path, "1", tau_path, str(first_tick)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

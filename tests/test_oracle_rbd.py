@@ -288,3 +288,42 @@ def test_sample_states_do_not_depend_on_the_sharding():
     part = mdl.sample_states(m, tm, 5, 42_000 + 4)
     for k in ("q", "v", "ref"):
         assert np.array_equal(full[k][4:9], part[k])
+
+
+def test_cop_rows_of_a_yawed_robot_are_the_physics_not_the_formula(oracle_mod):
+    """ADVICE (round 4): the device code, this oracle and structure.cop_rows all carry the same recalled expression (d n' - (n . d) I) R for tsid's
+    TaskCopEquality -- a shared misreading would pass every parity test.  This check shares nothing with them: the contact frames' placements
+    come from the numpy forward kinematics (inria_wbc_amd/model.py), the robot is turned by 40 degrees about the vertical (plus the usual state
+    noise), and the three rows applied to random contact-FRAME forces must be n x sum_i (p_i - c) x (R f_i), the tangential moment of the world
+    forces about the reference point, computed with np.cross.  (Without the factor R -- the other reading of upstream -- the identity fails as
+    soon as a foot is not world-aligned: that variant is evaluated below and must NOT pass.)"""
+    from inria_wbc_amd import model as mdl, structure
+    from oracle import rbd
+    m = mdl.talos_like()
+    st = structure.STRUCTURES["talos_torque_cop"]()
+    stack = mdl.talos_stack() + [dict(name="torque", type="torque", weight=1e-2), dict(name="cop", type="cop", weight=10.0)]
+    tm = mdl.build_taskmap(m, st, stack)
+    s = mdl.sample_states(m, tm, 4, 77, q_noise=0.05)
+    yaw = np.deg2rad(40.0)
+    for i in range(4):  # turn the floating base about the world's z axis: q[3:7] = (x, y, z, w)
+        x, y, z, w = s["q"][i, 3:7]
+        c, sn = np.cos(yaw / 2), np.sin(yaw / 2)
+        s["q"][i, 3:7] = [c * x - sn * y, c * y + sn * x, c * z + sn * w, c * w - sn * z]  # (0, 0, sn, c) * q
+    rows = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"])
+    n = np.array([0.0, 0.0, 1.0])
+    rng = np.random.default_rng(3)
+    for i in range(4):
+        A = rows["Acop"][i].reshape(3, st.k)
+        Rf, pf = m.frame_placements(s["q"][i])
+        f = rng.standard_normal(st.k)
+        mom, no_R = np.zeros(3), np.zeros(3)
+        for c, contact in enumerate(st.contacts):
+            R, p = Rf[tm.contact_frame[c]], pf[tm.contact_frame[c]]
+            assert abs(np.arctan2(R[1, 0], R[0, 0])) > np.deg2rad(25.0)  # the foot really is yawed
+            for k in range(4):
+                d = R @ contact.points[:, k] + p  # cop_ref = 0
+                fk = f[12 * c + 3 * k:12 * c + 3 * k + 3]
+                mom += np.cross(d, R @ fk)
+                no_R += np.cross(d, fk)
+        assert np.abs(A @ f - np.cross(n, mom)).max() <= 1e-10 * max(1.0, np.abs(mom).max())
+        assert np.abs(A @ f - np.cross(n, no_R)).max() > 1e-3  # the reading without R is a different constraint on a yawed foot
