@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/golden/eiquadprog_unit.npz: the two-variable unit problems of eiquadprog's own test file for EiquadprogFast
+"""tests/golden/eiquadprog/eiquadprog_unit.npz: the two-variable unit problems of eiquadprog's own test file for EiquadprogFast
 (stack-of-tasks/eiquadprog, tests/eiquadprog-fast.cpp -- not in /root/reference: [UPSTREAM-RECALL] for the problem list, but every optimum,
 objective value and outcome below is derivable by hand and is written next to its derivation, so the fixture pins the oracle's
 `wbco_eiquadprog_fast` and the library's dense seam independently of either).
@@ -9,7 +9,7 @@ Status codes (eiquadprog-fast.hpp): OPTIMAL 0, INFEASIBLE 1, UNBOUNDED 2, MAX_IT
 inequalities leaves solve_quadprog through "t = inf" = UNBOUNDED (the dual is unbounded), which tsid's
 SolverHQuadProgFast reports as HQP_STATUS_INFEASIBLE -- `tsid` below is the status the C ABI returns.
 
-    python tests/golden/make_eiquadprog_unit.py      # rewrites the .npz next to this file
+    python tests/golden/eiquadprog/make_eiquadprog_unit.py      # rewrites the .npz next to this file
 """
 import os
 

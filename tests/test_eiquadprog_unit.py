@@ -1,4 +1,4 @@
-"""eiquadprog's own two-variable unit problems for EiquadprogFast (tests/golden/make_eiquadprog_unit.py: optimum, objective and outcome of each
+"""eiquadprog's own two-variable unit problems for EiquadprogFast (tests/golden/eiquadprog/make_eiquadprog_unit.py: optimum, objective and outcome of each
 derived by hand there) against the CPU restatement `wbco_eiquadprog_fast` and, on the GPU, against the dense seam `wbcqp_solve_dense_host`:
 one more pin of the status map (eiquadprog code -> tsid code) that does not pass through the oracle's own outputs."""
 import os
@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-Z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eiquadprog_unit.npz"))
+Z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eiquadprog", "eiquadprog_unit.npz"))
 NAMES = [str(n) for n in Z["names"]]
 
 
@@ -26,7 +26,7 @@ def test_oracle_on_eiquadprogs_unit_problems(oracle_mod, nm):
 def test_fixture_is_what_its_generator_writes(tmp_path):
     """the committed .npz equals a fresh run of the committed script"""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_eiquadprog_unit.py"))
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eiquadprog", "make_eiquadprog_unit.py"))
     mk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mk)
     assert [c[0] for c in mk.CASES] == NAMES
