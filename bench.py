@@ -738,6 +738,14 @@ def main():
         elapsed = float(t.item())
     kern_avg_s = ev_s / args.steps
 
+    # the last timed step's outputs, with the tick they belong to (parity sample below) -- on the host BEFORE the exchange leg: that leg
+    # solves further ticks into the same buffers, and a collective that hangs on the device would block any later copy from its stream
+    last_tick = (t_first + args.warmup + args.steps - 1) % len(tick_dicts)
+    status = d_out["status"].cpu().numpy()
+    iters = d_out["iters"].cpu().numpy()
+    x_gpu = d_out["x"].cpu().numpy().astype(np.float64)
+    tau_gpu = d_out["tau"].cpu().numpy()[:, :st.na].astype(np.float64)
+
     # ---- the optional exchange step of BASELINE config 4, timed APART from the solve (the path itself has no collective): the
     # library's own wbcqp_allgather_tau on a communicator of this job's ranks.  It has never run on more than one rank before the
     # driver's 8-GPU run, so it runs under a watchdog: a hang costs the exchange figures, never the line.
@@ -745,12 +753,6 @@ def main():
     if distributed and args.backend == "nccl" and not args.no_exchange:
         exchange = exchange_leg(torch, dist, h, gather, rank, world, dev, d_out, st, B, tdt, sp, step, fence, args.exchange_timeout)
 
-    # the last timed step's outputs, with the tick they belong to (parity sample below)
-    last_tick = (t_first + args.warmup + args.steps - 1) % len(tick_dicts)
-    status = d_out["status"].cpu().numpy()
-    iters = d_out["iters"].cpu().numpy()
-    x_gpu = d_out["x"].cpu().numpy().astype(np.float64)
-    tau_gpu = d_out["tau"].cpu().numpy()[:, :st.na].astype(np.float64)
 
     traffic = args.traffic
     pmc = None
@@ -1024,8 +1026,9 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result["franka_single_tick"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
-        if not args.no_cpu_baseline and world == 1:
-            # the oracle is the checker here and the reported CPU baseline -- never the thing shipped.  One call per figure:
+        if not args.no_cpu_baseline:
+            # (at N > 1 too: rank 0 times the host while the other ranks wait at the final barrier -- a SCALE record then carries the baseline
+            #  beside its roofline.)  The oracle is the checker here and the reported CPU baseline -- never the thing shipped.  One call per figure:
             # work items from one counter, per-thread workspace, the clock inside the C driver between the threads' common
             # start line and the last one's end (loop shape of qp_timer_test.cpp:55-63)
             from oracle import oracle
@@ -1074,9 +1077,11 @@ def main():
         print(json.dumps(result), flush=True)
 
     if exchange is not None and exchange.get("hung"):
+        # a collective that never returned holds this process' stream and its handle: no barrier, no destructors.  The line is out (rank 0);
+        # the exit code says that the run was not clean.  Every rank's own watchdog fires on the same collective, so nobody is left waiting.
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)  # a collective that never returned holds this process' stream: no barrier, no destructors
+        os._exit(3)
     h.close()
     if distributed:
         dist.barrier()

@@ -38,6 +38,19 @@ def test_gpus_2_typed_without_a_launcher_prints_one_line_with_n_gpus_2(built_lib
     assert "torch.distributed.run" in r.stderr  # the parent says what it starts
 
 
+def test_the_n_gpus_2_line_carries_the_cpu_baseline_and_the_parity_sample(built_lib):
+    """Round 4's line had `cpu_baseline` and `parity` at N = 1 only: a SCALE record would have carried a roofline with no baseline beside it.
+    Rank 0 now times the host (and checks its sample against the oracle) while the other ranks wait at the final barrier."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+                        "--steps", "6", "--warmup", "2", "--no-compare", "--no-sweep", "--cpu-seconds", "3"],
+                       capture_output=True, text=True, timeout=900, env=_env())
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["parity"]["status_equal"] and d["parity"]["max_rel_dx"] <= 1e-8 and d["parity"]["sample"] >= 64
+    assert d["roofline"]["frac"] > 0
+
+
 def test_n1_line_has_the_contract_keys(built_lib):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
                         "--no-sweep", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900, env=_env())

@@ -16,10 +16,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+# stamp index -> phase.  The inequality loop's names are the compact kernel's (round 5: P / A / B / C / E / D1 / D2 of csrc/wbcqp_compact.hpp, a work
+# stamp before each barrier and a wait stamp behind it); the full layout (flags 16) keeps round 1's phases under the same indices 9-15
 NAMES = ["load", "assemble_Hg", "cholesky", "J=U^-1", "x0", "eq:N,rhs,B=J0'N", "eq:QR", "actuation rows -> registers", "eq:solve x,u (+Givens path)",
-         "in:s+psi+save", "in:argmin+build", "in:d", "in:z+r", "in:steplen+step", "in:add", "in:delete",
-         "loop-exit", "decode+store", "in:B z dot (compact)", "eq:W<-WT || y,u", "in:C scalars (compact)", "in:C J update (compact) | eq:N build (full)", "eq:rhs", "in:C next s (compact)",
-         "in:A d (work, before its barrier)", "in:B tail (reductions; wave 3: r, t1, scalars)", "in:C publish", "in:D1 (work)", "in:D2 (work)", "", "", ""]
+         "in:P decide | full: s+psi+save", "in:P row constants | full: argmin+build", "in:A barrier wait | full: d", "in:B barrier wait | full: z+r",
+         "in:D1 barrier wait | full: steplen+step", "in:E read the word, re-arm, x swap | full: add", "in:D2 barrier wait | full: delete",
+         "loop-exit", "decode+store", "in:B pending update + z (waves 0-2)", "eq:W<-WT || y,u", "in:C read B's results, decide", "eq:N build (full)", "eq:rhs",
+         "in:C w, x, u, Ri column, next s", "in:A d = J'n (work)", "in:B ballot | wave 3: r, t1, |d2|^2, reflector", "in:C bookkeeping", "in:D1 move, coefficients (work)",
+         "in:D2 rows of J / Ri (work)", "in:E minimum: atomics, barrier E1", "in:E word: read, atomic, barrier E2", ""]
 
 
 def main():
