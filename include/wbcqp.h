@@ -41,7 +41,14 @@
 extern "C" {
 #endif
 
-#define WBCQP_VERSION 150 /* 0.1.5: launch-order state per (handle, stream), active_mask written by every kernel, torque / cop task rows (wbcqp_structure.n_acteq, cop_*), posture mask; 140: + wbcqp_rollout, wbcqp_outputs.active_mask (WBCQP_FLAG_WARM_START), wbcqp_state.momentum, wbcqp_layout.wave_per_qp (WBCQP_FLAG_WORKGROUP_PER_QP); 130: wbcqp_integrate, wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions; 121: queue + packed launch order, wbcqp_launch_order */
+/* Interface history (WBCQP_VERSION = 100 major + 10 minor + patch; round 5 changed no declaration of this header):
+ *   150  launch-order state per (handle, stream), active_mask written by every kernel, torque / cop task rows
+ *        (wbcqp_structure.n_acteq, cop_*), posture mask
+ *   140  wbcqp_rollout, wbcqp_outputs.active_mask (WBCQP_FLAG_WARM_START), wbcqp_state.momentum, wbcqp_layout.wave_per_qp
+ *        (WBCQP_FLAG_WORKGROUP_PER_QP)
+ *   130  wbcqp_integrate, wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions
+ *   121  queue + packed launch order, wbcqp_launch_order */
+#define WBCQP_VERSION 150
 #define WBCQP_MAX_STRUCTURES 16
 #define WBCQP_MAX_INEQ_BLOCKS 16
 #define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: every per-QP vector fits one 128-entry LDS slot, n + 2 <= 128 */
@@ -123,7 +130,8 @@ typedef struct {
     const int32_t* acteq_joint;    /* [n_acteq] actuated joint in [0, na), ascending                       */
     const double* acteq_scale;     /* [n_acteq]                                                            */
     int32_t acteq_task;            /* -> index into w                                                      */
-    int32_t cop_task;              /* -> index into w; -1: no cop task (a zero-initialised structure must set it to -1) */
+    int32_t cop_task;              /* -> index into w, a task of its own (shared with no other row); -1: no cop task.  A zero-initialised structure must set it
+                                      to -1: 0 declares a cop task on task 0 -- wbcqp_set_structure refuses that when task 0 has other rows, as it has in every stack */
 } wbcqp_structure;
 
 /* Sizes derived from a structure (what PosTracker prints under `verbose`, pos_tracker.cpp:150-158). */
@@ -436,9 +444,12 @@ int wbcqp_tick_host(wbcqp_handle* handle, int slot, int batch, const wbcqp_tick_
  * workload, measured (tools/rollout_bench.py, profiles/r03/rollout_bench.log, profiles/r04/): two sub-batches 1.04x of the tick loop at
  * B = 1024 where one instance stays the hard one, but 0.76x where every instance is heavy (nothing idles in a tick's tail) and 0.93x at
  * B = 4096 (the launch hides its own tail); three sub-batches 1.02x, four 0.57x.  So the library MEASURES: every roll-out is timed on
- * the device by an event pair that a later call reads without blocking; the first roll-out of a (slot, batch) runs as one stream, the
- * next one as two, from then on whichever was faster (the other one retried every 64th call while within 20 %).  Never slower than the
- * tick loop once both are measured; what it buys is bounded by the slowest INSTANCE's own chain of K ticks.  Bit for bit the result of K
+ * the device by an event pair that a later call reads without blocking; the first roll-outs of a (slot, batch) run as one stream, then
+ * as two -- the first sample of either form is not kept: it pays that form's allocations, stream creation and a device synchronisation
+ * (so the first TWO calls of each form block on the device once) --, from then on whichever was faster, the other one tried again every
+ * 64th call whatever its last figure.  With both measured it is the tick loop or better, up to what a drifting workload changes between
+ * two such retries; what it buys is bounded by the slowest INSTANCE's own chain of K ticks (round 5, B = 1024: 1.06x with two sub-batches,
+ * 1.09x with three -- a tick's solve is 0.12 ms of which the hard instance's own chain is 0.10 -- profiles/r05/).  Bit for bit the result of K
  * calls of wbcqp_tick with q_next / v_next fed back, whatever the choice.  (A single persistent kernel running the three phases back to back per instance was built and measured first: 0.69x of the tick
  * loop -- the three phases together do not fit 256 VGPRs, and an instance's rows phase runs at 8 waves per CU instead of 16;
  * profiles/r03/fused_rollout_kernel_not_kept.log, DESIGN.md.)  Loop shape: qp_timer_test.cpp:55-63.  All pointers are DEVICE pointers.

@@ -155,12 +155,32 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
             shutil.copy(os.path.join(tmpdir, asm[0]), DEVICE_ASM + ".refused")
             raise RuntimeError("%d of %d s_barrier without a preceding s_waitcnt lgkmcnt(0): %s ... -- refuse to ship (assembly kept as %s.refused)" %
                                (len(bad), total, bad[:4], DEVICE_ASM))
+        check_specialisations(LIB + ".tmp")
         os.replace(LIB + ".tmp", LIB)
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)  # (-save-temps leaves some 40 MB there)
         if os.path.exists(LIB + ".tmp"):
             os.remove(LIB + ".tmp")
     return LIB
+
+
+def check_specialisations(lib_path: str) -> None:
+    """kSpecDims (csrc/wbcqp_types.hpp) repeats by hand what derive_compact computes for the shipped stacks; a layout change that is not carried over
+    would move them to the generic kernel without a word (about 8 % slower, same results).  The library just built is asked for the layout of each
+    stack (host code only: no GPU needed) and refused when one does not get its own instantiation; WBCQP_DEBUG_DUMP_STRUCT=1 prints the row to paste."""
+    import ctypes
+    from . import capi, structure
+    lib = ctypes.CDLL(lib_path)  # (a private handle on the file just built: the process may already hold the previous libwbcqp.so)
+    lib.wbcqp_layout_of.argtypes = [ctypes.POINTER(capi.CStructure), ctypes.POINTER(capi.CLayout)]
+    for name, want in (("talos", 1), ("icub", 2), ("talos_single_support", 3)):
+        sb, L = capi.StructureBuffers(structure.STRUCTURES[name]()), capi.CLayout()
+        if lib.wbcqp_layout_of(ctypes.byref(sb.c), ctypes.byref(L)) != 0:
+            raise RuntimeError("wbcqp_layout_of refuses the %s stack" % name)
+        got = L.specialised
+        if got != want:
+            raise RuntimeError("%s: wbcqp_layout.specialised = %d, expected %d -- kSpecDims (csrc/wbcqp_types.hpp) no longer equals the layout derive_compact "
+                               "computes for this stack; WBCQP_DEBUG_DUMP_STRUCT=1 python -c 'from inria_wbc_amd import capi, structure; "
+                               "capi.layout_of(structure.STRUCTURES[\"%s\"]())' prints the row" % (name, got, want, name))
 
 
 def _resource_usage(text: str) -> dict:

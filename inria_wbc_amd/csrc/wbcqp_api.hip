@@ -124,6 +124,7 @@ struct wbcqp_handle {
     struct RollStat {
         int slot = -1, batch = 0, calls = 0;
         double us[3] = {0.0, 0.0, 0.0}; // [S] running mean, 0: never measured
+        int cold[3] = {1, 1, 1};        // [S] the next measurement of this form is its first: it paid the form's allocations and stream set-up, it is not kept
     };
     std::vector<RollStat> roll_stats;
     struct RollMeas { // one timed event pair around a roll-out, read by a later call once the device has passed it
@@ -187,6 +188,19 @@ int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout
     if (D.cop_task >= D.n_tasks) { why = "cop_task out of range"; return WBCQP_ERR_INVALID; }
     if (D.cop_task < 0) D.cop_task = -1;
     if (D.cop_task >= 0 && D.nc == 0) { why = "a cop task needs a contact"; return WBCQP_ERR_INVALID; }
+    if (D.cop_task >= 0) {
+        // A cop task is a task of its own: its index into w is shared with no other row.  This is also what catches the C idiom the field is a trap
+        // for -- a zero-initialised (memset) structure says cop_task = 0, which is some dense or selection task's index in every real stack
+        bool shared = (D.n_acteq > 0 && D.acteq_task == D.cop_task);
+        for (int r = 0; r < st->n_dense && st->dense_row_task && !shared; ++r) shared = st->dense_row_task[r] == D.cop_task;
+        for (int r = 0; r < st->n_sel && st->sel_task && !shared; ++r) shared = st->sel_task[r] == D.cop_task;
+        for (int c2 = 0; c2 < st->nc && st->forcereg_task && !shared; ++c2) shared = st->forcereg_task[c2] == D.cop_task;
+        if (shared) {
+            why = "cop_task " + std::to_string(D.cop_task) + " is also the task of other level-1 rows: a cop task has a weight of its own (a structure WITHOUT a cop "
+                  "task sets cop_task = -1; zero-initialisation alone declares one on task 0)";
+            return WBCQP_ERR_INVALID;
+        }
+    }
     D.dense_h = (D.n_acteq > 0 || D.cop_task >= 0) ? 1 : 0;
     if (D.dense_h && D.n > 80) { why = "a torque / cop task makes H dense: supported for n <= 80 (the dense seam, wbcqp_solve_dense, carries n <= 96)"; return WBCQP_ERR_UNSUPPORTED; }
     if (D.cop_task >= 0 && 3 * D.k > kSlot) { why = "cop rows exceed one 128-entry slot"; return WBCQP_ERR_UNSUPPORTED; }
@@ -1512,17 +1526,19 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
     // above the rest, B = 1024: 1.04x -- and cost where it has none (every instance heavy: 0.76x) or where the launch is large
     // enough to hide its tail by itself (B = 4096: 0.93x); three gain less (1.02x), four queue behind one another (0.57x)
     // [tools/rollout_bench.py].  Which regime a caller is in is not knowable from the arguments, so it is measured: the first
-    // roll-out of a (slot, batch) runs one sub-batch, the second two, each timed on the device by an event pair the NEXT call
-    // reads without blocking; from then on the faster of the two, the other one tried again every 64th call while it is within
-    // 20 % (a workload drifts).  WBCQP_ROLLOUT_STREAMS overrides (1 .. 8).  The result does not depend on the choice, bit for bit.
+    // roll-outs of a (slot, batch) run one sub-batch, then two, each timed on the device by an event pair a LATER call reads
+    // without blocking -- the first sample of either form is discarded (it pays that form's allocations, stream creation and a
+    // device synchronisation) --; from then on the faster of the two, the other one tried again every 64th call (a workload drifts).  WBCQP_ROLLOUT_STREAMS overrides (1 .. 8).  The result does not depend on the choice, bit for bit.
     for (auto& mz : h->roll_meas) {
         if (!mz.pending || hipEventQuery(mz.t1) != hipSuccess) continue;
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, mz.t0, mz.t1) == hipSuccess && mz.ticks > 0 && mz.S >= 1 && mz.S <= 2 && mz.stat >= 0 &&
             mz.stat < (int)h->roll_stats.size()) {
-            double& slot_us = h->roll_stats[mz.stat].us[mz.S];
+            auto& stt = h->roll_stats[mz.stat];
+            double& slot_us = stt.us[mz.S];
             const double us = (double)ms * 1e3 / mz.ticks;
-            slot_us = slot_us > 0.0 ? 0.5 * (slot_us + us) : us;
+            if (stt.cold[mz.S]) stt.cold[mz.S] = 0; // (the form runs once more before it is compared)
+            else slot_us = slot_us > 0.0 ? 0.5 * (slot_us + us) : us;
         }
         mz.pending = false;
     }
@@ -1551,7 +1567,7 @@ int wbcqp_rollout(wbcqp_handle* h, int slot, int batch, int n_ticks, const wbcqp
             else {
                 S = stt.us[2] < stt.us[1] ? 2 : 1;
                 const int other = 3 - S;
-                if (stt.calls % 64 == 63 && stt.us[other] < 1.2 * stt.us[S]) S = other;
+                if (stt.calls % 64 == 63) S = other; // the other form again, whatever its last figure: a workload drifts, and one inflated sample must not pin the choice
             }
         }
         ++stt.calls;

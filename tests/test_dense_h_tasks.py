@@ -168,3 +168,18 @@ def test_invalid_torque_and_cop_structures_are_rejected(built_lib):
     assert e.value.code == 3
     with pytest.raises(ValueError, match="wrong size in torque mask"):
         structure.with_torque_task(structure.talos_structure(), 1.0, mask=[1, 1])
+
+
+def test_a_zero_initialised_cop_task_is_refused(built_lib):
+    """ADVICE (round 4): wbcqp_structure.cop_task uses -1 for "none", so the usual C idiom -- memset the structure, fill what you know -- declares a
+    cop task on task 0.  Task 0 carries other rows in every stack (Talos: the head task's), and a cop task is a task of its own: the library says so
+    instead of sizing b1 / Acop for a task nobody asked for."""
+    from inria_wbc_amd import capi
+    import dataclasses
+    plain = structure.talos_structure()
+    assert plain.cop_task == -1 and capi.layout_of(plain)["len_Acop"] == 0
+    with pytest.raises(capi.WbcqpError, match="cop_task = -1") as e:
+        capi.layout_of(dataclasses.replace(plain, cop_task=0))
+    assert e.value.code == 1
+    good = structure.STRUCTURES["talos_cop"]()  # its cop task is the last one, with a weight of its own
+    assert capi.layout_of(good)["len_Acop"] == 3 * good.k
