@@ -84,3 +84,24 @@ def test_ragged_launch_sends_small_groups_to_their_own_kernel(oracle_mod):
         x = d_out["x"].cpu().numpy()
         assert np.abs(x[:, :st.nv] - ref["x"][:, :st.nv]).max() <= TOL_F64 * max(1.0, np.abs(ref["x"]).max()), st.name
     h.close()
+
+
+@pytest.mark.parametrize("nv", [11, 13, 15])
+def test_odd_sizes_on_the_four_wave_compact_kernel(oracle_mod, nv):
+    """The compact loop walks the rows of J in 16-byte pairs from an even column on, with a zero pad pair behind column n: an odd n puts the pad
+    INSIDE the last pair of a row (round 5).  Tiago-like stacks of odd size through the four-wave kernel (WBCQP_FLAG_WORKGROUP_PER_QP), bounds
+    binding (adds, drops), against the oracle and against the one-wavefront kernel."""
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.tiago_structure(nv=nv)
+    assert st.n % 2 == 1
+    inputs = synth.generate(st, 200, synth.SEED_BASE["tiago"] + 100 + nv, task_noise=30.0, p_bnd=0.3)
+    ref = oracle_mod.tick_batch(st, inputs)
+    wg = _solve(st, inputs, flags=capi.FLAG_WORKGROUP_PER_QP)
+    one = _solve(st, inputs)
+    assert ref["iters"].max() >= 4
+    for got in (wg, one):
+        assert np.array_equal(got["status"], ref["status"])
+        ok = ref["status"] == 0
+        scale = np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
+        assert (np.abs(got["x"] - ref["x"]).max(axis=1)[ok] <= TOL_F64 * scale[ok]).all()
+        assert (got["iters"] == ref["iters"]).mean() >= 0.9

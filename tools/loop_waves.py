@@ -24,6 +24,9 @@ ROWS = [(9, "P  decide (new outer iteration: optimal? psi?)"), (10, "P  row cons
         (29, "E  minimum: atomics, barrier E1"), (30, "E  word: read, atomic, barrier E2"), (14, "E  read the word, re-arm, x swap"),
         (27, "D1 move, coefficients (work)"), (13, "D1 barrier wait"), (28, "D2 rows of J / Ri (work)"), (15, "D2 barrier wait")]
 
+SETUP = [(0, "load, landing"), (1, "H, g assembly"), (2, "elimination of the dv block"), (3, "force blocks, J = U^-1"), (4, "x0"), (22, "rhs of the equalities"),
+         (5, "B = J0'N"), (6, "equality QR"), (19, "y"), (8, "x, u"), (7, "actuation rows -> registers, loop's arrays zeroed"), (16, "loop exit"), (17, "decode, store")]
+
 
 def one(lib, qp_list, tick):
     import torch
@@ -88,6 +91,10 @@ def main():
             print("   %-46s %7.0f %7.0f %7.0f %7.0f" % (nm, *vals))
         loop = [sum(data[(qp, w)][1][idx] for idx, _ in ROWS) / max(it, 1) for w in range(4)]
         print("   %-46s %7.0f %7.0f %7.0f %7.0f" % ("loop, per iteration", *loop))
+        print("   set-up, cycles of the QP (a phase's stamp follows its last barrier: a wave that finishes early shows the others' time as its own):")
+        for idx, nm in SETUP:
+            print("   %-46s %7.0f %7.0f %7.0f %7.0f" % (nm, *[data[(qp, w)][1][idx] for w in range(4)]))
+        print("   %-46s %7.0f %7.0f %7.0f %7.0f" % ("set-up, total", *[sum(data[(qp, w)][1][idx] for idx, _ in SETUP) for w in range(4)]))
 
 
 if __name__ == "__main__":
