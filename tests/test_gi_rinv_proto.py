@@ -1,5 +1,6 @@
-"""The arithmetic of the round-3 active-set loop (R^-1 carried instead of R, drop rotations from one prefix sum, rank-one
-updates of d / z / r after a drop: tools/gi_rinv_proto.py) against the C oracle's eiquadprog-fast restatement
+"""The arithmetic of the compact kernel's active-set loop (round 3: R^-1 carried instead of R, drop rotations from one prefix sum, rank-one
+updates of d / z / r after a drop; round 5: the rotations in closed form -- one running sum per row -- and a constraint's reflector kept
+pending and folded into the next pick's d: tools/gi_rinv_proto.py) against the C oracle's eiquadprog-fast restatement
 (oracle/wbc_oracle.c).  CPU only: pins the MATH the HIP kernel implements before any GPU is involved."""
 import numpy as np
 import pytest
@@ -15,8 +16,8 @@ from tools import gi_rinv_proto as proto
     ("icub", 0, 6, dict(task_noise=2.0)),
     ("talos_single_support", 0, 4, dict(task_noise=2.0)),
 ])
-@pytest.mark.parametrize("projector", [False, True])
-def test_proto_matches_oracle(name, first, count, kw, projector):
+@pytest.mark.parametrize("projector,round5", [(False, False), (True, False), (False, True)])
+def test_proto_matches_oracle(name, first, count, kw, projector, round5):
     st = structure.STRUCTURES[name]()
     seed = synth.SEED_BASE["talos_squat" if kw.get("squat") else name]
     inp = synth.generate(st, count, seed, first=first, **kw)
@@ -25,7 +26,7 @@ def test_proto_matches_oracle(name, first, count, kw, projector):
     for i in range(count):
         H, g, CE, ce0, CI, ci0 = oracle.assemble(st, inp, i)
         tr = {}
-        out = proto.solve(H, g, CE, ce0, CI, ci0, trace=tr, projector=projector)
+        out = proto.solve(H, g, CE, ce0, CI, ci0, trace=tr, projector=projector, round5=round5)
         assert out["status"] == ref["status"][i]
         scale = max(1.0, float(np.abs(ref["x"][i]).max()))
         assert np.abs(out["x"] - ref["x"][i]).max() <= 1e-8 * scale

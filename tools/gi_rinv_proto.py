@@ -20,8 +20,13 @@ EPS = np.finfo(float).eps
 OPTIMAL, INFEASIBLE, MAX_ITER, ERROR = 0, 1, 3, 4
 
 
-def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False, store=None):
-    """store=np.float32: SURVEY section 7's "fp32 storage, fp64 accumulate" option, modelled: J and Ri -- the two arrays that live in LDS for
+def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False, store=None, round5=False):
+    """round5=True: the loop as round 5 runs it (csrc/wbcqp_compact.hpp) -- a drop's rotations in CLOSED FORM (with rho = row p of Ri from column p on,
+    S_l = sum_{i<=l} rho_i^2 and P_l = sum_{i<=l} rho_i x_i, the new element of column l of any row x is a_l P_l + b_l x_{l+1}, a_l = -rho_{l+1} / sqrt(S_l S_{l+1}),
+    b_l = sqrt(S_l / S_{l+1}), and -P_L / sqrt(S_L) leaves the active block: one running sum per row instead of a chain of rotations), and a constraint's
+    reflector kept PENDING: J is left as it is when a constraint is added, the next pick forms d = J_old'n - v (w'n) and applies J <- J - w v' only then.
+
+    store=np.float32: SURVEY section 7's "fp32 storage, fp64 accumulate" option, modelled: J and Ri -- the two arrays that live in LDS for
     the whole loop -- are rounded to `store` after every update, every product and sum stays in f64 (tools/f32_storage_probe.py)."""
     n = g.size
     rnd = (lambda a: a) if store is None else (lambda a: a.astype(store).astype(np.float64))
@@ -47,6 +52,7 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False, st
     # (Goldfarb-Idnani's H* operator): z = G n, adding a constraint is G -= z z' / (z'n) with the new column z / sqrt(z'n) of J1,
     # dropping one returns the leaving column q of J1: G += q q'.
     G = J[:, iq:] @ J[:, iq:].T if projector else None
+    pend = None  # (w, v, first column) of the last accepted constraint's reflector, not applied to J yet (round5)
     A = [-(i + 1) for i in range(neq)]
     u = np.zeros(n + 2)
     act = np.zeros(m, bool)
@@ -77,7 +83,14 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False, st
                 trace.setdefault("events", []).append(("pick", ip, iq - neq))
             u[iq] = 0.0
             A = A[:iq] + [ip]
-            d = J.T @ npv
+            if round5 and pend is not None:
+                w_, v_, pc_ = pend
+                d = J.T @ npv                       # from J as it stands ...
+                d[pc_:] -= v_ * float(w_ @ npv)     # ... with the pending update folded in
+                J[:, pc_:] = rnd(J[:, pc_:] - np.outer(w_, v_))  # (the kernel does this in the pass that forms z)
+                pend = None
+            else:
+                d = J.T @ npv
             if projector:
                 d[iq:] = 0.0
                 z = G @ npv
@@ -118,7 +131,22 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False, st
                 rho = Ri[p, p:mi].copy()
                 S = np.cumsum(rho * rho)
                 Z = Ri[:mi, :mi].copy()
-                for j in range(mi - 1 - p):  # columns (p + j, p + j + 1)
+                Lr = mi - 1 - p
+                if round5:
+                    al = -rho[1:] / np.sqrt(S[:-1] * S[1:])
+                    bl = np.sqrt(S[:-1] / S[1:])
+                    cl = -1.0 / np.sqrt(S[-1])
+
+                    def rot(X):  # rows x columns p .. mi - 1 -> (new columns p .. mi - 2, what leaves)
+                        P = np.cumsum(X * rho, axis=1)
+                        return al * P[:, :-1] + bl * X[:, 1:], cl * P[:, -1]
+                    Zn, Zl = rot(Z[:, p:mi])
+                    Jn, Jl = rot(J[:, neq + p:neq + mi])
+                    dn, dl = rot(d[None, neq + p:neq + mi])
+                    Z[:, p:mi - 1] = Zn; Z[:, mi - 1] = Zl
+                    J[:, neq + p:neq + mi - 1] = rnd(Jn); J[:, neq + mi - 1] = rnd(Jl)
+                    d[neq + p:neq + mi - 1] = dn[0]; d[neq + mi - 1] = dl[0]
+                for j in range(0 if round5 else Lr):  # (rounds 3-4: the rotations one after the other) columns (p + j, p + j + 1)
                     a = rho[0] if j == 0 else -np.sqrt(S[j])
                     b = rho[j + 1]
                     hh = np.sqrt(S[j + 1])
@@ -161,7 +189,10 @@ def solve(H, g, CE, ce0, CI, ci0, max_iter=1000, trace=None, projector=False, st
                 v[0] -= alpha
                 tau = 1.0 / (nx * abs(diq) + dn2)
                 w = tau * (z - alpha * J[:, iq])
-                J[:, iq:] = rnd(J[:, iq:] - np.outer(w, v))
+                if round5:
+                    pend = (w, v, iq)
+                else:
+                    J[:, iq:] = rnd(J[:, iq:] - np.outer(w, v))
             if abs(alpha) <= EPS * R_norm:  # dependent: back to the saved iterate, pick another
                 excl[ip] = False
                 for i in range(min(iq, len(A_old))):
