@@ -199,8 +199,13 @@ def test_full_size_properties(handle, oracle_mod):
         worst_eq = max(worst_eq, np.abs(np.einsum("crj,j->cr", Ac, dv).ravel() - inputs["bc"][i]).max())
         tau = M[nu:] @ dv + h[nu:] - Jc[:, nu:].T @ f
         worst_tau = max(worst_tau, np.abs(tau - got["tau"][i]).max())
-        # bounds hold up to the solver's own stopping rule: sum of violations <= nIneq*eps*tr(H)*tr(J)*100 (GI step 1)
-        assert (tau >= inputs["tlb"][i] - 1.0).all() and (tau <= inputs["tub"][i] + 1.0).all()
+        # bounds hold up to the solver's own stopping rule -- and THAT number is the bar: eiquadprog stops when the sum of all violations is at most
+        # nIneq * eps * tr(H) * tr(J) * 100 with J = L^-T (about 0.3 on this stack), so the torque bounds' share of it is at most that
+        Hd = oracle_mod.assemble(st, inputs, i)[0]
+        psi_tol = st.nin2 * np.finfo(float).eps * np.trace(Hd) * (1.0 / np.diag(np.linalg.cholesky(Hd))).sum() * 100.0
+        viol = np.maximum(0.0, inputs["tlb"][i] - tau).sum() + np.maximum(0.0, tau - inputs["tub"][i]).sum()
+        assert viol <= psi_tol * (1.0 + 1e-6) + 1e-9, (i, viol, psi_tol)
+        assert 0.01 < psi_tol < 5.0  # (the tolerance is what DESIGN 4c says it is on these stacks)
     assert worst_eq < 1e-6 and worst_tau < 1e-9, (worst_eq, worst_tau)
     sub = {k: v[:32] for k, v in inputs.items()}
     ref = oracle_mod.tick_batch(st, sub, nthreads=4)
