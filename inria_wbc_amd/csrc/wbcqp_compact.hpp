@@ -940,7 +940,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         double tau_q = 0.0; // tau' of the quad's actuation row at the iterate of the last evaluation (all four lanes)
         auto eval_rows = [&](const double* xp, const double* zp, double t, int ipx) __attribute__((always_inline)) {
             bool oka = false, oko = false;
-            if (act_ineq) {
+            if (act_ineq && arr < na) { // (quads past the last actuated joint have no row: the fourth wave skips the dot product altogether)
                 const double acc = act_dot(c, ar, xp, zp, t);
                 tau_q = acc;
                 if (aq == 0 && arr < na) tact[arr] = acc;
@@ -978,7 +978,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         // tau' of the final iterate is evaluated from scratch in the decode, so the output never carries the accumulated sum.
         auto eval_rows_inc = [&](const double* zp, double t, int ipx) __attribute__((always_inline)) {
             bool oka = false, oko = false;
-            if (act_ineq) {
+            if (act_ineq && arr < na) {
                 const double acc = fma(t, act_dot1(c, ar, zp), tau_q);
                 tau_q = acc;
                 if (act_owner) {
