@@ -1013,8 +1013,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             return cand_of(oka, oko);
         };
         // The election (two barriers): on return every thread holds the most violated candidate's (s, word) -- word ~0: nobody stood --
-        // and the same for the hinted rows.  The slots alternate; the one not in use is re-armed behind the second barrier (its last
-        // readers passed the first one, its next atomics lie behind at least one more barrier).
+        // and the same for the hinted rows.  The slots alternate; the one not in use is re-armed in the next pick's phase A.
         int par = 0;
         double el_v = 0.0, el_wv = 0.0;
         unsigned el_key = 0xffffffffu, el_wkey = 0xffffffffu;
@@ -1038,15 +1037,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 el_wv = mw;
                 el_wkey = ELu[lp::EWKEY + par];
             }
-            par ^= 1;
-            if (tid == kThreads - 1) {
-                EL[lp::EMIN + par] = lp::kNone;
-                ELu[lp::EKEY + par] = 0xffffffffu;
-                if (use_warm) {
-                    EL[lp::EWMIN + par] = lp::kNone;
-                    ELu[lp::EWKEY + par] = 0xffffffffu;
-                }
-            }
+            par ^= 1; // (the other slot is re-armed where the pick is set up: phase A, below)
         };
         if (neq == 0) bsync(); // (with equalities: the barrier of the equality phase's last reduction)
         const double psi_tol = (double)nin2 * eps * c1 * c2 * 100.0;
@@ -1123,6 +1114,14 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             if (tid == kThreads - 1) {
                 c.u[iq0] = 0.0;
                 c.A[iq0] = ip;
+                // the slot of the NEXT election is re-armed here: its last readers passed the barrier of the election just held, its next atomics lie
+                // behind this pick's barriers
+                EL[lp::EMIN + par] = lp::kNone;
+                ELu[lp::EKEY + par] = 0xffffffffu;
+                if (use_warm) {
+                    EL[lp::EWMIN + par] = lp::kNone;
+                    ELu[lp::EWKEY + par] = 0xffffffffu;
+                }
             }
             STAMP(10)
 
