@@ -1296,11 +1296,14 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         v0 = diq - alpha;
                         tau = fast_rcp(fma(nx, fabs(diq), dn2));
                     }
-                    if (c.lane == 0) {
-                        LS[lp::BDN2] = dn2;
-                        LS[lp::BALPHA] = alpha;
-                        LS[lp::BV0] = v0;
-                        LS[lp::BTAU] = tau;
+                    if (c.lane == 0) { // (|d2|^2, alpha) and (v0, tau) are read as pairs: written as pairs
+                        double2v o;
+                        o.x = dn2;
+                        o.y = alpha;
+                        *reinterpret_cast<double2v*>(__builtin_assume_aligned(LS + lp::BDN2, 16)) = o;
+                        o.x = v0;
+                        o.y = tau;
+                        *reinterpret_cast<double2v*>(__builtin_assume_aligned(LS + lp::BV0, 16)) = o;
                         LS[lp::BT2C] = ratio_pos(-sip, dn2);
                     }
                 }
