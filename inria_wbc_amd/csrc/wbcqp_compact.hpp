@@ -268,7 +268,11 @@ struct OwnRow {
 
 template <int SPEC> __device__ __forceinline__ Dims dims_of(const DevStruct& S)
 {
-    if constexpr (SPEC > 0) return kSpecDims[SPEC - 1]; // literals (wbcqp_types.hpp); the host has checked that they are this structure's
+    if constexpr (SPEC > 0) {
+        Dims d = kSpecDims[SPEC - 1]; // literals (wbcqp_types.hpp); the host has checked that they are this structure's
+        d.max_iter = S.max_iter;      // ... all but the iteration bound: a caller that bounds its tick time keeps its stack's instantiation
+        return d;
+    }
     else return dims_from(S);
 }
 

@@ -120,7 +120,8 @@ __host__ __device__ inline Dims dims_from(const DevStruct& S)
     return Dims{S.nv, S.na, S.nc, S.k, S.n, S.nu, S.n_dense, S.n_tasks, S.n_sel, S.n_bound, S.act_bounds, S.neq, S.nin2, S.r1, S.max_iter,
                 S.ldj, S.ldb, S.o_J, S.o_R, S.o_vec, S.o_int, S.o_pan, S.act_off};
 }
-// 1-based index into kSpecDims of the specialisation whose literals equal this compact layout, 0: none
+// 1-based index into kSpecDims of the specialisation whose literals equal this compact layout, 0: none (max_iter is not matched: the
+// instantiations read it from the structure)
 inline int spec_of(const DevStruct& C)
 {
     if (!C.compact) return 0;
@@ -129,7 +130,7 @@ inline int spec_of(const DevStruct& C)
         const Dims& s = kSpecDims[i];
         if (d.nv == s.nv && d.na == s.na && d.nc == s.nc && d.k == s.k && d.n == s.n && d.nu == s.nu && d.n_dense == s.n_dense && d.n_tasks == s.n_tasks &&
             d.n_sel == s.n_sel && d.n_bound == s.n_bound && d.act_bounds == s.act_bounds && d.neq == s.neq && d.nin2 == s.nin2 && d.r1 == s.r1 &&
-            d.max_iter == s.max_iter && d.ldj == s.ldj && d.ldb == s.ldb && d.o_J == s.o_J && d.o_R == s.o_R && d.o_vec == s.o_vec && d.o_int == s.o_int &&
+            d.ldj == s.ldj && d.ldb == s.ldb && d.o_J == s.o_J && d.o_R == s.o_R && d.o_vec == s.o_vec && d.o_int == s.o_int &&
             d.o_pan == s.o_pan && d.act_off == s.act_off)
             return i + 1;
     }

@@ -61,19 +61,20 @@ def test_max_iter_on_the_four_wave_kernels(oracle_mod, kernel):
     assert n_hit[0] == 96 and n_hit[0] > n_hit[1] > n_hit[2] > 0  # max_iter 1 stops every QP before its first pick
 
 
-def test_a_bound_other_than_1000_runs_the_generic_kernel_with_the_same_bits(oracle_mod):
-    """The per-stack instantiations carry max_iter as a literal (csrc/wbcqp_types.hpp: kSpecDims): a structure with another bound must be
-    reported as not specialised, and the generic kernel it runs must give what the stack's own instantiation gives wherever no QP is stopped."""
+def test_a_bound_other_than_1000_keeps_the_stacks_own_kernel(oracle_mod):
+    """The per-stack instantiations carry every size as a literal (csrc/wbcqp_types.hpp: kSpecDims) except the iteration bound, which they
+    read from the structure: a caller that bounds its tick time (max_iter = 200) keeps its stack's instantiation, and that kernel, the same
+    one with the default bound and the generic kernel give the same bits wherever no QP is stopped."""
     from inria_wbc_amd import capi, structure, synth
     st = structure.talos_structure()
     assert capi.layout_of(st)["specialised"] == 1
     st200 = dataclasses.replace(st, max_iter=200)
-    assert capi.layout_of(st200)["specialised"] == 0 and capi.layout_of(st200)["waves_per_cu"] == 2
+    assert capi.layout_of(st200)["specialised"] == 1 and capi.layout_of(st200)["waves_per_cu"] == 2
     inputs = synth.generate(st, 200, synth.SEED_BASE["talos"] + 32, task_noise=2.0)
-    a, b = _solve(st, inputs), _solve(st200, inputs)
+    a, b, g = _solve(st, inputs), _solve(st200, inputs), _solve(st200, inputs, capi.FLAG_GENERIC_KERNEL)
     assert (a["status"] == 0).all() and a["iters"].max() < 200
     for k in ("x", "tau", "status", "iters"):
-        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], g[k]), k
 
 
 def test_max_iter_on_one_wavefront_per_qp(oracle_mod):
