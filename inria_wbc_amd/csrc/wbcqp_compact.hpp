@@ -669,7 +669,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     const double eps = 2.220446049250313e-16;
     const double inf = __builtin_huge_val();
     int status = -2; // running
-    int iter = 0;
+    int left = D.max_iter; // outer iterations left before status 3: counted down, so that the loop keeps one register and never the bound itself
     // the loop's flags, set here so that the equality phase's barriers make them visible (other threads read them in the first evaluation
     // of s): with equalities the loop then needs no barrier of its own before it starts
     if (nin2 > 0) {
@@ -1072,8 +1072,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             if (!redo) {
                 // l1: a new outer iteration
                 slow = false;
-                ++iter;
-                if (iter >= D.max_iter) {
+                if (--left <= 0) { // (eiquadprog: ++iter >= maxIter)
                     status = HQP_MAX_ITER;
                     break;
                 }
@@ -1585,7 +1584,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     }
     else if (status == -2) {
         // no inequality rows at all: the equality-constrained minimiser is the solution (eiquadprog: one pass of l1)
-        iter = 1;
+        --left; // (iter = 1)
         status = HQP_OPTIMAL;
     }
 
@@ -1617,7 +1616,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     }
     if (tid == 0) {
         ga.status[qp] = status;
-        ga.iters[qp] = iter;
+        ga.iters[qp] = D.max_iter - left;
         if (ga.objective) ga.objective[qp] = (TI)f_value;
         if (ga.n_active) ga.n_active[qp] = c.iq;
     }
