@@ -145,6 +145,12 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
             if ("solve_kernel" in name or "solve_queue_kernel" in name or "terms_kernel" in name or "integrate_kernel" in name) and (u.get("AGPRs", 0) != 0 or u.get("ScratchSize [bytes/lane]", 0) != 0 or u.get("VGPRs Spill", 0) != 0):
                 raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, VGPR spills %s -- refuse to ship (see the comment in build.py)" %
                                    (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("VGPRs Spill")))
+            # the three-per-CU twin of the compact queue kernel is the one place scratch is admitted: it is compiled for 168 VGPRs and measured
+            # faster WITH its spills than the two-per-CU kernel without (tools/occ3_probe.py).  It must really reach three waves per SIMD, keep
+            # AGPRs out (the bug above) and its spills bounded.
+            if "solve_queue3_kernel" in name and (u.get("AGPRs", 0) != 0 or u.get("Occupancy [waves/SIMD]", 0) < 3 or u.get("ScratchSize [bytes/lane]", 0) > 320):
+                raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, occupancy %s -- refuse to ship" %
+                                   (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("Occupancy [waves/SIMD]")))
         # The device assembly is part of the build too: every workgroup barrier must wait for the wave's own LDS traffic first
         # (tools/check_barriers.py says why; bsync() in wbcqp_prims.hpp issues the wait).
         asm = [f for f in os.listdir(tmpdir) if f.endswith("gfx950.s")]

@@ -76,6 +76,7 @@ struct OrderState {
 
 constexpr size_t kMaxQueues = 16;
 constexpr int kQueueMinLds = 48 * 1024; // workgroups at least this large take their QPs from the queue by default
+constexpr int kLdsThree = 54592;        // the largest dynamic LDS block of which a CU holds three (tools/ubench/lds_granule.hip)
 constexpr int kOrderRefresh = 4; // default period of the launch-order renewal (WBCQP_FLAG_REFRESH)
 
 struct wbcqp_handle {
@@ -108,6 +109,7 @@ struct wbcqp_handle {
     wbcqp_dense_output dense_out{};
     int lds_pad = 0; // diagnostic (env WBCQP_DEBUG_LDS_PAD): extra dynamic LDS per workgroup, to force a lower residency
     int queue_lds[2 + kNumSpecs], queue_occ[2 + kNumSpecs] = {}; // occupancy of solve_queue_kernel<., CP, SPEC> at queue_lds bytes of LDS
+    bool queue_three[2 + kNumSpecs] = {};                        // ... and whether solve_queue3_kernel<., SPEC> holds three workgroups per CU at that size
     // wbcqp_rollout: sub-batches on streams of their own (each with its own launch-order state and queue counter), the record
     // arrays and the state ping-pong of the whole batch
     struct RollSub {
@@ -155,7 +157,7 @@ int fail(wbcqp_handle* h, int code, const std::string& msg)
     } while (0)
 
 int odd(int v) { return v | 1; }
-void set_lds(wbcqp_layout& L, int lds_bytes);
+void set_lds(wbcqp_layout& L, int lds_bytes, bool compact = false);
 
 // Validates a structure and derives sizes + LDS layout. Pure host code.
 int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout& L, std::string& why)
@@ -333,11 +335,15 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
     return true;
 }
 
-void set_lds(wbcqp_layout& L, int lds_bytes)
+void set_lds(wbcqp_layout& L, int lds_bytes, bool compact)
 {
     L.lds_bytes = lds_bytes;
     L.waves_per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 0;
-    if (L.waves_per_cu > 2) L.waves_per_cu = 2; // registers: the solve kernels allocate 256 VGPRs = two waves per SIMD = two workgroups per CU
+    // registers: the solve kernels allocate up to 256 VGPRs = two waves per SIMD = two workgroups per CU; the compact layout has a twin compiled
+    // for three (solve_queue3_kernel), taken when three workgroups fit the CU's LDS: measured (tools/ubench/lds_granule.hip) the third one fits
+    // up to 54 592 bytes of dynamic LDS beside the kernel's static word -- no coarser granule than 16 bytes (the launch asks the runtime itself)
+    const int cap = (compact && lds_bytes >= kQueueMinLds && lds_bytes <= kLdsThree) ? 3 : 2; // (below kQueueMinLds: solve_kernel, two per CU)
+    if (L.waves_per_cu > cap) L.waves_per_cu = cap;
 }
 
 template <typename T>
@@ -404,6 +410,9 @@ int check_io(wbcqp_handle* h, const Slot& s, int batch, const wbcqp_inputs* in, 
     return WBCQP_OK;
 }
 
+// which instantiations have a three-per-CU twin: the compact kernel, generic or of a stack that can ever fit (not Talos on two feet: 81 KB)
+template <bool CP, int SPEC> constexpr bool kThree = CP && SPEC != 1;
+
 template <typename TI, bool CP, int SPEC = 0>
 int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipStream_t stream)
 {
@@ -415,6 +424,9 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel<TI, CP, SPEC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        if constexpr (kThree<CP, SPEC>)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue3_kernel<TI, SPEC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         h->max_lds[V] = lds_bytes;
     }
     // schedule: the order left by the previous launch is used when it is of this very shape and was produced on this
@@ -457,6 +469,19 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         if (occ < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel: no workgroup fits a CU");
         h->queue_occ[V] = occ;
         h->queue_lds[V] = lds_bytes;
+        h->queue_three[V] = false;
+        // a workgroup small enough for three on a CU takes the kernel compiled for three waves per SIMD (wbcqp_device.hpp: solve_queue3_kernel);
+        // the runtime, not a formula, says whether three fit (LDS granule, the static word beside the dynamic block)
+        if constexpr (kThree<CP, SPEC>) {
+            if (lds_bytes * 3 <= 160 * 1024 && h->lds_pad == 0) {
+                int occ3 = 0;
+                HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, solve_queue3_kernel<TI, SPEC>, kThreads, (size_t)lds_bytes));
+                if (occ3 >= 3) {
+                    h->queue_three[V] = true;
+                    h->queue_occ[V] = occ3;
+                }
+            }
+        }
     }
     const int queue_occ = h->queue_occ[V];
     int* queue = nullptr;
@@ -469,8 +494,16 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     }
     if (queue) {
         const long long resident = (long long)queue_occ * h->n_cu;
-        hipLaunchKernelGGL((solve_queue_kernel<TI, CP, SPEC>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
-                           stream, tab, queue, total);
+        bool three = false;
+        if constexpr (kThree<CP, SPEC>) three = h->queue_three[V];
+        if constexpr (kThree<CP, SPEC>) {
+            if (three)
+                hipLaunchKernelGGL((solve_queue3_kernel<TI, SPEC>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
+                                   stream, tab, queue, total);
+        }
+        if (!three)
+            hipLaunchKernelGGL((solve_queue_kernel<TI, CP, SPEC>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
+                               stream, tab, queue, total);
     }
     else
         hipLaunchKernelGGL((solve_kernel<TI, CP, SPEC>), dim3(total), dim3(kThreads), lds_bytes, stream, tab);
@@ -565,7 +598,7 @@ int wbcqp_layout_of(const wbcqp_structure* st, wbcqp_layout* out)
     if (rc != WBCQP_OK) return fail(nullptr, rc, why);
     DevStruct C;
     if (derive_compact(D, C)) {
-        set_lds(L, C.lds_doubles * 8);
+        set_lds(L, C.lds_doubles * 8, true);
         L.specialised = spec_of(C);
     }
     // how a row of kSpecDims (wbcqp_types.hpp) is made: the derived sizes and offsets of a stack, in the order of struct Dims
@@ -722,7 +755,7 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     s.host_cp = DevStruct{};
     if (!(h->flags & WBCQP_FLAG_FULL_LDS) && derive_compact(D, s.host_cp)) {
         s.lds_cp = s.host_cp.lds_doubles * 8;
-        set_lds(L, s.lds_cp);
+        set_lds(L, s.lds_cp, true);
     }
     s.small = small_ok(D, HB);
     L.wave_per_qp = s.small ? 1 : 0;

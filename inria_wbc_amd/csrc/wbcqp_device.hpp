@@ -1046,6 +1046,43 @@ __global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<
 }
 
 // ------------------------------------------------------------------------------------------------
+// The queue kernel for stacks whose workgroup leaves room for a THIRD one on a CU (compact layout, LDS <= a third of the CU's 160 KB:
+// n <= ~52 today).  Same body, compiled for three waves per SIMD: 168 VGPRs, what does not fit goes to scratch (208-232 bytes per lane;
+// build.py admits scratch for this kernel only).  Measured before it was built in (tools/occ3_probe.py, profiles/r05/occ3_probe.txt:
+// iCub on one foot, n 50, B = 8192): two per CU without scratch 10.55 M QP/s; this build held at two per CU 9.59 M (the spills cost 9 %);
+// this build at three per CU 12.24 M (+16 %, same bits) -- the chains of a third QP fill the issue slots two leave idle.
+// ------------------------------------------------------------------------------------------------
+template <typename TI, int SPEC = 0>
+__global__ __launch_bounds__(kThreads, 3) void solve_queue3_kernel(const GroupTable<TI> tab, int* queue, const int total)
+{
+    extern __shared__ __align__(16) double lds[];
+    __shared__ int next_qp;
+    for (bool first = true;; first = false) {
+        if (threadIdx.x == 0) {
+            int pos = (int)blockIdx.x;
+            if (!first) {
+                const int c = atomicAdd(queue, 1);
+                pos = (int)gridDim.x + c;
+                if (c == total - 1) *queue = 0;
+            }
+            next_qp = pos < total ? (tab.order ? tab.order[pos] : pos) : -1;
+        }
+        bsync();
+        int b = uni(next_qp), gi = 0;
+        if (b < 0) break;
+        while (gi + 1 < tab.n && b >= tab.g[gi].count) {
+            b -= tab.g[gi].count;
+            ++gi;
+        }
+        const GroupArgs<TI>& ga = tab.g[gi];
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        solve_one_compact<TI, SPEC>(ga, ga.st, b, lds, tid);
+        bsync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Longest-first launch order.  A CU holds one QP at a time and the hardware hands out workgroups in index order, so a
 // QP with many active-set iterations that starts late ends the launch late (measured on 1024 Talos QPs: 1.15 M cycles
 // against 0.76 M for a perfect split; longest-first: 0.89 M).  The cost of a QP is setup + iterations x constant, and

@@ -310,17 +310,20 @@ def talos_structure(single_support: bool = False) -> Structure:
     return _mk("talos_single_support" if single_support else "talos", 50, 44, contacts, dense, None, sc, True, True, level0, kp)
 
 
-def icub_structure() -> Structure:
+def icub_structure(single_support: bool = False) -> Structure:
     """/root/reference/etc/icub/tasks.yaml: nv 38, na 32, two contacts (normal 0,0,-1), bounds but no
-    actuation bounds -> n 62, nEq 18, nIn 66 (132), 83 level-1 rows."""
+    actuation bounds -> n 62, nEq 18, nIn 66 (132), 83 level-1 rows.
+    single_support=True drops contact_lfoot the way WalkOnSpot does (walk_on_spot.cpp:165-184, as talos_structure above): n 50, nEq 12,
+    nIn 49, 77 level-1 rows -- the one humanoid stack whose workgroup is small enough (52.9 KB of LDS) for three on a CU."""
     pts = contact6d_points(lxn=0.06, lyn=0.045, lxp=0.14, lyp=0.045, lz=0.065)
-    contacts = [Contact("contact_lfoot", pts, (0.0, 0.0, -1.0), 0.3, 5.0, 1500.0),
-                Contact("contact_rfoot", pts, (0.0, 0.0, -1.0), 0.3, 5.0, 1500.0)]
-    dense = [("lh", 6, 1.0), ("rh", 6, 1.0), ("lf", 6, 1000.0), ("rf", 6, 10.0), ("com", 3, 3000.0), ("momentum", 2, 1000.0),
+    cl = Contact("contact_lfoot", pts, (0.0, 0.0, -1.0), 0.3, 5.0, 1500.0)
+    cr = Contact("contact_rfoot", pts, (0.0, 0.0, -1.0), 0.3, 5.0, 1500.0)
+    contacts = [cr] if single_support else [cl, cr]
+    dense = [("lh", 6, 1.0), ("rh", 6, 1.0), ("lf", 6, 1000.0), ("rf", 6, 10.0), ("com", 3, 3000.0), ("momentum", 2, 0.0 if single_support else 1000.0),
              ("__posture__", "posture", 0.05), ("torso", 3, 1.0), ("head", 5, 10.0), ("__contacts__",)]
     sc = [("self_collision-left", 500.0), ("self_collision-right", 500.0)]
-    level0 = [(INEQ_BOUNDS, 0), (INEQ_FORCE, 0), (INEQ_FORCE, 1)]
-    return _mk("icub", 38, 32, contacts, dense, None, sc, True, False, level0, {"com": 50.0, "posture": 10.0})
+    level0 = [(INEQ_BOUNDS, 0)] + [(INEQ_FORCE, c) for c in range(len(contacts))]
+    return _mk("icub_single_support" if single_support else "icub", 38, 32, contacts, dense, None, sc, True, False, level0, {"com": 50.0, "posture": 10.0})
 
 
 def franka_structure() -> Structure:
@@ -416,6 +419,7 @@ STRUCTURES = {
     "talos": talos_structure,
     "talos_single_support": lambda: talos_structure(single_support=True),
     "icub": icub_structure,
+    "icub_single_support": lambda: icub_structure(single_support=True),
     "franka": franka_structure,
     "tiago": tiago_structure,
     "three_contact": three_contact_structure,

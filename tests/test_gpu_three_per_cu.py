@@ -1,0 +1,71 @@
+"""Three workgroups per CU for a stack whose LDS leaves room for them (csrc/wbcqp_device.hpp: solve_queue3_kernel).  The
+compact queue kernel has a twin compiled for three waves per SIMD (168 VGPRs, the rest in scratch); the launch takes it when the runtime says
+three workgroups fit a CU.  iCub on one foot (n 50, nEq 12: 52.9 KB) is the humanoid stack that does; the shipped two-foot stacks do not (62 KB,
+81 KB).  What must hold: the layout reports it, and the results are the bits of the two-per-CU kernels (hardware dispatch: solve_kernel, 256
+VGPRs, no scratch) and within the parity bar of the oracle -- other registers, same arithmetic (controller.cpp:244-251 is the contract)."""
+import numpy as np
+import pytest
+
+from tests.util import TOL_F64
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(st, inputs, flags=0):
+    import torch
+    from inria_wbc_amd import capi
+    B = next(iter(inputs.values())).shape[0]
+    dev = torch.device("cuda", 0)
+    d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
+    h = capi.Handle(0, capi.F64, flags=flags)
+    h.set_structure(0, st)
+    d_out = dict(x=torch.full((B, st.n), float("nan"), dtype=torch.float64, device=dev), tau=torch.full((B, st.na), float("nan"), dtype=torch.float64, device=dev),
+                 status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.full((B,), -1, dtype=torch.int32, device=dev))
+    for _ in range(2):  # (the second launch runs in the longest-first order the first one left)
+        h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    h.close()
+    return {k: v.cpu().numpy() for k, v in d_out.items()}
+
+
+@pytest.mark.parametrize("noise", [0.5, 2.0])
+def test_three_per_cu_gives_the_bits_of_two_per_cu(oracle_mod, noise):
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.icub_structure(single_support=True)
+    B = 2304  # three rounds of 768 resident workgroups
+    inputs = synth.generate(st, B, synth.SEED_BASE["icub"] + 77, task_noise=noise)
+    three = _solve(st, inputs)                                # the queue: solve_queue3_kernel
+    two = _solve(st, inputs, capi.FLAG_HW_DISPATCH)           # solve_kernel, two per CU
+    two_idx = _solve(st, inputs, capi.FLAG_HW_DISPATCH | capi.FLAG_INDEX_ORDER)
+    assert (three["status"] == 0).all() and three["iters"].max() >= 6
+    for k in ("x", "tau", "status", "iters"):
+        assert np.array_equal(three[k], two[k]) and np.array_equal(three[k], two_idx[k]), k
+    sample = {k: v[:48] for k, v in inputs.items()}
+    ref = oracle_mod.tick_batch(st, sample)
+    assert np.array_equal(ref["status"], three["status"][:48])
+    scale = np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
+    assert (np.abs(three["x"][:48] - ref["x"]).max(axis=1) <= TOL_F64 * scale).all()
+
+
+def test_f32_boundary_takes_the_same_kernel_family():
+    """The f32 boundary (BASELINE config 3's dtype) has its own instantiations of the twin: it must run and agree with its two-per-CU form."""
+    import torch
+    from inria_wbc_amd import capi, structure, synth
+    st = structure.icub_structure(single_support=True)
+    B = 1024
+    inputs = synth.generate(st, B, synth.SEED_BASE["icub"] + 78, dtype=np.float32)
+    dev = torch.device("cuda", 0)
+    res = []
+    for flags in (0, capi.FLAG_HW_DISPATCH):
+        d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
+        h = capi.Handle(0, capi.F32, flags=flags)
+        h.set_structure(0, st)
+        o = dict(x=torch.zeros(B, st.n, dtype=torch.float32, device=dev), tau=torch.zeros(B, st.na, dtype=torch.float32, device=dev),
+                 status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+        h.solve_batch(0, B, d_in, o, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        h.close()
+        res.append({k: v.cpu().numpy() for k, v in o.items()})
+    assert (res[0]["status"] == 0).all()
+    for k in ("x", "tau", "status", "iters"):
+        assert np.array_equal(res[0][k], res[1][k]), k

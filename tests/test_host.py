@@ -229,3 +229,13 @@ def test_every_workgroup_barrier_in_the_sources_is_bsync():
             if re.search(r"__syncthreads\s*\(|__builtin_amdgcn_s_barrier\s*\(", code):
                 hits.append((fn, i))
     assert len(hits) == 1 and hits[0][0] == "wbcqp_prims.hpp", hits
+
+
+def test_layout_reports_three_only_where_three_fit():
+    """wbcqp_layout.waves_per_cu: three for the compact layout when three workgroups fit a CU's LDS (solve_queue3_kernel, tests/test_gpu_three_per_cu.py), else two."""
+    from inria_wbc_amd import capi, structure
+    one_foot = capi.layout_of(structure.icub_structure(single_support=True))
+    assert one_foot["n"] == 50 and one_foot["neq"] == 12 and one_foot["waves_per_cu"] == 3 and 3 * one_foot["lds_bytes"] <= 160 * 1024
+    for st in (structure.icub_structure(), structure.talos_structure(), structure.talos_structure(single_support=True)):
+        assert capi.layout_of(st)["waves_per_cu"] == 2
+    assert capi.layout_of(structure.franka_structure())["waves_per_cu"] == 2  # (below the queue's size: hardware dispatch of solve_kernel)
