@@ -286,7 +286,44 @@ def other_configs(local_rank, torch, parity=True):
     from tools import ragged_bench
     ns5 = argparse.Namespace(batch=8192, steps=30, no_parity=not parity)
     out["config5_ragged_b8192"] = ragged_bench.run(ns5)
+    out["icub_single_support_b4096_f32"] = three_per_cu(local_rank, torch)
     return out
+
+
+def three_per_cu(local_rank, torch):
+    """Config 3's robot on ONE foot (walk_on_spot's single-support stack: n 50, nEq 12), the humanoid stack whose workgroup leaves room for a
+    third one on a CU (52.9 KB of LDS): the queue takes solve_queue3_kernel for it (csrc/wbcqp_device.hpp).  Same batch through the two-per-CU
+    kernel (hardware dispatch) beside it, and whether the two gave the same bits."""
+    from inria_wbc_amd import capi, structure, synth
+    dev = torch.device("cuda", local_rank)
+    st = structure.icub_structure(single_support=True)
+    Bg, Bt = 1024, 4096
+    inp = synth.generate(st, Bg, synth.SEED_BASE["icub"] + 500_000)
+    base = {k: torch.from_numpy(np.ascontiguousarray(np.tile(v, (Bt // Bg, 1)).astype(np.float32))).to(dev) for k, v in inp.items() if v.size}
+    sp = torch.cuda.current_stream().cuda_stream
+    res, xs = {}, []
+    for name, flags in (("value", 0), ("two_per_cu_value", capi.FLAG_HW_DISPATCH)):
+        o = dict(x=torch.zeros(Bt, st.n, dtype=torch.float32, device=dev), tau=torch.zeros(Bt, st.na, dtype=torch.float32, device=dev),
+                 status=torch.full((Bt,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(Bt, dtype=torch.int32, device=dev))
+        h = capi.Handle(device=local_rank, dtype=capi.F32, flags=flags)
+        h.set_structure(0, st)
+        for _ in range(6):
+            h.solve_batch(0, Bt, base, o, stream=sp)
+        torch.cuda.synchronize()
+        nrep = 40
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            h.solve_batch(0, Bt, base, o, stream=sp)
+        torch.cuda.synchronize()
+        res[name] = Bt * nrep / (time.perf_counter() - t0)
+        xs.append(o["x"].cpu().numpy())
+        if not flags:
+            res["status_optimal"] = int((o["status"] == 0).sum().item())
+            res["iters_mean"] = float(o["iters"].float().mean().item())
+        h.close()
+    lay = capi.layout_of(st)
+    return {"workload": "icub_single_support_b4096_fp32_boundary", "unit": "QP/s", "waves_per_cu": lay["waves_per_cu"], "lds_bytes": lay["lds_bytes"],
+            "same_bits_as_two_per_cu": bool(np.array_equal(xs[0], xs[1])), **res}
 
 
 def warm_start(local_rank, torch, st, tick_dicts, new_out, B, cdt, base_flags, steps, inputs, b1_ticks, parity=True):

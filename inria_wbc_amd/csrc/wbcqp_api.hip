@@ -75,7 +75,8 @@ struct OrderState {
 };
 
 constexpr size_t kMaxQueues = 16;
-constexpr int kQueueMinLds = 48 * 1024; // workgroups at least this large take their QPs from the queue by default
+constexpr int kQueueMinLds = 40 * 1024; // workgroups at least this large take their QPs from the queue by default (40-54 KB: three per CU through
+                                        // solve_queue3_kernel; the dispatcher's solve_kernel holds two)
 constexpr int kLdsThree = 54592;        // the largest dynamic LDS block of which a CU holds three (tools/ubench/lds_granule.hip)
 constexpr int kOrderRefresh = 4; // default period of the launch-order renewal (WBCQP_FLAG_REFRESH)
 
@@ -304,28 +305,32 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
         return false;
     int o = 0;
     auto take = [&](int count) { int at = o; o += (count + 1) & ~1; return at; };
-    // rows of J: 16-byte aligned with at least one zero pad pair behind column n, and 2 x odd long -- sixteen rows then start in sixteen
+    // rows of J: 16-byte aligned, a zero pad pair behind column n, and 2 x odd long -- sixteen rows then start in sixteen
     // different bank groups for 8-byte and for 16-byte accesses alike
     {
         int l = ((n + 1) & ~1) + 2;
         while ((l & 3) != 2) l += 2;
+        // n itself is 2 x odd and there are equality columns to spare: the pad pair of a row is the next row's (dead, zeroed) columns 0-1 in the
+        // loop, two more doubles end the last row
+        if ((n & 3) == 2 && F.neq >= 2) l = n;
         D.ldj = l;
     }
     const int as_size = (F.n_dense * 66 + 8 + 1) & ~1;   // staged task rows: 64 columns + (w, b) pairs
-    int jsize = n * D.ldj;
+    int jsize = n * D.ldj + 2;
     if (as_size + 1024 > jsize) jsize = as_size + 1024;  // + the elimination's panels (2 x 2 x 256)
     D.o_pan = as_size;
     D.o_J = take(jsize);
     int rs = 512;                                        // packed R of the equalities (neq <= 22 columns)
-    if (F.neq > 0 && 256 + (n + 4) * F.ldb + 8 > rs) rs = 256 + (n + 4) * F.ldb + 8; // N = CE', then B = J0'N
+    if (F.neq > 0 && (n + 4) * F.ldb + 8 > rs) rs = (n + 4) * F.ldb + 8; // N = CE', then B = J0'N (from the region's start: the packed R follows it in time)
     {   // the inequality loop: Ri (row-packed, n - neq rows, one spare element per row, 64 doubles of over-read behind it), four doubles per
-        // rotation of a drop, the friction rows' table
+        // rotation of a drop, the friction rows' table (one sign)
         const int mmax = n - F.neq;
-        const int need = ((2 + mmax * (mmax + 3) / 2 + 64 + 1) & ~1) + 4 * (mmax + 2) + F.nc * 34 * 12 + 2;
+        const int fric = cp::fric_in_j(n, F.neq, F.nc) ? 0 : F.nc * 17 * 12; // (with fourteen equalities the table lives in J's dead columns: wbcqp_compact.hpp)
+        const int need = ((2 + mmax * (mmax + 3) / 2 + 64 + 1) & ~1) + 4 * (mmax + 2) + fric + 2;
         if (need > rs) rs = need;
     }
     D.o_R = take(rs);
-    D.o_vec = take(cp::COUNT);
+    D.o_vec = take(cp::vec_map(n, nv, F.act_bounds).COUNT);
     D.o_int = o;
     o += cp::ICOUNT / 2;
     D.o_M = D.o_Jc = D.o_Ac = D.o_eqw = D.o_eqt = 0;

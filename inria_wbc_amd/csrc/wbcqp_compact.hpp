@@ -11,7 +11,7 @@
 //     from the record's registers straight into N; the actuation rows [M_a | -J_a'] (44 x 74 for Talos, constant for the
 //     whole loop) are re-read from the L2-resident record once and then live in REGISTERS, four lanes per row, where
 //     act_rows() used to read them from LDS in every iteration;
-//   * vectors in 80-entry slots (n <= 80) with the dead ones aliased; iai / iaexcl as bytes.
+//   * vectors in 80-entry slots (64 where the stack fits them: cp::vec_map) with the dead ones aliased; iai / iaexcl as bytes.
 // Talos: 81.2 KB, iCub 60 KB.  Eligibility (host, derive_compact): n <= 80, neq <= 22, nv <= 52, nc <= 2, nu <= 8,
 // nin2 <= 256, r1 <= 128, n_tasks <= 64 -- every stack the reference ships.  Anything else runs solve_one.
 //
@@ -34,14 +34,31 @@ namespace wbcqp {
 #ifdef __HIPCC__
 
 namespace cp {
-// vector region (doubles, compile-time offsets from one base: immediates, not pointers in SGPRs)
-constexpr int X = 0, NP = 80, D = 160, Z = 240, XOLD = 320, R = 400, U = 480 /* n + 2 <= 88 */, UOLD = 568, RDINV = 648,
-              PART = 728, TACT = 808 /* 64 */, S = 872 /* 256 */, BLB = 1128, BUB = 1192, TL = 1256, TU = 1320, RED = 1384 /* 32 */,
-              CE0 = 1416 /* 24 */, COUNT = 1440;
-// dead-time aliases: g and 1/sqrt(pivot) die with x0, the weights with the force blocks, b1 with the assembly.  The S slot (b1, the force
-// blocks' panels, the equality QR's reflector) is free in the inequality loop: the pending update's w, d of the active positions and the
-// block-reduction scratch of the loop's rare paths live there; the loop's own slots (lp::) take RED and CE0.
-constexpr int G = XOLD, DINV = UOLD, W = R, B1 = S, PRM = D, PW = S, DI = S + 80 /* 128 */, LRED = S + 208 /* 32 */, EL = S + 240 /* 8 */;
+// vector region (doubles from one base; the offsets are literals in a shipped stack's instantiation, a few scalar operations in the generic kernel).
+// Slots of VS entries: 80, or 64 for the stacks that fit them (n <= 62, and act_dot's unconditional reads -- x and z up to entry nv + 23 -- stay
+// inside the slot); U has n + 2 entries (VS + 8).  The two slots only a stack WITH actuation bounds uses come last and are left out without them.
+struct VecMap {
+    int X, NP, D, Z, XOLD, R, U, UOLD, RDINV, PART, TACT /* 64 */, S /* 256 */, BLB, BUB, RED /* 32 */, CE0 /* 24 */, TL, TU, COUNT, VS;
+    // dead-time aliases: g and 1/sqrt(pivot) die with x0, the weights with the force blocks, b1 with the assembly.  The S slot (b1, the force
+    // blocks' panels, the equality QR's reflector) is free in the inequality loop: the pending update's w, d of the active positions and the
+    // block-reduction scratch of the loop's rare paths live there; the loop's own slots (lp::) take RED and CE0 (adjacent).
+    int G, DINV, W, B1, PRM, PW, DI /* 128 */, LRED /* 32 */, EL /* 8 */;
+};
+// the friction table in J's dead equality columns 2..13 of rows 0 .. 17 nc - 1 (wbcqp_compact.hpp, phase 4) instead of the R region
+__host__ __device__ constexpr bool fric_in_j(int n, int neq, int nc) { return neq >= 14 && n >= 17 * nc; }
+__host__ __device__ constexpr int vec_stride(int n, int nv) { return (n <= 62 && nv + 24 <= 64) ? 64 : 80; }
+__host__ __device__ constexpr VecMap vec_map(int n, int nv, int act_bounds)
+{
+    VecMap m{};
+    const int VS = vec_stride(n, nv);
+    m.VS = VS;
+    m.X = 0; m.NP = VS; m.D = 2 * VS; m.Z = 3 * VS; m.XOLD = 4 * VS; m.R = 5 * VS; m.U = 6 * VS; m.UOLD = 7 * VS + 8; m.RDINV = 8 * VS + 8;
+    m.PART = 9 * VS + 8; m.TACT = 10 * VS + 8; m.S = m.TACT + 64; m.BLB = m.S + 256; m.BUB = m.BLB + 64; m.RED = m.BUB + 64; m.CE0 = m.RED + 32;
+    m.TL = m.CE0 + 24; m.TU = m.TL + 64;
+    m.COUNT = act_bounds ? m.TU + 64 : m.TL;
+    m.G = m.XOLD; m.DINV = m.UOLD; m.W = m.R; m.B1 = m.S; m.PRM = m.D; m.PW = m.S; m.DI = m.S + 80; m.LRED = m.S + 208; m.EL = m.S + 240;
+    return m;
+}
 // int region (ints)
 constexpr int IA = 0 /* n + 2 <= 84 */, IAOLD = 84, IACT = 164 /* 256 bytes */, IEXCL = 228, ICOUNT = 292;
 constexpr int NVQ = 13; // ceil(52 / 4): M_a coefficients per lane of a row's quad
@@ -57,7 +74,7 @@ struct ActRegs {
 // One actuation row of tau' = M_a xn - J_a' fn with xn = xp + t zp formed on the fly (t = 0: xn = xp exactly): four lanes per
 // row (act_rows()' layout), every lane of the quad returns the row's total.  Every read is base + immediate from ONE
 // per-lane address: coefficients past nv / k are zero and what they multiply is finite -- the x and z slots are zero from
-// n to their end (set once per QP) and nv + 23 < 80.
+// n to their end (set once per QP) and nv + 23 < the slot's length (cp::vec_stride).
 __device__ __forceinline__ double act_dot(const Ctx& c, const ActRegs& a, const double* xp, const double* zp, double t)
 {
     const int nv = c.nv, q4 = c.tid & 3;
@@ -221,13 +238,13 @@ __device__ __forceinline__ void rotate_row(const double* prm, const double* dcur
 
 // ---- the compact kernel's inequality loop (solve_one_compact, phase 4): its slots and the helpers of its row-packed inverse
 namespace lp {
-// slots in the RED + CE0 area (doubles from cp::RED; `I` entries are int indices into the same area).  Every field has ONE writing phase, and
+// slots in the RED + CE0 area (doubles from VecMap::RED; `I` entries are int indices into the same area).  Every field has ONE writing phase, and
 // at least one barrier lies between its readers and the next write -- no double buffering.  The phase-B / drop fields sit where the set-up's
 // block reductions had their slots (first written two barriers into the loop); the pick's fields, which are written before the loop's first
 // barrier, in CE0 (y of the equality phase: read for the last time before the set-up's final barrier).
 constexpr int BZF = 0 /* 3 ints (doubles 0, 1): a wave's rows hold a z_k^2 > eps */, BDN2 = 2, BALPHA = 3, BV0 = 4, BTAU = 5, BT2C = 6, NPW = 7, DDELTA = 8, DCL = 9,
               DRHO0 = 10;
-// election slots (doubles from cp::EL; `u` entries index the same area as unsigned): two generations of the pick's (minimum, word), the same for
+// election slots (doubles from VecMap::EL; `u` entries index the same area as unsigned): two generations of the pick's (minimum, word), the same for
 // the warm start's hinted rows, one of the step length's (minimum, position)
 constexpr int EMIN = 0 /* 2 */, EKEY = 2 * 2 /* 2 u */, EWMIN = 3 /* 2 */, EWKEY = 2 * 5 /* 2 u */, ET1 = 6, ET1POS = 2 * 7 /* u */;
 constexpr double kNone = 1e300; // "nobody stood": any candidate (s < 0) is below it
@@ -263,7 +280,7 @@ __device__ __forceinline__ void rotate_row_ps(const double* prm, int L, double& 
 struct OwnRow {
     int meta;        // -1: none
     double ci0;
-    const double* coef; // friction rows only: the row's 12 coefficients (sign folded in) in the LDS table, else null
+    const double* coef; // friction rows only: the 12 coefficients of the row (of its positive twin) in the LDS table, else null
 };
 
 template <int SPEC> __device__ __forceinline__ Dims dims_of(const DevStruct& S)
@@ -286,6 +303,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     for (int i = tid; i < S.lds_doubles; i += kThreads) lds[i] = __longlong_as_double(WBCQP_POISON_LDS);
     bsync();
 #endif
+    const cp::VecMap vm = cp::vec_map(D.n, D.nv, D.act_bounds);
+    const int VS = vm.VS;
     Ctx c;
     c.S = &S;
     c.tid = tid;
@@ -300,14 +319,14 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     c.eqw = nullptr; c.eqt = nullptr; c.bc = nullptr; c.iai = nullptr; c.iaexcl = nullptr;
     {
         double* vec = lds + D.o_vec;
-        c.x = vec + cp::X; c.np = vec + cp::NP; c.d = vec + cp::D; c.z = vec + cp::Z; c.xold = vec + cp::XOLD;
-        c.r = vec + cp::R; c.u = vec + cp::U; c.uold = vec + cp::UOLD; c.rdinv = vec + cp::RDINV; c.part = vec + cp::PART;
-        c.s = vec + cp::S; c.blb = vec + cp::BLB; c.bub = vec + cp::BUB; c.tl = vec + cp::TL; c.tu = vec + cp::TU;
-        c.red = vec + cp::RED; c.g = vec + cp::G; c.dinv = vec + cp::DINV; c.w = vec + cp::W; c.b1 = vec + cp::B1;
-        c.prm = vec + cp::PRM;
+        c.x = vec + vm.X; c.np = vec + vm.NP; c.d = vec + vm.D; c.z = vec + vm.Z; c.xold = vec + vm.XOLD;
+        c.r = vec + vm.R; c.u = vec + vm.U; c.uold = vec + vm.UOLD; c.rdinv = vec + vm.RDINV; c.part = vec + vm.PART;
+        c.s = vec + vm.S; c.blb = vec + vm.BLB; c.bub = vec + vm.BUB; c.tl = vec + vm.TL; c.tu = vec + vm.TU; // (tl, tu: only with actuation bounds)
+        c.red = vec + vm.RED; c.g = vec + vm.G; c.dinv = vec + vm.DINV; c.w = vec + vm.W; c.b1 = vec + vm.B1;
+        c.prm = vec + vm.PRM;
     }
-    double* const tact = lds + D.o_vec + cp::TACT;
-    double* const ce0v = lds + D.o_vec + cp::CE0; // ce0 of the equalities, then rhs, then y
+    double* const tact = lds + D.o_vec + vm.TACT;
+    double* const ce0v = lds + D.o_vec + vm.CE0; // ce0 of the equalities, then rhs, then y
     int* ia = reinterpret_cast<int*>(lds + D.o_int);
     c.A = ia + cp::IA; c.Aold = ia + cp::IAOLD; c.gskip = nullptr; c.meta = nullptr;
     signed char* const act = reinterpret_cast<signed char*>(ia + cp::IACT);   // 1: row is in the active set (iai == -1)
@@ -323,7 +342,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     double* const As = c.J;                  // dense task rows are staged in the J region (J appears after the elimination)
     double* const RB = c.J + D.o_pan;        // the elimination's panels, behind the staged rows
     double* const YB = RB + 512;
-    double* const Nm = c.R + 256;            // N = CE' (n x ldb), then B = J0'N: tail of the R region
+    double* const Nm = c.R;                  // N = CE' (n x ldb), then B = J0'N: the R region (the packed R replaces it when the QR has B in registers)
     const int lenM = nv * (nv + 1) / 2, lenA = n_dense * nv, lenAc = nc * 6 * nv;
     const TI* const pM = ga.M + qr * lenM;
     const TI* const pAc = ga.Ac + qr * (size_t)lenAc;
@@ -448,7 +467,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             c.z[tid] = 0.0;
             c.d[tid] = 0.0;
         }
-        if (tid >= n && tid < 80) { // finite padding for act_dot's unconditional reads; never written again
+        if (tid >= n && tid < VS) { // finite padding for act_dot's unconditional reads; never written again
             c.z[tid] = 0.0;
             c.x[tid] = 0.0;
         }
@@ -567,7 +586,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         eliminate_block<4, 4, false, 0>(c, h, y, ta, te, opaque_uniform((nv + 3) & ~3) /* not a constant for the unroller (a specialised build would lay out thirteen panel bodies: 256 VGPRs + 256 AGPRs + scratch) */, RB, YB, c.dinv, tid >= 128 && tid < 132, tid & 3);
         STAMP(2)
         bsync(); // staged rows and panels are dead: the region becomes J
-        for (int e = tid; e < n * ldj; e += kThreads) c.J[e] = 0.0;
+        for (int e = tid; e < n * ldj + 2; e += kThreads) c.J[e] = 0.0; // (+ 2: the last row's pad pair when the rows are exactly n long, derive_compact)
         // ---- force blocks: wave-local (8 x 8 lane grid, 2 x 2 positions per lane), one contact per wave (nc <= 2), panels
         //      in the (idle) s slot
         const int fb = nv + 12 * c.wave;
@@ -677,9 +696,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             act[tid] = 0;
             excl[tid] = 1;
         }
-        if (tid >= n && tid < 80) c.xold[tid] = 0.0; // the second x buffer gets the same finite padding as the first (g, its tenant so far, ends at n)
+        if (tid >= n && tid < VS) c.xold[tid] = 0.0; // the second x buffer gets the same finite padding as the first (g, its tenant so far, ends at n)
         if (tid == 0) { // the loop's election slots (lp::E*), both generations armed
-            double* EL0 = lds + D.o_vec + cp::EL;
+            double* EL0 = lds + D.o_vec + vm.EL;
             unsigned* EL0u = reinterpret_cast<unsigned*>(EL0);
             EL0[lp::EMIN] = lp::kNone; EL0[lp::EMIN + 1] = lp::kNone; EL0[lp::EWMIN] = lp::kNone; EL0[lp::EWMIN + 1] = lp::kNone;
             EL0u[lp::EKEY] = 0xffffffffu; EL0u[lp::EKEY + 1] = 0xffffffffu; EL0u[lp::EWKEY] = 0xffffffffu; EL0u[lp::EWKEY + 1] = 0xffffffffu;
@@ -838,27 +857,40 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     const bool act_ineq = D.act_bounds && na > 0; // actuation rows are inequality rows (otherwise tau' is only decoded)
     if (status == -2 && nin2 > 0) {
         const int MM = n - neq;                       // the most inequality constraints that can be active (<= 64, host check)
-        const int ne = (n + 1) & ~1;                  // first pad pair of a row of J, of V and of the pending v (ldj >= ne + 2; zero for good)
+        const int ne = (n + 1) & ~1;                  // first pad pair of a row of J (ldj >= ne + 2, or the next row's dead columns 0-1), of V and of the pending v: zero for good
         double* const Ri = c.R + 2;                   // inverse of R's inequality block, ROW-packed: (i, j), i <= j, at rio(i) + j - i (R is dead);
                                                       // one zero in front of it: what a row's rotation reads left of its diagonal
         const int ri_size = lp::rio(MM, MM);
         double* const prm = c.R + ((2 + ri_size + 64 + 1) & ~1);  // drop: 4 doubles per rotation (a_l, b_l, rho_{l+1}, -), behind Ri's over-read pad
-        double* const fct = prm + 4 * (MM + 2);       // friction rows: 12 coefficients per one-sided row, sign folded in
-        double* const Wp = lds + D.o_vec + cp::PW;    // pending update: J(:, pc:) <- J(:, pc:) - w v(pc:)'; w = 0 when there is none
-        double* const dI = lds + D.o_vec + cp::DI;    // d at the active inequality positions, zero from mi on (read up to 2 x 64)
-        double* const LS = lds + D.o_vec + cp::RED;   // the loop's slots (lp::)
+        // friction rows: the 12 coefficients of row pair e = 17 ct + rr (one sign kept: the other is folded into the use -- negation commutes with every
+        // rounding) at fct + e fst.  With fourteen or more equalities they sit in J itself: columns 2..13 of row e, equality columns the loop never
+        // reads (columns 0-1 may be the pad pair of the row before); otherwise behind the rotation table in the R region.
+        const bool fric_in_J = cp::fric_in_j(n, neq, nc);
+        double* const fct = fric_in_J ? c.J + 2 : prm + 4 * (MM + 2);
+        const int fst = fric_in_J ? ldj : 12;
+        double* const Wp = lds + D.o_vec + vm.PW;    // pending update: J(:, pc:) <- J(:, pc:) - w v(pc:)'; w = 0 when there is none
+        double* const dI = lds + D.o_vec + vm.DI;    // d at the active inequality positions, zero from mi on (read up to 2 x 64)
+        double* const LS = lds + D.o_vec + vm.RED;   // the loop's slots (lp::)
         int* const LSi = reinterpret_cast<int*>(LS);
-        double* const EL = lds + D.o_vec + cp::EL;    // election slots (lp::E*; initialised ahead of the equality phase)
+        double* const EL = lds + D.o_vec + vm.EL;    // election slots (lp::E*; initialised ahead of the equality phase)
         unsigned* const ELu = reinterpret_cast<unsigned*>(EL);
-        double* const dbuf0 = lds + D.o_vec + cp::D;      // V of the current pick in one, the pending v in the other
-        double* const dbuf1 = lds + D.o_vec + cp::RDINV;  // (1/R(j,j) of the equality phase is dead by now)
-        c.red = lds + D.o_vec + cp::LRED;             // block_sum of the rare paths (the set-up's slot is part of LS now)
+        double* const dbuf0 = lds + D.o_vec + vm.D;      // V of the current pick in one, the pending v in the other
+        double* const dbuf1 = lds + D.o_vec + vm.RDINV;  // (1/R(j,j) of the equality phase is dead by now)
+        c.red = lds + D.o_vec + vm.LRED;             // block_sum of the rare paths (the set-up's slot is part of LS now)
         c.rslot = 0;
         // ---- loop-time arrays start from zero (every region here was last read behind the equality phase's final barrier)
+        // Rows of J exactly n long (derive_compact: n = 2 mod 4, neq >= 2): the zero pad pair the 16-byte row passes need behind column n is the
+        // NEXT row's first two columns -- equality columns, which the loop never reads (x = x0 + J1 y was their last use) -- zeroed here.
+        if (ldj == n && tid < n) {
+            double2v zz;
+            zz.x = 0.0;
+            zz.y = 0.0;
+            *reinterpret_cast<double2v*>(__builtin_assume_aligned(c.J + tid * ldj, 16)) = zz;
+        }
         for (int e = tid; e < ri_size + 64 + 2; e += kThreads) c.R[e] = 0.0;
         if (tid < 128) dI[tid] = 0.0;
-        if (tid < 80) {
-            Wp[tid] = 0.0;
+        if (tid < 80) Wp[tid] = 0.0;
+        if (tid < VS) {
             dbuf0[tid] = 0.0;
             dbuf1[tid] = 0.0;
         }
@@ -879,12 +911,14 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     own.meta = mt;
                     own.ci0 = neg ? S.fric_ub[ct * 17 + rr] : -S.fric_lb[ct * 17 + rr];
                     const double* B = S.fric_mat + (ct * 17 + rr) * 12;
-                    double* dst = fct + ((2 * ct + (neg ? 1 : 0)) * 17 + rr) * 12;
+                    double* dst = fct + (ct * 17 + rr) * fst;
+                    // (every friction row comes with its negation, [A; -A]: both twins store the same twelve values, so each reads what it wrote
+                    // itself in the first evaluation below -- no barrier needed between here and there)
                     double bv[12];
 #pragma unroll
                     for (int m = 0; m < 12; ++m) bv[m] = B[m];
 #pragma unroll
-                    for (int m = 0; m < 12; ++m) dst[m] = neg ? -bv[m] : bv[m];
+                    for (int m = 0; m < 12; ++m) dst[m] = bv[m];
                     own.coef = dst;
                 }
             }
@@ -969,7 +1003,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     double a = 0.0;
 #pragma unroll
                     for (int m = 0; m < 12; ++m) a = fma(own.coef[m], fma(t, zf[m], f[m]), a); // (coef: LDS)
-                    v = a;
+                    v = neg ? -a : a;
                 }
                 v += own.ci0;
                 s_own = v;
@@ -1008,7 +1042,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         a = fma(own.coef[m], zf[m], a);
                         b2 = fma(own.coef[m + 1], zf[m + 1], b2);
                     }
-                    dz = a + b2;
+                    dz = neg ? -(a + b2) : (a + b2);
                 }
                 const double v = fma(t, dz, s_own);
                 s_own = v;
@@ -1147,7 +1181,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 const int jq = tid >> 2, q4 = tid & 3;
                 const int j = neq + min(jq, MM - 1);
                 const int k0 = nv + 12 * ct + 3 * q4;
-                const double* F = fct + ((2 * ct + (negrow ? 1 : 0)) * 17 + rr) * 12 + 3 * q4;
+                const double* F = fct + (17 * ct + rr) * fst + 3 * q4;
                 const double* Jb = c.J + k0 * ldj + j;
                 const double* wb = Wp + k0;
                 const double f0 = F[0], f1 = F[1], f2 = F[2];
@@ -1158,7 +1192,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 double fw = fma(f2, w2, fma(f1, w1, f0 * w0));
                 a = quad_sum(a);
                 fw = quad_sum(fw);
-                const double dj = fma(-fw, vj, a);
+                const double dj = sg * fma(-fw, vj, a); // (the table holds the positive row)
                 if (q4 == 0 && jq < MM) {
                     Vn[j] = (j >= iq0) ? dj : 0.0;
                     dI[jq] = (j < iq0) ? dj : 0.0;

@@ -1,8 +1,9 @@
 """Three workgroups per CU for a stack whose LDS leaves room for them (csrc/wbcqp_device.hpp: solve_queue3_kernel).  The
 compact queue kernel has a twin compiled for three waves per SIMD (168 VGPRs, the rest in scratch); the launch takes it when the runtime says
-three workgroups fit a CU.  iCub on one foot (n 50, nEq 12: 52.9 KB) is the humanoid stack that does; the shipped two-foot stacks do not (62 KB,
-81 KB).  What must hold: the layout reports it, and the results are the bits of the two-per-CU kernels (hardware dispatch: solve_kernel, 256
-VGPRs, no scratch) and within the parity bar of the oracle -- other registers, same arithmetic (controller.cpp:244-251 is the contract)."""
+three workgroups fit a CU: iCub -- BASELINE config 3's stack, 52.8 KB since its rows of J are exactly n long and its friction table lives in J's
+dead equality columns -- and iCub on one foot (48.9 KB); Talos (72 KB) and Talos on one foot (57.9 KB) do not.  What must hold: the layout reports
+it (tests/test_host.py), and the results are the bits of the two-per-CU kernels (hardware dispatch: solve_kernel, up to 256 VGPRs, no scratch)
+and within the parity bar of the oracle -- other registers, same arithmetic (controller.cpp:244-251 is the contract)."""
 import numpy as np
 import pytest
 
@@ -28,18 +29,21 @@ def _solve(st, inputs, flags=0):
     return {k: v.cpu().numpy() for k, v in d_out.items()}
 
 
+@pytest.mark.parametrize("single_support", [False, True])
 @pytest.mark.parametrize("noise", [0.5, 2.0])
-def test_three_per_cu_gives_the_bits_of_two_per_cu(oracle_mod, noise):
+def test_three_per_cu_gives_the_bits_of_two_per_cu(oracle_mod, noise, single_support):
     from inria_wbc_amd import capi, structure, synth
-    st = structure.icub_structure(single_support=True)
+    st = structure.icub_structure(single_support=single_support)
+    assert capi.layout_of(st)["waves_per_cu"] == 3
     B = 2304  # three rounds of 768 resident workgroups
     inputs = synth.generate(st, B, synth.SEED_BASE["icub"] + 77, task_noise=noise)
-    three = _solve(st, inputs)                                # the queue: solve_queue3_kernel
+    three = _solve(st, inputs)                                # the queue: solve_queue3_kernel (the stack's own instantiation for iCub on two feet)
     two = _solve(st, inputs, capi.FLAG_HW_DISPATCH)           # solve_kernel, two per CU
     two_idx = _solve(st, inputs, capi.FLAG_HW_DISPATCH | capi.FLAG_INDEX_ORDER)
+    gen = _solve(st, inputs, capi.FLAG_GENERIC_KERNEL)        # the generic twin
     assert (three["status"] == 0).all() and three["iters"].max() >= 6
     for k in ("x", "tau", "status", "iters"):
-        assert np.array_equal(three[k], two[k]) and np.array_equal(three[k], two_idx[k]), k
+        assert np.array_equal(three[k], two[k]) and np.array_equal(three[k], two_idx[k]) and np.array_equal(three[k], gen[k]), k
     sample = {k: v[:48] for k, v in inputs.items()}
     ref = oracle_mod.tick_batch(st, sample)
     assert np.array_equal(ref["status"], three["status"][:48])
@@ -51,7 +55,7 @@ def test_f32_boundary_takes_the_same_kernel_family():
     """The f32 boundary (BASELINE config 3's dtype) has its own instantiations of the twin: it must run and agree with its two-per-CU form."""
     import torch
     from inria_wbc_amd import capi, structure, synth
-    st = structure.icub_structure(single_support=True)
+    st = structure.icub_structure()
     B = 1024
     inputs = synth.generate(st, B, synth.SEED_BASE["icub"] + 78, dtype=np.float32)
     dev = torch.device("cuda", 0)

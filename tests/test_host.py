@@ -236,6 +236,8 @@ def test_layout_reports_three_only_where_three_fit():
     from inria_wbc_amd import capi, structure
     one_foot = capi.layout_of(structure.icub_structure(single_support=True))
     assert one_foot["n"] == 50 and one_foot["neq"] == 12 and one_foot["waves_per_cu"] == 3 and 3 * one_foot["lds_bytes"] <= 160 * 1024
-    for st in (structure.icub_structure(), structure.talos_structure(), structure.talos_structure(single_support=True)):
+    two_feet = capi.layout_of(structure.icub_structure())  # BASELINE config 3's stack: 52.8 KB since its rows of J are n long and the friction table lives in them
+    assert two_feet["n"] == 62 and two_feet["waves_per_cu"] == 3 and two_feet["specialised"] == 2 and 3 * two_feet["lds_bytes"] <= 160 * 1024
+    for st in (structure.talos_structure(), structure.talos_structure(single_support=True)):
         assert capi.layout_of(st)["waves_per_cu"] == 2
     assert capi.layout_of(structure.franka_structure())["waves_per_cu"] == 2  # (below the queue's size: hardware dispatch of solve_kernel)
