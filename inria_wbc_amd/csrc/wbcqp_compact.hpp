@@ -496,16 +496,20 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     STAMP(0)
 
     // ---------------- phases 1-2b in registers: H assembly, Cholesky H = U'U, J = U^-1 (as solve_one) ----------------
+    // A thread of the 16 x 16 grid owns positions (ta + 16 u, te + 16 w), u <= w < NU, of the dv block: NU = 4 covers nv <= 64; a shipped stack
+    // with nv <= 48 (iCub: 38) is instantiated with NU = 3 -- nine tile elements instead of sixteen in the assembly, the elimination and J = U^-1,
+    // the same operations on every element that exists (the positions left out are the identity padding past nv): same bits, 28 registers fewer.
+    constexpr int NU = (SPEC > 0 && kSpecDims[SPEC > 0 ? SPEC - 1 : 0].nv <= 48) ? 3 : 4;
     double c1, c2;
     {
         const int ta = tid >> 4, te = tid & 15;
-        double h[4][4];
+        double h[NU][NU];
         double trace = 0.0;
         {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NU; ++u)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) h[u][w] = 0.0;
+                for (int w = 0; w < NU; ++w) h[u][w] = 0.0;
             double gacc[4] = {0.0, 0.0, 0.0, 0.0};
             const double* Ai = As + ta * 2; // (layout of a staged row: wbcqp_types.hpp, apack)
             const double* Aj = As + te * 2;
@@ -521,11 +525,11 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 const double a[4] = {ai[0].x, ai[0].y, ai[1].x, ai[1].y};
                 const double ajw[4] = {aj[0].x * wb.x, aj[0].y * wb.x, aj[1].x * wb.x, aj[1].y * wb.x};
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < NU; ++u)
 #pragma unroll
-                    for (int w = u; w < 4; ++w) h[u][w] = fma(a[u], ajw[w], h[u][w]);
+                    for (int w = u; w < NU; ++w) h[u][w] = fma(a[u], ajw[w], h[u][w]);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) gacc[w] = fma(ajw[w], wb.y, gacc[w]);
+                for (int w = 0; w < NU; ++w) gacc[w] = fma(ajw[w], wb.y, gacc[w]);
             };
             if (n_dense > 0) {
                 const int nd = opaque_uniform(n_dense); // (a literal in the specialised builds: as a loop bound it would unroll forty row bodies)
@@ -542,14 +546,14 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             }
             if (ta == 0) {
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < NU; ++w) {
                     const int col = te + 16 * w;
                     if (col < nv) c.g[col] = -gacc[w] - c.d[col];
                 }
             }
             if (ta == te) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < NU; ++u) {
                     const int i = ta + 16 * u;
                     if (i < nv) {
                         h[u][u] += c.z[i] + S.hessian_reg;
@@ -560,17 +564,17 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         }
         STAMP(1)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int w = u; w < 4; ++w) {
+            for (int w = u; w < NU; ++w) {
                 const int r = ta + 16 * u, q = te + 16 * w;
                 if (r >= nv || q >= nv) h[u][w] = (r == q) ? 1.0 : 0.0;
             }
-        double y[4][4];
+        double y[NU][NU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) y[u][w] = 0.0;
+            for (int w = 0; w < NU; ++w) y[u][w] = 0.0;
         const int la = c.lane >> 3, le = c.lane & 7;
         double hF[2][2], yF[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
         {
@@ -582,8 +586,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 for (int w = 0; w < 2; ++w) hF[u][w] = (nc > 0) ? ftf[min(la + 8 * u, 11) * 12 + min(le + 8 * w, 11)] : 0.0;
         }
         // the panels lie behind the staged rows: a fast thread may publish while a slow one still reads its last task row
-        publish_panel<4, 4, false, 0>(c, h, y, ta, te, 0, RB, YB);
-        eliminate_block<4, 4, false, 0>(c, h, y, ta, te, opaque_uniform((nv + 3) & ~3) /* not a constant for the unroller (a specialised build would lay out thirteen panel bodies: 256 VGPRs + 256 AGPRs + scratch) */, RB, YB, c.dinv, tid >= 128 && tid < 132, tid & 3);
+        publish_panel<4, NU, false, 0>(c, h, y, ta, te, 0, RB, YB);
+        eliminate_block<4, NU, false, 0>(c, h, y, ta, te, opaque_uniform((nv + 3) & ~3) /* not a constant for the unroller (a specialised build would lay out thirteen panel bodies: 256 VGPRs + 256 AGPRs + scratch) */, RB, YB, c.dinv, tid >= 128 && tid < 132, tid & 3);
         STAMP(2)
         bsync(); // staged rows and panels are dead: the region becomes J
         for (int e = tid; e < n * ldj + 2; e += kThreads) c.J[e] = 0.0; // (+ 2: the last row's pad pair when the rows are exactly n long, derive_compact)
@@ -624,9 +628,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         }
         // final: J(r,q) = Y(r,q) dinv[q], J(r,r) = dinv[r]
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int w = u; w < 4; ++w) {
+            for (int w = u; w < NU; ++w) {
                 const int r = ta + 16 * u, q = te + 16 * w;
                 if (q < nv && r < q) c.J[r * ldj + q] = y[u][w] * c.dinv[q];
                 else if (r == q && r < nv) c.J[r * ldj + r] = c.dinv[r];
