@@ -144,7 +144,8 @@ typedef struct {
     /* element counts of the per-QP input arrays below */
     int32_t len_M, len_h, len_A, len_b1, len_Ac, len_bc, len_blb, len_bub, len_tlb, len_tub, len_w;
     int32_t lds_bytes;         /* dynamic LDS one QP (one 256-thread workgroup) needs */
-    int32_t waves_per_cu;      /* resident QPs (workgroups) per CU that LDS admits */
+    int32_t waves_per_cu;      /* resident QPs (workgroups) per CU: 1 (full layout), 2 (compact layout: the kernels' registers admit two), or 3 --
+                                  compact layout with lds_bytes <= 54592: such launches take the queue kernel compiled for three waves per SIMD */
     int64_t algorithmic_bytes; /* compact in+out bytes per QP at WBCQP_F64 */
     int32_t wave_per_qp;       /* 1: the structure runs one WAVEFRONT per QP (n <= 16, fixed base, no contacts, bounds only: Franka, Tiago),
                                   four QPs per workgroup, 7.7 KB of LDS per QP; lds_bytes / waves_per_cu then describe the four-wave

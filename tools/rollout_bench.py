@@ -66,7 +66,9 @@ def run(batch=1024, ticks=64, phase=1, reps=5, noise=0.01):
     res = {}
     finals = {}
     for name, fn in (("ticks", by_ticks), ("rollout", by_rollout)):
-        for _ in range(3 if name == "rollout" else 1):  # the library measures one stream of ticks, then two sub-batches, then chooses
+        # the library measures one stream of ticks, then two sub-batches -- the first sample of either form discarded, each read by a LATER call --
+        # and then chooses: eight calls settle it (three did before the cold samples were discarded, round 5)
+        for _ in range(8 if name == "rollout" else 1):
             fn()
             torch.cuda.synchronize()
         t0 = time.perf_counter()
