@@ -176,6 +176,11 @@ def check_specialisations(lib_path: str) -> None:
     stack (host code only: no GPU needed) and refused when one does not get its own instantiation; WBCQP_DEBUG_DUMP_STRUCT=1 prints the row to paste."""
     import ctypes
     from . import capi, structure
+    if "torch" not in sys.modules:  # (torch's HIP runtime before the library's: capi.load_library says why)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(lib_path)  # (a private handle on the file just built: the process may already hold the previous libwbcqp.so)
     lib.wbcqp_layout_of.argtypes = [ctypes.POINTER(capi.CStructure), ctypes.POINTER(capi.CLayout)]
     for name, want in (("talos", 1), ("icub", 2), ("talos_single_support", 3)):

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -124,11 +125,18 @@ _lib = None
 
 
 def load_library(path: Optional[str] = None):
-    """Loads libwbcqp.so. Import torch first when it is going to be used in the same process, so that
-    both share one HIP runtime (same soname libamdhip64.so.7)."""
+    """Loads libwbcqp.so -- after torch, when torch is installed: the library links libamdhip64.so.7, and a process in which it comes FIRST gets
+    /opt/rocm's HIP runtime while a later `import torch` brings torch's bundled one.  Two runtimes on one GPU work, but the first one then answers
+    hipOccupancyMaxActiveBlocksPerMultiprocessor with 1 for every solve kernel (measured, tools/occ_state_probe.py --torch-after: launches sized for
+    one workgroup per CU, half the throughput, same results).  This module moves tensors that torch allocated, so torch's runtime is the one to share."""
     global _lib
     if _lib is not None:
         return _lib
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401  (before the CDLL below: one HIP runtime per process)
+        except ImportError:
+            pass
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise FileNotFoundError(

@@ -489,6 +489,9 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         }
     }
     const int queue_occ = h->queue_occ[V];
+    if (std::getenv("WBCQP_DEBUG_LAUNCH"))
+        std::fprintf(stderr, "wbcqp launch: V %d spec %d total %d lds %d occupancy %d three %d n_cu %d flags 0x%x\n", V, SPEC, total, lds_bytes, queue_occ, (int)h->queue_three[V],
+                     h->n_cu, (unsigned)h->flags);
     int* queue = nullptr;
     if (osp && !(h->flags & WBCQP_FLAG_HW_DISPATCH) && (lds_bytes >= kQueueMinLds || (h->flags & WBCQP_FLAG_QUEUE))) {
         if (!os.queue && !h->graph_ord) {

@@ -753,7 +753,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         }
         bsync();
         STAMP(5)
-        bool ok = qr_unified(c, Nm, c.s, c.s + 160);
+        constexpr int NTQ = (SPEC > 0 && kSpecDims[SPEC > 0 ? SPEC - 1 : 0].n <= 64) ? 8 : 10; // row pairs per lane of the QR (iCub, Talos on one foot: n 62)
+        bool ok = qr_unified<NTQ>(c, Nm, c.s, c.s + 160);
         if (!ok) status = HQP_ERROR; // redundant equalities
         else {
             bsync();

@@ -10,7 +10,8 @@ namespace wbcqp {
 // ------------------------------------------------------------------------------------------------
 // Householder QR of B (n x m) with J <- J Q in its shadow; every vector on a quad of its own.  A column of B and a row of J
 // take the same operation per reflector, x <- x - tau (x . v) v: m columns + n rows = up to 102 vectors, four lanes each, lane
-// kc of a vector keeps the row pairs (2 kc + 8 t, + 1), t < 10, in registers for the whole factorisation.  Per step only the
+// kc of a vector keeps the row pairs (2 kc + 8 t, + 1), t < NT (ten; eight in the instantiation of a stack with n <= 64: the pairs left out hold
+// rows past n, zeros that add nothing to any sum -- same bits), in registers for the whole factorisation.  Per step only the
 // reflector travels: the quad of column j leaves v_j (zeros above row j, v0 on it) and (tau_j, alpha_j) in LDS, every other
 // vector reads it ONCE (10 x 16 bytes per lane), reduces its dot product over its quad by DPP and updates its registers; the
 // quad of column j + 1 goes on to the next reflector.  One barrier per column, no reloads or stores of the trailing matrix, and
@@ -25,6 +26,7 @@ namespace wbcqp {
 // wait for the other waves.)  Requires n <= 80, m <= 22, m + n <= 102.
 // On return: J = J0 Q in LDS, the packed R and 1/R(j,j).  Returns false when a column is (numerically) dependent.
 // ------------------------------------------------------------------------------------------------
+template <int NT = 10>
 __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbuf, double* sc)
 {
     const int n = c.n, m = c.neq, ldb = c.ldb, ldj = c.ldj, tid = c.tid;
@@ -35,12 +37,13 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
     const bool row1 = !col1 && jr1 < n;
     const bool has2 = e >= 64 - r2;          // round 2: row jr2 of J
     const int jr2 = 64 - m + (e - (64 - r2));
-    double b[10][2], b2[10][2];
+    static_assert(NT == 8 || NT == 10, "row pairs per lane: ten cover n <= 80, eight n <= 64");
+    double b[NT][2], b2[NT][2];
     {
         const int es = col1 ? e : 0;
         const double* Jr = c.J + (row1 ? jr1 : 0) * ldj;
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int k = 2 * kc + 8 * t + i, kk = min(k, n - 1);
@@ -49,7 +52,7 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
             }
         const double* Jr2 = c.J + (has2 ? jr2 : 0) * ldj;
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int k = 2 * kc + 8 * t + i;
@@ -65,15 +68,15 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
         const double e0 = (row0 >= jn) ? b[T0][0] : 0.0, e1 = (row0 + 1 >= jn) ? b[T0][1] : 0.0;
         double sq0 = e0 * e0, sq1 = e1 * e1, sq2 = 0.0, sq3 = 0.0;
 #pragma unroll
-        for (int t = T0 + 1; t + 1 < 10; t += 2) {
+        for (int t = T0 + 1; t + 1 < NT; t += 2) {
             sq0 = fma(b[t][0], b[t][0], sq0);
             sq1 = fma(b[t][1], b[t][1], sq1);
             sq2 = fma(b[t + 1][0], b[t + 1][0], sq2);
             sq3 = fma(b[t + 1][1], b[t + 1][1], sq3);
         }
-        if constexpr (((10 - (T0 + 1)) & 1) != 0) {
-            sq0 = fma(b[9][0], b[9][0], sq0);
-            sq1 = fma(b[9][1], b[9][1], sq1);
+        if constexpr (((NT - (T0 + 1)) & 1) != 0) {
+            sq0 = fma(b[NT - 1][0], b[NT - 1][0], sq0);
+            sq1 = fma(b[NT - 1][1], b[NT - 1][1], sq1);
         }
         double x0 = (row0 == jn) ? b[T0][0] : ((row0 + 1 == jn) ? b[T0][1] : 0.0);
         const double nrm = quad_sum((sq0 + sq1) + (sq2 + sq3));
@@ -88,7 +91,7 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
         if (row0 == jn) b[T0][0] = v0;
         if (row0 + 1 == jn) b[T0][1] = v0;
 #pragma unroll
-        for (int t = 0; t < 10; ++t) {
+        for (int t = 0; t < NT; ++t) {
             double2v o;
             if (t < T0) {
                 o.x = 0.0;
@@ -117,10 +120,10 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
         default: prepare_t(std::integral_constant<int, 3>{}, jn); break;
         }
     };
-    auto apply = [&](double (&x)[10][2], const double2v (&v)[10], double tj) __attribute__((always_inline)) {
+    auto apply = [&](double (&x)[NT][2], const double2v (&v)[NT], double tj) __attribute__((always_inline)) {
         double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
-        for (int t = 0; t < 10; t += 2) {
+        for (int t = 0; t < NT; t += 2) {
             d0 = fma(v[t].x, x[t][0], d0);
             d1 = fma(v[t].y, x[t][1], d1);
             d2 = fma(v[t + 1].x, x[t + 1][0], d2);
@@ -128,7 +131,7 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
         }
         const double coef = quad_sum((d0 + d1) + (d2 + d3)) * tj;
 #pragma unroll
-        for (int t = 0; t < 10; ++t) {
+        for (int t = 0; t < NT; ++t) {
             x[t][0] = fma(-coef, v[t].x, x[t][0]);
             x[t][1] = fma(-coef, v[t].y, x[t][1]);
         }
@@ -142,9 +145,9 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
     for (int j = 0; j < m; ++j) {
         bsync();
         const double* vb = vbuf + (j & 1) * 80 + 2 * kc;
-        double2v v[10];
+        double2v v[NT];
 #pragma unroll
-        for (int t = 0; t < 10; ++t) v[t] = ld2(vb + 8 * t);
+        for (int t = 0; t < NT; ++t) v[t] = ld2(vb + 8 * t);
         const double tj = sc[(j & 1) * 2], alpha = sc[(j & 1) * 2 + 1];
         bad = bad || !(fabs(alpha) > 2.220446049250313e-16 * c.R_norm); // also catches a NaN pivot
         c.R_norm = fmax(c.R_norm, fabs(alpha));
@@ -159,7 +162,7 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
     if (col1) {
         double* Rc = c.R + roff(e);
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 2 * kc + 8 * t + i;
@@ -173,7 +176,7 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
     if (row1) {
         double* Jr = c.J + jr1 * ldj;
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int k = 2 * kc + 8 * t + i;
@@ -183,7 +186,7 @@ __device__ __forceinline__ bool qr_unified(Ctx& c, const double* Bm, double* vbu
     if (has2) {
         double* Jr = c.J + jr2 * ldj;
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int k = 2 * kc + 8 * t + i;
