@@ -240,4 +240,7 @@ def test_layout_reports_three_only_where_three_fit():
     assert two_feet["n"] == 62 and two_feet["waves_per_cu"] == 3 and two_feet["specialised"] == 2 and 3 * two_feet["lds_bytes"] <= 160 * 1024
     for st in (structure.talos_structure(), structure.talos_structure(single_support=True)):
         assert capi.layout_of(st)["waves_per_cu"] == 2
+    # the sizes DESIGN section 4 quotes (a layout change shows here first; kSpecDims and build.check_specialisations follow it)
+    sizes = {name: capi.layout_of(structure.STRUCTURES[name]())["lds_bytes"] for name in ("talos", "icub", "talos_single_support", "icub_single_support")}
+    assert sizes == {"talos": 72128, "icub": 52832, "talos_single_support": 57904, "icub_single_support": 48928}, sizes
     assert capi.layout_of(structure.franka_structure())["waves_per_cu"] == 2  # (below the queue's size: hardware dispatch of solve_kernel)
