@@ -127,8 +127,8 @@ _lib = None
 def load_library(path: Optional[str] = None):
     """Loads libwbcqp.so -- after torch, when torch is installed: the library links libamdhip64.so.7, and a process in which it comes FIRST gets
     /opt/rocm's HIP runtime while a later `import torch` brings torch's bundled one.  Two runtimes on one GPU work, but the first one then answers
-    hipOccupancyMaxActiveBlocksPerMultiprocessor with 1 for every solve kernel (measured, tools/occ_state_probe.py --torch-after: launches sized for
-    one workgroup per CU, half the throughput, same results).  This module moves tensors that torch allocated, so torch's runtime is the one to share."""
+    hipOccupancyMaxActiveBlocksPerMultiprocessor with 1 for every solve kernel (measured, tools/occ_state_probe.py --torch-after; the library overrules
+    such an answer and says so on stderr).  This module moves tensors that torch allocated, so torch's runtime is the one to share."""
     global _lib
     if _lib is not None:
         return _lib

@@ -110,6 +110,7 @@ struct wbcqp_handle {
     wbcqp_dense_output dense_out{};
     int lds_pad = 0; // diagnostic (env WBCQP_DEBUG_LDS_PAD): extra dynamic LDS per workgroup, to force a lower residency
     int queue_lds[2 + kNumSpecs], queue_occ[2 + kNumSpecs] = {}; // occupancy of solve_queue_kernel<., CP, SPEC> at queue_lds bytes of LDS
+    bool warned_occupancy = false;                               // the one-time note of launch() when the runtime's occupancy answer is overruled
     bool queue_three[2 + kNumSpecs] = {};                        // ... and whether solve_queue3_kernel<., SPEC> holds three workgroups per CU at that size
     // wbcqp_rollout: sub-batches on streams of their own (each with its own launch-order state and queue counter), the record
     // arrays and the state ping-pong of the whole batch
@@ -472,6 +473,17 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         int occ = 0;
         HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI, CP, SPEC>, kThreads, (size_t)lds_bytes));
         if (occ < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel: no workgroup fits a CU");
+        // What the CU admits by the measured rule -- k workgroups while k (lds + 16) <= 160 KB (tools/ubench/lds_granule.hip) -- and the kernels' registers (two
+        // waves per SIMD).  A runtime that answers less is not believed: seen when a process holds TWO HIP runtimes (the library loaded before torch: the
+        // first one then answers 1 for every kernel, tools/occ_state_probe.py); the dispatcher places workgroups by the hardware's rules either way, and
+        // workgroups that do not fit wait their turn.
+        const int lds_fit = (160 * 1024) / (lds_bytes + 16);
+        const int want = std::min(lds_fit, 2);
+        bool distrust = false;
+        if (occ < want && h->lds_pad == 0) {
+            distrust = true;
+            occ = want;
+        }
         h->queue_occ[V] = occ;
         h->queue_lds[V] = lds_bytes;
         h->queue_three[V] = false;
@@ -481,11 +493,20 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
             if (lds_bytes * 3 <= 160 * 1024 && h->lds_pad == 0) {
                 int occ3 = 0;
                 HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, solve_queue3_kernel<TI, SPEC>, kThreads, (size_t)lds_bytes));
+                if (occ3 < 3 && lds_bytes <= kLdsThree) {
+                    distrust = true;
+                    occ3 = 3;
+                }
                 if (occ3 >= 3) {
                     h->queue_three[V] = true;
                     h->queue_occ[V] = occ3;
                 }
             }
+        }
+        if (distrust && !h->warned_occupancy) {
+            h->warned_occupancy = true;
+            std::fprintf(stderr, "wbcqp: the HIP runtime reports fewer resident workgroups per CU than LDS (%d B) and registers admit; launching %d per CU anyway. "
+                                 "Two HIP runtimes in this process (libwbcqp.so loaded before torch)?  See INTEGRATION.md.\n", lds_bytes, h->queue_occ[V]);
         }
     }
     const int queue_occ = h->queue_occ[V];

@@ -23,6 +23,27 @@ for name in ("talos", "icub"):
     out = h.solve_batch_host(0, inp)
     print(name, "optimal", int((out["status"] == 0).sum()), flush=True)
     h.close()
+    if "torch" in sys.modules:  # device-resident throughput at B = 8192 in this process (does the hardware place what the launch was sized for?)
+        import time
+        import torch
+        dev = torch.device("cuda", 0)
+        B = 8192
+        big = synth.generate(st, 1024, 6)
+        d_in = {k: torch.from_numpy(np.ascontiguousarray(np.tile(v, (8, 1)))).to(dev) for k, v in big.items() if v.size}
+        o = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, st.na, dtype=torch.float64, device=dev),
+                 status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+        h = capi.Handle(0, capi.F64)
+        h.set_structure(0, st)
+        sp = torch.cuda.current_stream().cuda_stream
+        for _ in range(4):
+            h.solve_batch(0, B, d_in, o, stream=sp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            h.solve_batch(0, B, d_in, o, stream=sp)
+        torch.cuda.synchronize()
+        print(name, "B = 8192: %.2f M QP/s" % (B * 10 / (time.perf_counter() - t0) / 1e6), flush=True)
+        h.close()
 import ctypes
 for lib in ("libamdhip64.so.7", "libamdhip64.so"):
     pass
