@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""One ragged launch against one launch per structure (round 5): iCub + Talos + Talos on one foot, 1638 QPs each (BASELINE config 5's compact share), through
+wbcqp_solve_ragged (one launch of the generic kernel at the largest group's LDS size) and as one wbcqp_solve_batch per group (each its own instantiation
+and residency: iCub three per CU) on one stream and on three.  Measured: single launch 0.696 ms; three launches on one stream 0.790 ms (three tails); on
+three free-running streams 0.641 ms -- but that figure pipelines consecutive calls into each other; with the fork and the join a library call needs
+(built into wbcqp_solve_ragged, measured, reverted) it is 0.759 ms: a persistent queue kernel holds every workgroup slot of the chip until its queue
+is empty, so kernels on other streams start when it ends, not beside it.  Not kept; recorded in profiles/r05/not_kept.txt.
+    python tools/ragged_split_probe.py"""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
@@ -36,4 +44,4 @@ def split_streams():
     for (slot, cnt, d_in, d_out), s in zip(groups, streams):
         h.solve_batch(slot, cnt, d_in, d_out, stream=s)
 apart3 = t(split_streams)
-print("one ragged launch %.3f ms; three launches on one stream %.3f ms; on three streams %.3f ms; same bits %s" % (together, apart, apart3, same))
+print("wbcqp_solve_ragged (one launch) %.3f ms; one launch per group: on one stream %.3f ms, on three free-running streams %.3f ms; same bits %s" % (together, apart, apart3, same))
