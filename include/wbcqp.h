@@ -41,7 +41,8 @@
 extern "C" {
 #endif
 
-/* Interface history (WBCQP_VERSION = 100 major + 10 minor + patch; round 5 changed no declaration of this header):
+/* Interface history (WBCQP_VERSION = 100 major + 10 minor + patch; round 5 changed no declaration of this header -- wbcqp_layout.waves_per_cu may now be 3,
+ * and wbcqp_structure.max_iter no longer decides whether a shipped stack runs its own instantiation):
  *   150  launch-order state per (handle, stream), active_mask written by every kernel, torque / cop task rows
  *        (wbcqp_structure.n_acteq, cop_*), posture mask
  *   140  wbcqp_rollout, wbcqp_outputs.active_mask (WBCQP_FLAG_WARM_START), wbcqp_state.momentum, wbcqp_layout.wave_per_qp
