@@ -110,6 +110,7 @@ struct wbcqp_handle {
     wbcqp_dense_output dense_out{};
     int lds_pad = 0; // diagnostic (env WBCQP_DEBUG_LDS_PAD): extra dynamic LDS per workgroup, to force a lower residency
     int queue_lds[2 + kNumSpecs], queue_occ[2 + kNumSpecs] = {}; // occupancy of solve_queue_kernel<., CP, SPEC> at queue_lds bytes of LDS
+    int queue_occ3[2 + kNumSpecs] = {};                          // ... of solve_queue3_kernel<., SPEC> where queue_three says it holds three
     bool warned_occupancy = false;                               // the one-time note of launch() when the runtime's occupancy answer is overruled
     bool queue_three[2 + kNumSpecs] = {};                        // ... and whether solve_queue3_kernel<., SPEC> holds three workgroups per CU at that size
     // wbcqp_rollout: sub-batches on streams of their own (each with its own launch-order state and queue counter), the record
@@ -159,7 +160,7 @@ int fail(wbcqp_handle* h, int code, const std::string& msg)
     } while (0)
 
 int odd(int v) { return v | 1; }
-void set_lds(wbcqp_layout& L, int lds_bytes, bool compact = false);
+void set_lds(wbcqp_layout& L, int lds_bytes, bool compact = false, bool act_bounds = false);
 
 // Validates a structure and derives sizes + LDS layout. Pure host code.
 int derive(const wbcqp_structure* st, DevStruct& D, HostBlocks& HB, wbcqp_layout& L, std::string& why)
@@ -323,11 +324,11 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
     D.o_J = take(jsize);
     int rs = 512;                                        // packed R of the equalities (neq <= 22 columns)
     if (F.neq > 0 && (n + 4) * F.ldb + 8 > rs) rs = (n + 4) * F.ldb + 8; // N = CE', then B = J0'N (from the region's start: the packed R follows it in time)
-    {   // the inequality loop: Ri (row-packed, n - neq rows, one spare element per row, 64 doubles of over-read behind it), four doubles per
+    {   // the inequality loop: Ri (row-packed, n - neq rows, one spare element per row; reads past its end land in what follows), four doubles per
         // rotation of a drop, the friction rows' table (one sign)
         const int mmax = n - F.neq;
-        const int fric = cp::fric_in_j(n, F.neq, F.nc) ? 0 : F.nc * 17 * 12; // (with fourteen equalities the table lives in J's dead columns: wbcqp_compact.hpp)
-        const int need = ((2 + mmax * (mmax + 3) / 2 + 64 + 1) & ~1) + 4 * (mmax + 2) + fric + 2;
+        const int fric = cp::fric_in_j(n, F.neq, F.nc) != 0 ? 0 : F.nc * 17 * 12; // (with fourteen equalities the table lives in J's dead columns: wbcqp_compact.hpp)
+        const int need = ((2 + mmax * (mmax + 3) / 2 + 1) & ~1) + 4 * (mmax + 2) + fric + 2; // (reads past Ri's last row reach at most mmax + 8 doubles into the 4 (mmax + 2) of the rotation table)
         if (need > rs) rs = need;
     }
     D.o_R = take(rs);
@@ -341,14 +342,15 @@ bool derive_compact(const DevStruct& F, DevStruct& D)
     return true;
 }
 
-void set_lds(wbcqp_layout& L, int lds_bytes, bool compact)
+void set_lds(wbcqp_layout& L, int lds_bytes, bool compact, bool act_bounds)
 {
     L.lds_bytes = lds_bytes;
     L.waves_per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 0;
     // registers: the solve kernels allocate up to 256 VGPRs = two waves per SIMD = two workgroups per CU; the compact layout has a twin compiled
     // for three (solve_queue3_kernel), taken when three workgroups fit the CU's LDS: measured (tools/ubench/lds_granule.hip) the third one fits
     // up to 54 592 bytes of dynamic LDS beside the kernel's static word -- no coarser granule than 16 bytes (the launch asks the runtime itself)
-    const int cap = (compact && lds_bytes >= kQueueMinLds && lds_bytes <= kLdsThree) ? 3 : 2; // (below kQueueMinLds: solve_kernel, two per CU)
+    const int cap = (compact && !act_bounds && lds_bytes >= kQueueMinLds && lds_bytes <= kLdsThree) ? 3 : 2; // (below kQueueMinLds: solve_kernel, two per CU;
+                                                                                                           //  with actuation bounds three per CU measured slower: kThree)
     if (L.waves_per_cu > cap) L.waves_per_cu = cap;
 }
 
@@ -416,8 +418,11 @@ int check_io(wbcqp_handle* h, const Slot& s, int batch, const wbcqp_inputs* in, 
     return WBCQP_OK;
 }
 
-// which instantiations have a three-per-CU twin: the compact kernel, generic or of a stack that can ever fit (not Talos on two feet: 81 KB)
-template <bool CP, int SPEC> constexpr bool kThree = CP && SPEC != 1;
+// which instantiations have a three-per-CU twin: the compact kernel, generic or iCub's.  Not Talos's (two feet: 72 KB of LDS; one foot fits since its layout's
+// last diet, 54 480 B, but LOSES there: 8.03 M QP/s at three per CU against 9.32 M at two -- with actuation bounds the loop keeps the actuation rows in 38
+// registers, and at 168 they live in scratch, on the chain of every pick; tools/occ3_probe.py --stack talos_single_support).  The generic twin is likewise
+// taken only for stacks WITHOUT actuation bounds (launch()).
+template <bool CP, int SPEC> constexpr bool kThree = CP && (SPEC == 0 || SPEC == 2);
 
 template <typename TI, bool CP, int SPEC = 0>
 int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipStream_t stream)
@@ -499,19 +504,26 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
                 }
                 if (occ3 >= 3) {
                     h->queue_three[V] = true;
-                    h->queue_occ[V] = occ3;
+                    h->queue_occ3[V] = occ3;
                 }
             }
         }
         if (distrust && !h->warned_occupancy) {
             h->warned_occupancy = true;
             std::fprintf(stderr, "wbcqp: the HIP runtime reports fewer resident workgroups per CU than LDS (%d B) and registers admit; launching %d per CU anyway. "
-                                 "Two HIP runtimes in this process (libwbcqp.so loaded before torch)?  See INTEGRATION.md.\n", lds_bytes, h->queue_occ[V]);
+                                 "Two HIP runtimes in this process (libwbcqp.so loaded before torch)?  See INTEGRATION.md.\n", lds_bytes,
+                         h->queue_three[V] ? h->queue_occ3[V] : h->queue_occ[V]);
         }
     }
-    const int queue_occ = h->queue_occ[V];
+    // three per CU: where the twin holds three AND no group of the launch has actuation bounds (kThree's comment says why)
+    bool three = false;
+    if constexpr (kThree<CP, SPEC>) {
+        three = h->queue_three[V];
+        for (int g = 0; g < tab.n; ++g) three = three && !tab.g[g].st.act_bounds;
+    }
+    const int queue_occ = three ? h->queue_occ3[V] : h->queue_occ[V];
     if (std::getenv("WBCQP_DEBUG_LAUNCH"))
-        std::fprintf(stderr, "wbcqp launch: V %d spec %d total %d lds %d occupancy %d three %d n_cu %d flags 0x%x\n", V, SPEC, total, lds_bytes, queue_occ, (int)h->queue_three[V],
+        std::fprintf(stderr, "wbcqp launch: V %d spec %d total %d lds %d occupancy %d three %d n_cu %d flags 0x%x\n", V, SPEC, total, lds_bytes, queue_occ, (int)three,
                      h->n_cu, (unsigned)h->flags);
     int* queue = nullptr;
     if (osp && !(h->flags & WBCQP_FLAG_HW_DISPATCH) && (lds_bytes >= kQueueMinLds || (h->flags & WBCQP_FLAG_QUEUE))) {
@@ -523,8 +535,6 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     }
     if (queue) {
         const long long resident = (long long)queue_occ * h->n_cu;
-        bool three = false;
-        if constexpr (kThree<CP, SPEC>) three = h->queue_three[V];
         if constexpr (kThree<CP, SPEC>) {
             if (three)
                 hipLaunchKernelGGL((solve_queue3_kernel<TI, SPEC>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
@@ -627,7 +637,7 @@ int wbcqp_layout_of(const wbcqp_structure* st, wbcqp_layout* out)
     if (rc != WBCQP_OK) return fail(nullptr, rc, why);
     DevStruct C;
     if (derive_compact(D, C)) {
-        set_lds(L, C.lds_doubles * 8, true);
+        set_lds(L, C.lds_doubles * 8, true, C.act_bounds != 0);
         L.specialised = spec_of(C);
     }
     // how a row of kSpecDims (wbcqp_types.hpp) is made: the derived sizes and offsets of a stack, in the order of struct Dims
@@ -784,7 +794,7 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     s.host_cp = DevStruct{};
     if (!(h->flags & WBCQP_FLAG_FULL_LDS) && derive_compact(D, s.host_cp)) {
         s.lds_cp = s.host_cp.lds_doubles * 8;
-        set_lds(L, s.lds_cp, true);
+        set_lds(L, s.lds_cp, true, s.host_cp.act_bounds != 0);
     }
     s.small = small_ok(D, HB);
     L.wave_per_qp = s.small ? 1 : 0;

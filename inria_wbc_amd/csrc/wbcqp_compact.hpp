@@ -35,8 +35,10 @@ namespace wbcqp {
 
 namespace cp {
 // vector region (doubles from one base; the offsets are literals in a shipped stack's instantiation, a few scalar operations in the generic kernel).
-// Slots of VS entries: 80, or 64 for the stacks that fit them (n <= 62, and act_dot's unconditional reads -- x and z up to entry nv + 23 -- stay
-// inside the slot); U has n + 2 entries (VS + 8).  The two slots only a stack WITH actuation bounds uses come last and are left out without them.
+// Slots of VS entries: 80, or 64 for n <= 62; U has n + 2 entries (VS + 8).  act_dot reads x, x_old and z up to entry nv + 23 unconditionally (the
+// coefficients past the stack's own are zero): with 64-entry slots and nv > 40 that runs up to ten entries into the NEXT slot -- NP behind X, the
+// R slot (weights, then r from entry neq on) behind XOLD, XOLD behind Z -- which therefore hold finite numbers from the first phase on (NP and the
+// weights' tail are zeroed with the padding of x and z).  The two slots only a stack WITH actuation bounds uses come last and are left out without them.
 struct VecMap {
     int X, NP, D, Z, XOLD, R, U, UOLD, RDINV, PART, TACT /* 64 */, S /* 256 */, BLB, BUB, RED /* 32 */, CE0 /* 24 */, TL, TU, COUNT, VS;
     // dead-time aliases: g and 1/sqrt(pivot) die with x0, the weights with the force blocks, b1 with the assembly.  The S slot (b1, the force
@@ -44,9 +46,10 @@ struct VecMap {
     // block-reduction scratch of the loop's rare paths live there; the loop's own slots (lp::) take RED and CE0 (adjacent).
     int G, DINV, W, B1, PRM, PW, DI /* 128 */, LRED /* 32 */, EL /* 8 */;
 };
-// the friction table in J's dead equality columns 2..13 of rows 0 .. 17 nc - 1 (wbcqp_compact.hpp, phase 4) instead of the R region
-__host__ __device__ constexpr bool fric_in_j(int n, int neq, int nc) { return neq >= 14 && n >= 17 * nc; }
-__host__ __device__ constexpr int vec_stride(int n, int nv) { return (n <= 62 && nv + 24 <= 64) ? 64 : 80; }
+// where the friction table lives in the loop (wbcqp_compact.hpp, phase 4).  1: in J's dead equality columns 2..13 of rows 0 .. 17 nc - 1 (fourteen
+// equalities or more); 2: in columns 2..7 of TWO rows per entry, rows 0 .. 34 nc - 1 (eight to thirteen equalities); 0: behind the rotation table in the R region
+__host__ __device__ constexpr int fric_in_j(int n, int neq, int nc) { return (neq >= 14 && n >= 17 * nc) ? 1 : ((neq >= 8 && n >= 34 * nc) ? 2 : 0); }
+__host__ __device__ constexpr int vec_stride(int n, int /* nv */) { return n <= 62 ? 64 : 80; }
 __host__ __device__ constexpr VecMap vec_map(int n, int nv, int act_bounds)
 {
     VecMap m{};
@@ -74,7 +77,7 @@ struct ActRegs {
 // One actuation row of tau' = M_a xn - J_a' fn with xn = xp + t zp formed on the fly (t = 0: xn = xp exactly): four lanes per
 // row (act_rows()' layout), every lane of the quad returns the row's total.  Every read is base + immediate from ONE
 // per-lane address: coefficients past nv / k are zero and what they multiply is finite -- the x and z slots are zero from
-// n to their end (set once per QP) and nv + 23 < the slot's length (cp::vec_stride).
+// n to their end (set once per QP); past the slot's end they meet finite numbers (cp::VecMap).
 __device__ __forceinline__ double act_dot(const Ctx& c, const ActRegs& a, const double* xp, const double* zp, double t)
 {
     const int nv = c.nv, q4 = c.tid & 3;
@@ -471,6 +474,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             c.z[tid] = 0.0;
             c.x[tid] = 0.0;
         }
+        if (tid < VS) c.np[tid] = 0.0;                    // ... which may run into the slot behind x (cp::VecMap)
+        if (tid >= n_tasks && tid < VS) c.w[tid] = 0.0;   // ... and into the one behind x_old: the weights' tail (r replaces the slot from entry neq on)
         bsync();
         if (tid < n_dense) { // (row weight, right-hand side) pairs behind the staged rows: one 16-byte read per row
             As[n_dense * 64 + 2 * tid] = c.w[drt];
@@ -866,13 +871,15 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         double* const Ri = c.R + 2;                   // inverse of R's inequality block, ROW-packed: (i, j), i <= j, at rio(i) + j - i (R is dead);
                                                       // one zero in front of it: what a row's rotation reads left of its diagonal
         const int ri_size = lp::rio(MM, MM);
-        double* const prm = c.R + ((2 + ri_size + 64 + 1) & ~1);  // drop: 4 doubles per rotation (a_l, b_l, rho_{l+1}, -), behind Ri's over-read pad
+        double* const prm = c.R + ((2 + ri_size + 1) & ~1);  // drop: 4 doubles per rotation (a_l, b_l, rho_{l+1}, -) right behind Ri: the matvec's reads past Ri's
+                                                              // last row (they meet zeros of d) land here, on numbers that are finite from the loop's first phase on
         // friction rows: the 12 coefficients of row pair e = 17 ct + rr (one sign kept: the other is folded into the use -- negation commutes with every
-        // rounding) at fct + e fst.  With fourteen or more equalities they sit in J itself: columns 2..13 of row e, equality columns the loop never
-        // reads (columns 0-1 may be the pad pair of the row before); otherwise behind the rotation table in the R region.
-        const bool fric_in_J = cp::fric_in_j(n, neq, nc);
-        double* const fct = fric_in_J ? c.J + 2 : prm + 4 * (MM + 2);
-        const int fst = fric_in_J ? ldj : 12;
+        // rounding) at fct + e fst.  With enough equalities they sit in J itself (cp::fric_in_j): columns 2..13 of row e, or 2..7 of rows 2 e and 2 e + 1 --
+        // equality columns the loop never reads (columns 0-1 may be the pad pair of the row before); otherwise behind the rotation table in the R region.
+        const int fric_mode = cp::fric_in_j(n, neq, nc);
+        double* const fct = fric_mode ? c.J + 2 : prm + 4 * (MM + 2);
+        const int fst = fric_mode == 1 ? ldj : (fric_mode == 2 ? 2 * ldj : 12); // entry to entry
+        const int fh = fric_mode == 2 ? ldj : 6;                                 // coefficient m of an entry at (m / 6) fh + m % 6
         double* const Wp = lds + D.o_vec + vm.PW;    // pending update: J(:, pc:) <- J(:, pc:) - w v(pc:)'; w = 0 when there is none
         double* const dI = lds + D.o_vec + vm.DI;    // d at the active inequality positions, zero from mi on (read up to 2 x 64)
         double* const LS = lds + D.o_vec + vm.RED;   // the loop's slots (lp::)
@@ -892,7 +899,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             zz.y = 0.0;
             *reinterpret_cast<double2v*>(__builtin_assume_aligned(c.J + tid * ldj, 16)) = zz;
         }
-        for (int e = tid; e < ri_size + 64 + 2; e += kThreads) c.R[e] = 0.0;
+        for (int e = tid; e < ((2 + ri_size + 1) & ~1) + 4 * (MM + 2) + 2; e += kThreads) c.R[e] = 0.0; // Ri and the rotation table
         if (tid < 128) dI[tid] = 0.0;
         if (tid < 80) Wp[tid] = 0.0;
         if (tid < VS) {
@@ -923,7 +930,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
 #pragma unroll
                     for (int m = 0; m < 12; ++m) bv[m] = B[m];
 #pragma unroll
-                    for (int m = 0; m < 12; ++m) dst[m] = bv[m];
+                    for (int m = 0; m < 12; ++m) dst[(m / 6) * fh + m % 6] = bv[m];
                     own.coef = dst;
                 }
             }
@@ -1007,7 +1014,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     const double* zf = zp + nv + 12 * ct;
                     double a = 0.0;
 #pragma unroll
-                    for (int m = 0; m < 12; ++m) a = fma(own.coef[m], fma(t, zf[m], f[m]), a); // (coef: LDS)
+                    for (int m = 0; m < 12; ++m) a = fma(own.coef[(m / 6) * fh + m % 6], fma(t, zf[m], f[m]), a); // (coef: LDS)
                     v = neg ? -a : a;
                 }
                 v += own.ci0;
@@ -1044,8 +1051,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     double a = 0.0, b2 = 0.0;
 #pragma unroll
                     for (int m = 0; m < 12; m += 2) {
-                        a = fma(own.coef[m], zf[m], a);
-                        b2 = fma(own.coef[m + 1], zf[m + 1], b2);
+                        a = fma(own.coef[(m / 6) * fh + m % 6], zf[m], a);
+                        b2 = fma(own.coef[((m + 1) / 6) * fh + (m + 1) % 6], zf[m + 1], b2);
                     }
                     dz = neg ? -(a + b2) : (a + b2);
                 }
@@ -1186,7 +1193,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 const int jq = tid >> 2, q4 = tid & 3;
                 const int j = neq + min(jq, MM - 1);
                 const int k0 = nv + 12 * ct + 3 * q4;
-                const double* F = fct + (17 * ct + rr) * fst + 3 * q4;
+                const double* F = fct + (17 * ct + rr) * fst + (q4 >> 1) * fh + 3 * (q4 & 1); // coefficients 3 q4 .. 3 q4 + 2
                 const double* Jb = c.J + k0 * ldj + j;
                 const double* wb = Wp + k0;
                 const double f0 = F[0], f1 = F[1], f2 = F[2];

@@ -1051,6 +1051,8 @@ __global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<
 // build.py admits scratch for this kernel only).  Measured before it was built in (tools/occ3_probe.py, profiles/r05/occ3_probe.txt:
 // iCub on one foot, n 50, B = 8192): two per CU without scratch 10.55 M QP/s; this build held at two per CU 9.59 M (the spills cost 9 %);
 // this build at three per CU 12.24 M (+16 %, same bits) -- the chains of a third QP fill the issue slots two leave idle.
+// Taken only for stacks WITHOUT actuation bounds: with them the loop's 38 registers of actuation rows go to scratch and three per CU loses (Talos on one
+// foot: 8.03 M QP/s against 9.32 M at two; wbcqp_api.hip, kThree).
 // ------------------------------------------------------------------------------------------------
 template <typename TI, int SPEC = 0>
 __global__ __launch_bounds__(kThreads, 3) void solve_queue3_kernel(const GroupTable<TI> tab, int* queue, const int total)

@@ -88,11 +88,11 @@ struct Dims {
 constexpr int kNumSpecs = 3;
 constexpr Dims kSpecDims[kNumSpecs] = {
     // 1: etc/talos/tasks.yaml on talos.urdf (nv 50, two foot contacts, bounds + actuation bounds): n 74, nEq 18, 244 one-sided rows
-    {50, 44, 2, 24, 74, 6, 41, 19, 44, 44, 1, 18, 244, 97, 1000, 74, 22, 0, 5478, 7430, 8870, 2714, 88},
+    {50, 44, 2, 24, 74, 6, 41, 19, 44, 44, 1, 18, 244, 97, 1000, 74, 22, 0, 5478, 7366, 8806, 2714, 88},
     // 2: etc/icub/tasks.yaml (nv 38, two contacts, no actuation bounds): n 62, nEq 18, 132 one-sided rows
     {38, 32, 2, 24, 62, 6, 39, 13, 32, 32, 0, 18, 132, 83, 1000, 62, 22, 0, 3846, 5306, 6458, 2582, -1},
     // 3: Talos in single support (walk / walk-on-spot between a lift-off and a touch-down): n 62, nEq 12, 210 one-sided rows
-    {50, 44, 1, 12, 62, 6, 41, 18, 44, 44, 1, 12, 210, 91, 1000, 62, 14, 0, 3846, 5652, 7092, 2714, 88},
+    {50, 44, 1, 12, 62, 6, 41, 18, 44, 44, 1, 12, 210, 91, 1000, 62, 14, 0, 3846, 5384, 6664, 2714, 88},
 };
 __host__ __device__ inline Dims dims_from(const struct DevStruct& S);
 

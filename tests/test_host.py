@@ -238,9 +238,12 @@ def test_layout_reports_three_only_where_three_fit():
     assert one_foot["n"] == 50 and one_foot["neq"] == 12 and one_foot["waves_per_cu"] == 3 and 3 * one_foot["lds_bytes"] <= 160 * 1024
     two_feet = capi.layout_of(structure.icub_structure())  # BASELINE config 3's stack: 52.8 KB since its rows of J are n long and the friction table lives in them
     assert two_feet["n"] == 62 and two_feet["waves_per_cu"] == 3 and two_feet["specialised"] == 2 and 3 * two_feet["lds_bytes"] <= 160 * 1024
-    for st in (structure.talos_structure(), structure.talos_structure(single_support=True)):
-        assert capi.layout_of(st)["waves_per_cu"] == 2
+    # Talos on one foot fits since its layout's last diet (54 480 B) but stays at two: with actuation bounds the three-per-CU kernel measured SLOWER (its 38
+    # registers of actuation rows go to scratch: csrc/wbcqp_api.hip, kThree)
+    one_foot_talos = capi.layout_of(structure.talos_structure(single_support=True))
+    assert one_foot_talos["waves_per_cu"] == 2 and one_foot_talos["specialised"] == 3 and one_foot_talos["lds_bytes"] <= 54592
+    assert capi.layout_of(structure.talos_structure())["waves_per_cu"] == 2
     # the sizes DESIGN section 4 quotes (a layout change shows here first; kSpecDims and build.check_specialisations follow it)
     sizes = {name: capi.layout_of(structure.STRUCTURES[name]())["lds_bytes"] for name in ("talos", "icub", "talos_single_support", "icub_single_support")}
-    assert sizes == {"talos": 72128, "icub": 52832, "talos_single_support": 57904, "icub_single_support": 48928}, sizes
+    assert sizes == {"talos": 71616, "icub": 52832, "talos_single_support": 54480, "icub_single_support": 46784}, sizes
     assert capi.layout_of(structure.franka_structure())["waves_per_cu"] == 2  # (below the queue's size: hardware dispatch of solve_kernel)
