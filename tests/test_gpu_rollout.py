@@ -87,14 +87,15 @@ def _tick_buffers(m, st, tm, B, seed, dev, torch):
     return state, rows, out, torch.zeros_like(state["q"]), torch.zeros_like(state["v"])
 
 
-@pytest.mark.parametrize("B", [1, 37])
-def test_tick_and_graph_replay_are_the_three_calls(B):
+@pytest.mark.parametrize("B,robot", [(1, "talos"), (37, "talos"), (37, "icub"), (1000, "icub")])
+def test_tick_and_graph_replay_are_the_three_calls(B, robot):
     """wbcqp_tick = problem_data + solve_batch + integrate; the captured graph replays it bit for bit, tick after tick, with
-    the state fed back between launches."""
+    the state fed back between launches.  (iCub: the solve of the captured tick is the three-per-CU kernel, whose lanes keep part of their
+    registers in scratch -- a captured launch must bring that with it.)"""
     import torch
-    m = mdl.talos_like()
-    st = structure.talos_structure()
-    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    m = mdl.talos_like() if robot == "talos" else mdl.icub_like()
+    st = structure.talos_structure() if robot == "talos" else structure.icub_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack() if robot == "talos" else mdl.icub_stack())
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
     results = []
