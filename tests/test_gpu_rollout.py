@@ -265,16 +265,17 @@ def test_tick_keeps_the_state_of_an_instance_whose_qp_fails():
     h.close()
 
 
-@pytest.mark.parametrize("B,K", [(5, 1), (7, 6), (600, 4)])
-def test_rollout_equals_k_ticks_bit_for_bit(B, K):
+@pytest.mark.parametrize("B,K,robot", [(5, 1, "talos"), (7, 6, "talos"), (600, 4, "talos"), (900, 4, "icub")])
+def test_rollout_equals_k_ticks_bit_for_bit(B, K, robot):
     """wbcqp_rollout (K ticks of every instance in ONE launch, persistent workgroups, the record in a per-workgroup slot) against K
     calls of wbcqp_tick with the state fed back: the same device functions run the three phases, so every output is the same bits --
     the final state, q_solver, the last tick's x / tau / status / iters, the momentum of the last tick's state, and the iteration
-    total.  600 instances: more than the 512 resident workgroups, so some workgroups run two instances one after the other."""
+    total.  600 instances: more than the 512 resident workgroups, so some workgroups run two instances one after the other (iCub, 900:
+    more than its 768 -- three per CU)."""
     import torch
-    m = mdl.talos_like()
-    st = structure.talos_structure()
-    tm = mdl.build_taskmap(m, st, mdl.talos_stack())
+    m = mdl.talos_like() if robot == "talos" else mdl.icub_like()
+    st = structure.talos_structure() if robot == "talos" else structure.icub_structure()
+    tm = mdl.build_taskmap(m, st, mdl.talos_stack() if robot == "talos" else mdl.icub_stack())
     dev = torch.device("cuda", 0)
     s = mdl.sample_states(m, tm, B, 91_000, q_noise=0.01, v_noise=0.05, ref_noise=0.01)
     com_blk = next(b for b in tm.blocks if b.kind == mdl.T_COM)
