@@ -423,6 +423,9 @@ int check_io(wbcqp_handle* h, const Slot& s, int batch, const wbcqp_inputs* in, 
 // registers, and at 168 they live in scratch, on the chain of every pick; tools/occ3_probe.py --stack talos_single_support).  The generic twin is likewise
 // taken only for stacks WITHOUT actuation bounds (launch()).
 template <bool CP, int SPEC> constexpr bool kThree = CP && (SPEC == 0 || SPEC == 2);
+// which instantiations have a twin with the warm start's pick hint compiled in (WBCQP_FLAG_WARM_START): the generic compact kernel and Talos's; a handle
+// with that flag runs every compact launch through one of the two (wbcqp_solve_ragged routes the other stacks to the generic one)
+template <bool CP, int SPEC> constexpr bool kWarm = CP && (SPEC == 0 || SPEC == 1);
 
 template <typename TI, bool CP, int SPEC = 0>
 int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipStream_t stream)
@@ -435,6 +438,10 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel<TI, CP, SPEC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        if constexpr (kWarm<CP, SPEC>) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel_warm<TI, SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue_kernel_warm<TI, SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        }
         if constexpr (kThree<CP, SPEC>)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_queue3_kernel<TI, SPEC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -516,9 +523,11 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         }
     }
     // three per CU: where the twin holds three AND no group of the launch has actuation bounds (kThree's comment says why)
+    bool warm = false; // the handle asked for the warm start's pick hint: the kernels that carry its code
+    if constexpr (kWarm<CP, SPEC>) warm = (h->flags & WBCQP_FLAG_WARM_START) != 0;
     bool three = false;
     if constexpr (kThree<CP, SPEC>) {
-        three = h->queue_three[V];
+        three = h->queue_three[V] && !warm;
         for (int g = 0; g < tab.n; ++g) three = three && !tab.g[g].st.act_bounds;
     }
     const int queue_occ = three ? h->queue_occ3[V] : h->queue_occ[V];
@@ -540,12 +549,21 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
                 hipLaunchKernelGGL((solve_queue3_kernel<TI, SPEC>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
                                    stream, tab, queue, total);
         }
-        if (!three)
+        if constexpr (kWarm<CP, SPEC>) {
+            if (warm)
+                hipLaunchKernelGGL((solve_queue_kernel_warm<TI, SPEC>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
+                                   stream, tab, queue, total);
+        }
+        if (!three && !warm)
             hipLaunchKernelGGL((solve_queue_kernel<TI, CP, SPEC>), dim3((unsigned)(total < resident ? total : resident)), dim3(kThreads), lds_bytes,
                                stream, tab, queue, total);
     }
-    else
-        hipLaunchKernelGGL((solve_kernel<TI, CP, SPEC>), dim3(total), dim3(kThreads), lds_bytes, stream, tab);
+    else {
+        if constexpr (kWarm<CP, SPEC>) {
+            if (warm) hipLaunchKernelGGL((solve_kernel_warm<TI, SPEC>), dim3(total), dim3(kThreads), lds_bytes, stream, tab);
+        }
+        if (!warm) hipLaunchKernelGGL((solve_kernel<TI, CP, SPEC>), dim3(total), dim3(kThreads), lds_bytes, stream, tab);
+    }
     HIP_TRY(h, hipGetLastError());
     // the order is renewed every `period` launches: iteration counts drift slowly from tick to tick, the queue absorbs what
     // drift there is, and the two order kernels (4.5 + 15 us) are then a fraction of a launch instead of a twentieth
@@ -859,6 +877,7 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
     if (compact && used == 1 && !(h->flags & WBCQP_FLAG_GENERIC_KERNEL) && h->lds_pad == 0)
         for (int g = 0; g < n_groups; ++g)
             if (groups[g].batch > 0 && !(wave_per_qp && h->slots[groups[g].slot].small)) spec = h->slots[groups[g].slot].spec;
+    if ((h->flags & WBCQP_FLAG_WARM_START) && spec > 1) spec = 0; // the hint's code lives in the generic kernel and Talos's (kWarm)
     if (h->dtype == WBCQP_F64) {
         if (!compact) return launch<double, false>(h, t64, total, lds, hs);
         switch (spec) {

@@ -297,7 +297,7 @@ template <int SPEC> __device__ __forceinline__ Dims dims_of(const DevStruct& S)
 }
 
 // SPEC > 0: the instantiation for the shipped stack kSpecDims[SPEC - 1] -- every size and LDS offset below is a literal
-template <typename TI, int SPEC = 0>
+template <typename TI, int SPEC = 0, bool WARM = false>
 __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const DevStruct& S, const int b, double* lds, const int tid, const int brec = -1)
 {
     const Dims D = dims_of<SPEC>(S);
@@ -950,7 +950,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         // WBCQP_FLAG_WARM_START (opt-in, include/wbcqp.h): rows that were active at the previous tick's solution are picked first
         // (among the violated ones; the most violated of them first).  Any violated row is a legal Goldfarb-Idnani pick, so only
         // the order of the picks changes -- and with it the add / drop churn a cold start goes through.
-        const bool use_warm = ga.warm != 0 && ga.amask != nullptr;
+        // (WARM: the instantiations behind WBCQP_FLAG_WARM_START.  The default kernels are compiled without the hint's code: carrying it unused cost
+        //  them 4 % per pick -- four registers, a second pair of election slots, their masks; profiles/r05/not_kept.txt's KEPT list)
+        const bool use_warm = WARM && ga.warm != 0 && ga.amask != nullptr;
         bool warm_own = false, warm_act = false;
         if (use_warm) {
             const unsigned* am = ga.amask + qp * 8;

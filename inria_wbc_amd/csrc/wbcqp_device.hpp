@@ -1046,6 +1046,54 @@ __global__ __launch_bounds__(kThreads) void solve_queue_kernel(const GroupTable<
 }
 
 // ------------------------------------------------------------------------------------------------
+// The two compact kernels with the warm start's pick hint compiled IN (WBCQP_FLAG_WARM_START, opt-in: include/wbcqp.h): the generic one and Talos's.  The default
+// kernels above are compiled without it -- measured (tools/cmp_variants.sh, twice in one call): the stream's longest QP 203.4 -> 196.9 us, 3.52 -> 3.38 us per pick,
+// B = 8192 7.58 -> 7.71 M QP/s with the hint's code gone from a kernel that never takes the hint.  Same bodies.
+// ------------------------------------------------------------------------------------------------
+template <typename TI, int SPEC = 0>
+__global__ __launch_bounds__(kThreads) void solve_kernel_warm(const GroupTable<TI> tab)
+{
+    extern __shared__ __align__(16) double lds[];
+    int b = tab.order ? tab.order[blockIdx.x] : (int)blockIdx.x, gi = 0;
+    while (gi + 1 < tab.n && b >= tab.g[gi].count) {
+        b -= tab.g[gi].count;
+        ++gi;
+    }
+    const GroupArgs<TI>& ga = tab.g[gi];
+    solve_one_compact<TI, SPEC, true>(ga, ga.st, b, lds, threadIdx.x);
+}
+
+template <typename TI, int SPEC = 0>
+__global__ __launch_bounds__(kThreads) void solve_queue_kernel_warm(const GroupTable<TI> tab, int* queue, const int total)
+{
+    extern __shared__ __align__(16) double lds[];
+    __shared__ int next_qp;
+    for (bool first = true;; first = false) {
+        if (threadIdx.x == 0) {
+            int pos = (int)blockIdx.x;
+            if (!first) {
+                const int c = atomicAdd(queue, 1);
+                pos = (int)gridDim.x + c;
+                if (c == total - 1) *queue = 0;
+            }
+            next_qp = pos < total ? (tab.order ? tab.order[pos] : pos) : -1;
+        }
+        bsync();
+        int b = uni(next_qp), gi = 0;
+        if (b < 0) break;
+        while (gi + 1 < tab.n && b >= tab.g[gi].count) {
+            b -= tab.g[gi].count;
+            ++gi;
+        }
+        const GroupArgs<TI>& ga = tab.g[gi];
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        solve_one_compact<TI, SPEC, true>(ga, ga.st, b, lds, tid);
+        bsync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The queue kernel for stacks whose workgroup leaves room for a THIRD one on a CU (compact layout, LDS <= a third of the CU's 160 KB:
 // n <= ~52 today).  Same body, compiled for three waves per SIMD: 168 VGPRs, what does not fit goes to scratch (208-232 bytes per lane;
 // build.py admits scratch for this kernel only).  Measured before it was built in (tools/occ3_probe.py, profiles/r05/occ3_probe.txt:
