@@ -247,7 +247,8 @@ def other_configs(local_rank, torch, parity=True):
         d["b1"] = torch.from_numpy(np.ascontiguousarray(b1s[t])).to(dev)
         dicts.append(d)
     o = dict(x=torch.zeros(Bt, st.n, dtype=torch.float32, device=dev), tau=torch.zeros(Bt, st.na, dtype=torch.float32, device=dev),
-             status=torch.full((Bt,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(Bt, dtype=torch.int32, device=dev))
+             status=torch.full((Bt,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(Bt, dtype=torch.int32, device=dev),
+             active_mask=torch.zeros(Bt, 8, dtype=torch.int32, device=dev))
     h = capi.Handle(device=local_rank, dtype=capi.F32)
     h.set_structure(0, st)
     sp = torch.cuda.current_stream().cuda_stream
@@ -280,6 +281,9 @@ def other_configs(local_rank, torch, parity=True):
         okr = ref["status"] == 0
         c3["parity"] = {"sample": ns, "max_rel_dx": float((np.abs(xg - ref["x"]).max(axis=1) / np.maximum(1.0, np.abs(ref["x"]).max(axis=1)))[okr].max()),
                         "status_equal": bool(np.array_equal(o["status"][:ns].cpu().numpy(), ref["status"])),
+                        "iters_equal_frac": float((o["iters"][:ns].cpu().numpy() == ref["iters"]).mean()),
+                        "active_set_equal_frac": (float((o["active_mask"][:ns].cpu().numpy().view(np.uint32) == ref["active_mask"]).all(axis=1)[okr].mean())
+                                                  if "active_mask" in o else None),
                         "tolerance": "1e-3 relative (SURVEY 8(d): fp32 boundary; outputs are rounded to f32)"}
     h.close()
     out["config3_icub_b4096_f32"] = c3
@@ -695,6 +699,11 @@ def main():
                     status=torch.full((b,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(b, dtype=torch.int32, device=dev))
 
     d_out = new_out()
+    # the rest of HQPOutput (objective, size of the active set, the active one-sided rows as a 256-bit mask): written by the timed launches too --
+    # 44 bytes per QP beside the 35 152 algorithmic ones, not counted in `roofline.achieved` -- so that the parity sample below compares the
+    # active set of the LAST TIMED launch with the oracle's (identical active set)
+    d_out.update(objective=torch.zeros(B, dtype=tdt, device=dev), n_active=torch.zeros(B, dtype=torch.int32, device=dev),
+                 active_mask=torch.zeros(B, 8, dtype=torch.int32, device=dev))
     base_flags = args.flags | (capi.FLAG_INDEX_ORDER if args.index_order else 0)
     h = capi.Handle(device=local_rank, dtype=cdt, flags=base_flags)
     h.set_structure(0, st)
@@ -782,6 +791,9 @@ def main():
     iters = d_out["iters"].cpu().numpy()
     x_gpu = d_out["x"].cpu().numpy().astype(np.float64)
     tau_gpu = d_out["tau"].cpu().numpy()[:, :st.na].astype(np.float64)
+    mask_gpu = d_out["active_mask"].cpu().numpy().view(np.uint32)
+    nact_gpu = d_out["n_active"].cpu().numpy()
+    obj_gpu = d_out["objective"].cpu().numpy().astype(np.float64)
 
     # ---- the optional exchange step of BASELINE config 4, timed APART from the solve (the path itself has no collective): the
     # library's own wbcqp_allgather_tau on a communicator of this job's ranks.  It has never run on more than one rank before the
@@ -1110,7 +1122,15 @@ def main():
                 "max_abs_dtau": float(np.abs(tau_gpu[:nsamp] - ref["tau"])[ok].max()) if st.na else 0.0,
                 "status_equal": bool(np.array_equal(status[:nsamp], ref["status"])),
                 "iters_equal_frac": float((iters[:nsamp] == ref["iters"]).mean()),
+                # the final active set as eiquadprog numbers it (bit r of wbcqp_outputs.active_mask = one-sided CI row r), its size and the
+                # objective, against the oracle's A / iq / f on the same sample
+                "active_set_equal_frac": float((mask_gpu[:nsamp] == ref["active_mask"]).all(axis=1)[ok].mean()) if ok.any() else 1.0,
+                "n_active_equal_frac": float((nact_gpu[:nsamp] == ref["n_active"])[ok].mean()) if ok.any() else 1.0,
+                "max_rel_dobjective": float((np.abs(obj_gpu[:nsamp] - ref["fval"]) / np.maximum(1.0, np.abs(ref["fval"])))[ok].max(initial=0.0)),
             }
+            if st.nc:  # raw contact-point forces: six directions per contact are held by the 1e-8 regulariser alone (tests/util.py: bounded at 1e-4) -- reported
+                result["parity"]["max_rel_draw_force"] = float((np.abs(x_gpu[:nsamp, st.nv:] - ref["x"][:, st.nv:]).max(axis=1) / xs)[ok].max(initial=0.0))
+                result["parity"]["max_rel_ddv"] = float((np.abs(x_gpu[:nsamp, :st.nv] - ref["x"][:, :st.nv]).max(axis=1) / xs)[ok].max(initial=0.0))
         print(json.dumps(result), flush=True)
 
     if exchange is not None and exchange.get("hung"):

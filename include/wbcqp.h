@@ -145,8 +145,11 @@ typedef struct {
     /* element counts of the per-QP input arrays below */
     int32_t len_M, len_h, len_A, len_b1, len_Ac, len_bc, len_blb, len_bub, len_tlb, len_tub, len_w;
     int32_t lds_bytes;         /* dynamic LDS one QP (one 256-thread workgroup) needs */
-    int32_t waves_per_cu;      /* resident QPs (workgroups) per CU: 1 (full layout), 2 (compact layout: the kernels' registers admit two), or 3 --
-                                  compact layout with lds_bytes <= 54592: such launches take the queue kernel compiled for three waves per SIMD */
+    int32_t waves_per_cu;      /* resident QPs (workgroups) per CU a launch of THIS structure alone runs with by default: 1 (full layout), 2 (compact
+                                  layout: the kernels' registers admit two), or 3 -- compact layout, NO actuation bounds, 40 KB <= lds_bytes <= 54592:
+                                  such launches take the queue kernel compiled for three waves per SIMD (iCub on one or two feet).  A launch falls
+                                  back to two per CU under WBCQP_FLAG_WARM_START, WBCQP_FLAG_HW_DISPATCH, env WBCQP_DEBUG_LDS_PAD, or when it is ragged
+                                  and any of its groups has actuation bounds; env WBCQP_DEBUG_LAUNCH=1 prints the residency of every launch */
     int64_t algorithmic_bytes; /* compact in+out bytes per QP at WBCQP_F64 */
     int32_t wave_per_qp;       /* 1: the structure runs one WAVEFRONT per QP (n <= 16, fixed base, no contacts, bounds only: Franka, Tiago),
                                   four QPs per workgroup, 7.7 KB of LDS per QP; lds_bytes / waves_per_cu then describe the four-wave
@@ -186,8 +189,17 @@ typedef struct {
     int32_t* iters;   /* [batch] active-set iterations (eiquadprog `iter`)                   */
     void* objective;  /* [batch] 0.5x'Hx + g'x (SolverHQPBase::getObjectiveValue), may be NULL */
     int32_t* n_active;/* [batch] size of the final active set incl. equalities, may be NULL  */
-    uint32_t* active_mask; /* [batch][8], may be NULL.  OUT: bit r of the 256-bit mask = one-sided inequality row r is active at the
-                         solution.  With WBCQP_FLAG_WARM_START also IN: the mask a previous tick left for the same instance (zeros: no
+    uint32_t* active_mask; /* [batch][8], may be NULL.  OUT: bit r of the 256-bit mask (bit r % 32 of word r / 32) = one-sided inequality row r is
+                         active at the solution (HQPOutput::activeSet's inequality entries).  r IS eiquadprog's CI row index, i.e. the row
+                         SolverHQuadProgFast::solve stacks: the level-0 inequality blocks in the order of wbcqp_structure.ineq_kind / ineq_arg
+                         (= the order tasks.yaml added them, pos_tracker.cpp:161-189), each two-sided block of m rows lb <= A x <= ub as
+                         rows [k, k + m) = +A with ci0 = -lb (the LOWER side) followed by rows [k + m, k + 2m) = -A with ci0 = ub (the UPPER
+                         side); m = n_bound for the bounds block (row j: joint bound_col[j]), na for the actuation bounds (row j: actuated
+                         joint j, limits shifted by -h_a), 17 for a contact's force block (rows 0-15 the friction pyramid of the four points,
+                         row 16 the normal-force sum).  Talos: bounds 0-43 / 44-87, torque 88-131 / 132-175, first contact 176-192 / 193-209,
+                         second contact 210-226 / 227-243.  Equalities (always active; eiquadprog tags them -i-1) have no bit: popcount =
+                         n_active - nEq.  tests/util.py:assert_parity compares the mask with the oracle's active list bit for bit on every
+                         parity case.  With WBCQP_FLAG_WARM_START also IN: the mask a previous tick left for the same instance (zeros: no
                          hint).  Device pointer on the device entry points.  Written by every kernel (rows beyond the 256th have no bit;
                          all zero where the status is not OPTIMAL); READ as the hint by the compact-layout kernel only -- structures on
                          the one-wavefront-per-QP kernel (wbcqp_layout.wave_per_qp) and on the full layout ignore the hint. */
@@ -431,7 +443,7 @@ typedef struct {
 
 int wbcqp_tick(wbcqp_handle* handle, int slot, int batch, const wbcqp_tick_io* io, void* stream);
 /* Same with HOST pointers; blocks until done.  Only the state, the references and the constant tlb / tub / w cross to the
- * device and only x, tau, status, iters (objective, n_active if given) and the integrated state come back: about 4 KB per
+ * device and only x, tau, status, iters (objective, n_active, active_mask if given) and the integrated state come back: about 4 KB per
  * Talos instance instead of the 34 KB record.  The row arrays M .. bub of io->rows may be NULL; where given they receive the
  * rows of this tick (what Controller::cost() reads). */
 int wbcqp_tick_host(wbcqp_handle* handle, int slot, int batch, const wbcqp_tick_io* io);

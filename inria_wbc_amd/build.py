@@ -41,9 +41,30 @@ def needs_build() -> bool:
 def build_stamps(verbose: bool = False) -> str:
     """Diagnostic library with in-kernel phase stamps (never the one tests or bench load)."""
     out = os.path.join(LIBDIR, "libwbcqp_stamps.so")
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out  # (built by __graft_entry__.build() here; it travels to the GPU box with the tree)
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-ffp-contract=on",
            "-DWBCQP_STAMPS", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out, "-ldl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_poison(verbose: bool = False, force: bool = False) -> str:
+    """Diagnostic library whose compact kernel fills its whole LDS block with signalling garbage (a NaN pattern) before the QP is loaded
+    (-DWBCQP_POISON_LDS): a read of LDS the kernel never wrote, or wrote from another wave without a barrier in between, shows up as a result
+    that differs from the product library's.  tests/test_gpu_layout_variants.py runs the layout branches through it (never the library tests
+    or bench load otherwise)."""
+    out = os.path.join(LIBDIR, "libwbcqp_poison.so")
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-ffp-contract=on",
+           "-DWBCQP_POISON_LDS=0x7ff4dead7ff4beefLL", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out, "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -217,5 +238,7 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--stamps" in sys.argv:
         print(build_stamps(verbose=True))
+    if "--poison" in sys.argv:
+        print(build_poison(verbose=True))
     if "--host" in sys.argv:
         print(build_host(verbose=True))

@@ -449,7 +449,8 @@ class Handle:
         self._check(self.lib.wbcqp_rollout(self._h, slot, batch, n_ticks, C.byref(io), C.c_void_p(stream)))
 
     def tick_host(self, slot: int, q: np.ndarray, v: np.ndarray, ref: np.ndarray, tlb, tub, w, dt: float, want_rows: bool = False):
-        """One whole tick with host arrays (wbcqp_tick_host): returns dict(x, tau, status, iters, q_next, v_next, q_solver[, rows])."""
+        """One whole tick with host arrays (wbcqp_tick_host): returns dict(x, tau, status, iters, objective, n_active, active_mask, q_next, v_next,
+        q_solver, momentum[, rows])."""
         st = self._structs[slot]
         L = st.field_lengths()
         f = lambda a: np.ascontiguousarray(a, dtype=self.np_dtype)
@@ -472,7 +473,9 @@ class Handle:
             cin.tlb, cin.tub = tlb.ctypes.data, tub.ctypes.data
         cin.w = w.ctypes.data
         io.rows = cin
-        io.out = COutputs(out["x"].ctypes.data, out["tau"].ctypes.data, out["status"].ctypes.data, out["iters"].ctypes.data, None, None)
+        out.update(objective=np.zeros(B, self.np_dtype), n_active=np.zeros(B, np.int32), active_mask=np.zeros((B, 8), np.uint32))
+        io.out = COutputs(out["x"].ctypes.data, out["tau"].ctypes.data, out["status"].ctypes.data, out["iters"].ctypes.data,
+                          out["objective"].ctypes.data, out["n_active"].ctypes.data, out["active_mask"].ctypes.data)
         io.q_next, io.v_next, io.q_solver, io.dt = out["q_next"].ctypes.data, out["v_next"].ctypes.data, out["q_solver"].ctypes.data, float(dt)
         self._check(self.lib.wbcqp_tick_host(self._h, slot, B, C.byref(io)))
         out["tau"] = out["tau"][:, :st.na]
@@ -521,8 +524,9 @@ class Handle:
             setattr(cin, k, a.ctypes.data)
         out = dict(x=np.zeros((batch, st.n), self.np_dtype), tau=np.zeros((batch, max(st.na, 1)), self.np_dtype),
                    status=np.full(batch, -99, np.int32), iters=np.zeros(batch, np.int32),
-                   objective=np.zeros(batch, self.np_dtype), n_active=np.zeros(batch, np.int32))
-        cout = COutputs(*[out[k].ctypes.data for k in ("x", "tau", "status", "iters", "objective", "n_active")])
+                   objective=np.zeros(batch, self.np_dtype), n_active=np.zeros(batch, np.int32),
+                   active_mask=np.zeros((batch, 8), np.uint32))  # (in/out: zeros = no warm-start hint; out = the solution's active rows)
+        cout = COutputs(*[out[k].ctypes.data for k in ("x", "tau", "status", "iters", "objective", "n_active", "active_mask")])
         self._check(self.lib.wbcqp_solve_batch_host(self._h, slot, batch, C.byref(cin), C.byref(cout)))
         out["tau"] = out["tau"][:, :st.na]
         return out

@@ -75,8 +75,9 @@ struct OrderState {
 };
 
 constexpr size_t kMaxQueues = 16;
-constexpr int kQueueMinLds = 40 * 1024; // workgroups at least this large take their QPs from the queue by default (40-54 KB: three per CU through
-                                        // solve_queue3_kernel; the dispatcher's solve_kernel holds two)
+constexpr int kQueueMinLds = 48 * 1024; // workgroups at least this large take their QPs from the queue by default (measured: below it the dispatcher wins, launch())
+constexpr int kQueue3MinLds = 40 * 1024; // ... and from 40 KB on where the launch runs three per CU through solve_queue3_kernel (the dispatcher's solve_kernel holds
+                                         // two); a 40-48 KB stack that cannot take the twin (actuation bounds, warm start) stays with the dispatcher
 constexpr int kLdsThree = 54592;        // the largest dynamic LDS block of which a CU holds three (tools/ubench/lds_granule.hip)
 constexpr int kOrderRefresh = 4; // default period of the launch-order renewal (WBCQP_FLAG_REFRESH)
 
@@ -110,6 +111,8 @@ struct wbcqp_handle {
     wbcqp_dense_output dense_out{};
     int lds_pad = 0; // diagnostic (env WBCQP_DEBUG_LDS_PAD): extra dynamic LDS per workgroup, to force a lower residency
     int queue_lds[2 + kNumSpecs], queue_occ[2 + kNumSpecs] = {}; // occupancy of solve_queue_kernel<., CP, SPEC> at queue_lds bytes of LDS
+    int queue_occ_warm[2 + kNumSpecs] = {};                      // ... of solve_queue_kernel_warm<., SPEC> (WBCQP_FLAG_WARM_START launches that kernel)
+    bool debug_launch = false;                                   // env WBCQP_DEBUG_LAUNCH, read once at wbcqp_create (never on the per-tick path)
     int queue_occ3[2 + kNumSpecs] = {};                          // ... of solve_queue3_kernel<., SPEC> where queue_three says it holds three
     bool warned_occupancy = false;                               // the one-time note of launch() when the runtime's occupancy answer is overruled
     bool queue_three[2 + kNumSpecs] = {};                        // ... and whether solve_queue3_kernel<., SPEC> holds three workgroups per CU at that size
@@ -349,7 +352,7 @@ void set_lds(wbcqp_layout& L, int lds_bytes, bool compact, bool act_bounds)
     // registers: the solve kernels allocate up to 256 VGPRs = two waves per SIMD = two workgroups per CU; the compact layout has a twin compiled
     // for three (solve_queue3_kernel), taken when three workgroups fit the CU's LDS: measured (tools/ubench/lds_granule.hip) the third one fits
     // up to 54 592 bytes of dynamic LDS beside the kernel's static word -- no coarser granule than 16 bytes (the launch asks the runtime itself)
-    const int cap = (compact && !act_bounds && lds_bytes >= kQueueMinLds && lds_bytes <= kLdsThree) ? 3 : 2; // (below kQueueMinLds: solve_kernel, two per CU;
+    const int cap = (compact && !act_bounds && lds_bytes >= kQueue3MinLds && lds_bytes <= kLdsThree) ? 3 : 2; // (below kQueueMinLds: solve_kernel, two per CU;
                                                                                                            //  with actuation bounds three per CU measured slower: kThree)
     if (L.waves_per_cu > cap) L.waves_per_cu = cap;
 }
@@ -482,33 +485,48 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
     // batch size).  Small QPs (Franka: 26 KB of LDS) give the dispatcher slack -- measured 27 M QP/s through the queue
     // against 36 M through the hardware.  WBCQP_FLAG_QUEUE forces the queue, WBCQP_FLAG_HW_DISPATCH the dispatcher.
     if (h->queue_lds[V] != lds_bytes) {
-        int occ = 0;
-        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, solve_queue_kernel<TI, CP, SPEC>, kThreads, (size_t)lds_bytes));
-        if (occ < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel: no workgroup fits a CU");
-        // What the CU admits by the measured rule -- k workgroups while k (lds + 16) <= 160 KB (tools/ubench/lds_granule.hip) -- and the kernels' registers (two
-        // waves per SIMD).  A runtime that answers less is not believed: seen when a process holds TWO HIP runtimes (the library loaded before torch: the
-        // first one then answers 1 for every kernel, tools/occ_state_probe.py); the dispatcher places workgroups by the hardware's rules either way, and
-        // workgroups that do not fit wait their turn.
-        const int lds_fit = (160 * 1024) / (lds_bytes + 16);
-        const int want = std::min(lds_fit, 2);
+        // Resident workgroups per CU of the kernel that will be launched: the runtime's answer, checked against what THIS kernel's own resources admit on
+        // the device the handle is bound to (wbcqp_create accepts gfx950 only): k workgroups while k (lds + 16) <= 160 KB (measured, tools/ubench/lds_granule.hip)
+        // and k waves per SIMD while k x (its allocated VGPRs, 8-register granule) <= 512 -- both read from the kernel itself (hipFuncGetAttributes), not from a
+        // constant.  A runtime that answers LESS than both admit is not believed: seen when a process holds TWO HIP runtimes (the library loaded before torch:
+        // the first one then answers 1 for every kernel, tools/occ_state_probe.py); workgroups that do not fit wait their turn, results never depend on it.
+        // An answer below the rule for any other reason (registers grown in a variant build, WBCQP_DEBUG_LDS_PAD) moves the rule with it and is kept.
         bool distrust = false;
-        if (occ < want && h->lds_pad == 0) {
-            distrust = true;
-            occ = want;
-        }
+        auto resident_of = [&](const void* kernel, const char* what, int cap, int& occ_out) -> int {
+            int occ = 0;
+            HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kThreads, (size_t)lds_bytes));
+            hipFuncAttributes fa{};
+            HIP_TRY(h, hipFuncGetAttributes(&fa, kernel));
+            const int regs = std::max(8, (fa.numRegs + 7) & ~7);
+            const int admitted = std::min({(160 * 1024) / (lds_bytes + 16), 512 / regs, cap}); // (+ 16: the granule and the kernel's static word, as measured)
+            if (occ < admitted && h->lds_pad == 0) {
+                distrust = true;
+                occ = admitted;
+            }
+            if (h->debug_launch)
+                std::fprintf(stderr, "wbcqp occupancy: %s lds %d B (+ %d static) VGPRs %d -> %d per CU%s\n", what, lds_bytes, (int)fa.sharedSizeBytes, fa.numRegs, occ,
+                             distrust ? " (runtime answered less)" : "");
+            occ_out = occ;
+            return WBCQP_OK;
+        };
+        int occ = 0;
+        if (int rc = resident_of(reinterpret_cast<const void*>(&solve_queue_kernel<TI, CP, SPEC>), "solve_queue_kernel", 2, occ); rc != WBCQP_OK) return rc;
+        if (occ < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel: no workgroup fits a CU");
         h->queue_occ[V] = occ;
+        h->queue_occ_warm[V] = occ;
+        if constexpr (kWarm<CP, SPEC>) { // the warm start's twin is a register allocation of its own: its occupancy, not its sibling's
+            int occw = 0;
+            if (int rc = resident_of(reinterpret_cast<const void*>(&solve_queue_kernel_warm<TI, SPEC>), "solve_queue_kernel_warm", 2, occw); rc != WBCQP_OK) return rc;
+            if (occw < 1) return fail(h, WBCQP_ERR_HIP, "solve_queue_kernel_warm: no workgroup fits a CU");
+            h->queue_occ_warm[V] = occw;
+        }
         h->queue_lds[V] = lds_bytes;
         h->queue_three[V] = false;
-        // a workgroup small enough for three on a CU takes the kernel compiled for three waves per SIMD (wbcqp_device.hpp: solve_queue3_kernel);
-        // the runtime, not a formula, says whether three fit (LDS granule, the static word beside the dynamic block)
+        // a workgroup small enough for three on a CU takes the kernel compiled for three waves per SIMD (wbcqp_device.hpp: solve_queue3_kernel)
         if constexpr (kThree<CP, SPEC>) {
-            if (lds_bytes * 3 <= 160 * 1024 && h->lds_pad == 0) {
+            if (lds_bytes <= kLdsThree && h->lds_pad == 0) {
                 int occ3 = 0;
-                HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, solve_queue3_kernel<TI, SPEC>, kThreads, (size_t)lds_bytes));
-                if (occ3 < 3 && lds_bytes <= kLdsThree) {
-                    distrust = true;
-                    occ3 = 3;
-                }
+                if (int rc = resident_of(reinterpret_cast<const void*>(&solve_queue3_kernel<TI, SPEC>), "solve_queue3_kernel", 3, occ3); rc != WBCQP_OK) return rc;
                 if (occ3 >= 3) {
                     h->queue_three[V] = true;
                     h->queue_occ3[V] = occ3;
@@ -517,7 +535,7 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         }
         if (distrust && !h->warned_occupancy) {
             h->warned_occupancy = true;
-            std::fprintf(stderr, "wbcqp: the HIP runtime reports fewer resident workgroups per CU than LDS (%d B) and registers admit; launching %d per CU anyway. "
+            std::fprintf(stderr, "wbcqp: the HIP runtime reports fewer resident workgroups per CU than LDS (%d B) and the kernel's registers admit; launching %d per CU anyway. "
                                  "Two HIP runtimes in this process (libwbcqp.so loaded before torch)?  See INTEGRATION.md.\n", lds_bytes,
                          h->queue_three[V] ? h->queue_occ3[V] : h->queue_occ[V]);
         }
@@ -530,12 +548,12 @@ int launch(wbcqp_handle* h, GroupTable<TI>& tab, int total, int lds_bytes, hipSt
         three = h->queue_three[V] && !warm;
         for (int g = 0; g < tab.n; ++g) three = three && !tab.g[g].st.act_bounds;
     }
-    const int queue_occ = three ? h->queue_occ3[V] : h->queue_occ[V];
-    if (std::getenv("WBCQP_DEBUG_LAUNCH"))
+    const int queue_occ = three ? h->queue_occ3[V] : (warm ? h->queue_occ_warm[V] : h->queue_occ[V]);
+    if (h->debug_launch)
         std::fprintf(stderr, "wbcqp launch: V %d spec %d total %d lds %d occupancy %d three %d n_cu %d flags 0x%x\n", V, SPEC, total, lds_bytes, queue_occ, (int)three,
                      h->n_cu, (unsigned)h->flags);
     int* queue = nullptr;
-    if (osp && !(h->flags & WBCQP_FLAG_HW_DISPATCH) && (lds_bytes >= kQueueMinLds || (h->flags & WBCQP_FLAG_QUEUE))) {
+    if (osp && !(h->flags & WBCQP_FLAG_HW_DISPATCH) && (lds_bytes >= kQueueMinLds || (three && lds_bytes >= kQueue3MinLds) || (h->flags & WBCQP_FLAG_QUEUE))) {
         if (!os.queue && !h->graph_ord) {
             HIP_TRY(h, hipMalloc(&os.queue, 2 * sizeof(int)));
             HIP_TRY(h, hipMemset(os.queue, 0, 2 * sizeof(int)));
@@ -691,6 +709,7 @@ int wbcqp_create(const wbcqp_desc* desc, wbcqp_handle** out)
     h->n_cu = prop.multiProcessorCount;
     for (int& q : h->queue_lds) q = -1;
     if (const char* pad = std::getenv("WBCQP_DEBUG_LDS_PAD")) h->lds_pad = std::atoi(pad);
+    h->debug_launch = std::getenv("WBCQP_DEBUG_LAUNCH") != nullptr;
     *out = h;
     return WBCQP_OK;
 }
@@ -1810,7 +1829,8 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     for (int f = 0; f < NR; ++f) { roff[f] = in_bytes; in_bytes += al((size_t)rlen[f] * B * es); }
     const size_t o_x = 0, o_tau = o_x + al((size_t)L.n * B * es), o_obj = o_tau + al((size_t)s.host.na * B * es), o_st = o_obj + al(B * es),
                  o_it = o_st + al(B * 4), o_na = o_it + al(B * 4), o_qn = o_na + al(B * 4), o_vn = o_qn + al((size_t)T.nq * B * es),
-                 o_qs = o_vn + al((size_t)T.nv * B * es), o_mom = o_qs + al((size_t)T.nv * B * es), out_bytes = o_mom + al((size_t)6 * B * es);
+                 o_qs = o_vn + al((size_t)T.nv * B * es), o_mom = o_qs + al((size_t)T.nv * B * es), o_am = o_mom + al((size_t)6 * B * es),
+                 out_bytes = o_am + (io->out.active_mask ? al(B * 32) : 0);
     int rc = ensure(h, h->stage_in, in_bytes + 256);
     if (rc != WBCQP_OK) return rc;
     rc = ensure(h, h->stage_out, out_bytes + 256);
@@ -1840,6 +1860,10 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     d.out.x = dout + o_x; d.out.tau = dout + o_tau; d.out.objective = dout + o_obj;
     d.out.status = reinterpret_cast<int32_t*>(dout + o_st); d.out.iters = reinterpret_cast<int32_t*>(dout + o_it);
     d.out.n_active = reinterpret_cast<int32_t*>(dout + o_na);
+    if (io->out.active_mask) { // in/out like wbcqp_solve_batch_host: the hint goes up (zeros: none), the solution's active rows come back
+        d.out.active_mask = reinterpret_cast<uint32_t*>(dout + o_am);
+        HIP_TRY(h, hipMemcpyAsync(d.out.active_mask, io->out.active_mask, B * 32, hipMemcpyHostToDevice, nullptr));
+    }
     d.q_next = dout + o_qn; d.v_next = dout + o_vn; d.q_solver = io->q_solver ? dout + o_qs : nullptr;
     d.dt = io->dt;
     rc = wbcqp_tick(h, slot, batch, &d, nullptr);
@@ -1856,6 +1880,7 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
         std::memcpy(io->out.iters, po + o_it, B * 4);
         if (io->out.objective) std::memcpy(io->out.objective, po + o_obj, B * es);
         if (io->out.n_active) std::memcpy(io->out.n_active, po + o_na, B * 4);
+        if (io->out.active_mask) std::memcpy(io->out.active_mask, po + o_am, B * 32);
         std::memcpy(io->q_next, po + o_qn, (size_t)T.nq * B * es);
         std::memcpy(io->v_next, po + o_vn, (size_t)T.nv * B * es);
         if (io->q_solver) std::memcpy(io->q_solver, po + o_qs, (size_t)T.nv * B * es);
@@ -1868,6 +1893,7 @@ int wbcqp_tick_host(wbcqp_handle* h, int slot, int batch, const wbcqp_tick_io* i
     HIP_TRY(h, hipMemcpyAsync(io->out.iters, d.out.iters, B * 4, hipMemcpyDeviceToHost, nullptr));
     if (io->out.objective) HIP_TRY(h, hipMemcpyAsync(io->out.objective, d.out.objective, B * es, hipMemcpyDeviceToHost, nullptr));
     if (io->out.n_active) HIP_TRY(h, hipMemcpyAsync(io->out.n_active, d.out.n_active, B * 4, hipMemcpyDeviceToHost, nullptr));
+    if (io->out.active_mask) HIP_TRY(h, hipMemcpyAsync(io->out.active_mask, d.out.active_mask, B * 32, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipMemcpyAsync(io->q_next, d.q_next, (size_t)T.nq * B * es, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(h, hipMemcpyAsync(io->v_next, d.v_next, (size_t)T.nv * B * es, hipMemcpyDeviceToHost, nullptr));
     if (io->q_solver) HIP_TRY(h, hipMemcpyAsync(io->q_solver, d.q_solver, (size_t)T.nv * B * es, hipMemcpyDeviceToHost, nullptr));

@@ -877,7 +877,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         // rounding) at fct + e fst.  With enough equalities they sit in J itself (cp::fric_in_j): columns 2..13 of row e, or 2..7 of rows 2 e and 2 e + 1 --
         // equality columns the loop never reads (columns 0-1 may be the pad pair of the row before); otherwise behind the rotation table in the R region.
         const int fric_mode = cp::fric_in_j(n, neq, nc);
-        double* const fct = fric_mode ? c.J + 2 : prm + 4 * (MM + 2);
+        // (R region: two doubles behind the table's end -- the zeroing loop below runs that far, in the same barrier-free phase as the owners' stores
+        // of the coefficients, from other waves; derive_compact's `need` holds the + 2)
+        double* const fct = fric_mode ? c.J + 2 : prm + 4 * (MM + 2) + 2;
         const int fst = fric_mode == 1 ? ldj : (fric_mode == 2 ? 2 * ldj : 12); // entry to entry
         const int fh = fric_mode == 2 ? ldj : 6;                                 // coefficient m of an entry at (m / 6) fh + m % 6
         double* const Wp = lds + D.o_vec + vm.PW;    // pending update: J(:, pc:) <- J(:, pc:) - w v(pc:)'; w = 0 when there is none

@@ -52,7 +52,8 @@ class _BatchInputs(C.Structure):
 
 
 class _BatchOutputs(C.Structure):
-    _fields_ = [("x", c_double_p), ("tau", c_double_p), ("status", c_int_p), ("iters", c_int_p)]
+    _fields_ = [("x", c_double_p), ("tau", c_double_p), ("status", c_int_p), ("iters", c_int_p),
+                ("active", c_int_p), ("n_active", c_int_p), ("fval", c_double_p)]
 
 
 def build(force: bool = False) -> str:
@@ -211,17 +212,36 @@ def eiquadprog_timed(H, g, CE, ce0, CI, ci0, reps: int = 200, max_iter: int = 10
     return float(secs) / max(1, reps), st.value, it.value
 
 
+ACTIVE_PAD = np.iinfo(np.int32).min  # entries of `active` beyond n_active
+
+
+def active_to_mask(active: np.ndarray, n_active: np.ndarray, words: int = 8) -> np.ndarray:
+    """eiquadprog's active list -> the C ABI's wbcqp_outputs.active_mask ([B, 8] uint32): bit r of the 256-bit mask set iff the
+    one-sided CI row r (a tag >= 0) is in A[0 .. n_active); equalities (tags < 0) have no bit, rows beyond the 256th neither."""
+    B = active.shape[0]
+    m = np.zeros((B, words), np.uint32)
+    for i in range(B):
+        a = active[i, :n_active[i]]
+        a = a[(a >= 0) & (a < 32 * words)]
+        np.bitwise_or.at(m[i], a >> 5, (np.uint32(1) << (a & 31).astype(np.uint32)))
+    return m
+
+
 def tick_batch(st, inputs: Dict[str, np.ndarray], nthreads: int = 1):
-    """P1..P4 for every QP of a [B, len] input set. Returns dict(x, tau, status, iters)."""
+    """P1..P4 for every QP of a [B, len] input set. Returns dict(x, tau, status, iters, active, n_active, fval, active_mask):
+    `active` [B, neq + nin2] is eiquadprog's A (equality i tagged -i-1, else the one-sided CI row), padded with ACTIVE_PAD
+    beyond n_active; `active_mask` the same set in the C ABI's form; `fval` the objective."""
     ost = OracleStructure(st)
     batch = np.asarray(inputs["h"]).reshape(-1, st.nv).shape[0]
     arrs = _prep_inputs(st, inputs, batch)
     x = np.zeros((batch, st.n)); tau = np.zeros((batch, max(st.na, 1)))
     status = np.zeros(batch, np.int32); iters = np.zeros(batch, np.int32)
+    active = np.full((batch, max(st.neq + st.nin2, 1)), ACTIVE_PAD, np.int32); n_active = np.zeros(batch, np.int32); fval = np.zeros(batch)
     bin_ = _BatchInputs(*[_dp(arrs[k]) for k in _FIELDS])
-    bout = _BatchOutputs(_dp(x), _dp(tau), _ip(status), _ip(iters))
+    bout = _BatchOutputs(_dp(x), _dp(tau), _ip(status), _ip(iters), _ip(active), _ip(n_active), _dp(fval))
     lib().wbco_tick_batch(C.byref(ost.c), int(batch), C.byref(bin_), C.byref(bout), int(nthreads))
-    return dict(x=x, tau=tau[:, :st.na], status=status, iters=iters)
+    return dict(x=x, tau=tau[:, :st.na], status=status, iters=iters, active=active, n_active=n_active, fval=fval,
+                active_mask=active_to_mask(active, n_active))
 
 
 def tick_batch_timed(st, inputs: Dict[str, np.ndarray], nthreads: int = 1, reps: int = 1, native: bool = False):
@@ -233,7 +253,7 @@ def tick_batch_timed(st, inputs: Dict[str, np.ndarray], nthreads: int = 1, reps:
     x = np.zeros((batch, st.n)); tau = np.zeros((batch, max(st.na, 1)))
     status = np.zeros(batch, np.int32); iters = np.zeros(batch, np.int32)
     bin_ = _BatchInputs(*[_dp(arrs[k]) for k in _FIELDS])
-    bout = _BatchOutputs(_dp(x), _dp(tau), _ip(status), _ip(iters))
+    bout = _BatchOutputs(_dp(x), _dp(tau), _ip(status), _ip(iters), None, None, None)
     f = (native_lib() if native else lib()).wbco_tick_batch_timed
     f.restype = C.c_double
     secs = f(C.byref(ost.c), int(batch), C.byref(bin_), C.byref(bout), int(nthreads), int(reps))

@@ -781,11 +781,13 @@ static void* batch_worker(void* arg)
             out.x = first ? job->out->x + (size_t)i * n : sx;
             out.tau = first ? job->out->tau + (size_t)i * na : stau;
             out.lambda = NULL;
-            out.active = NULL;
+            out.active = (first && job->out->active) ? job->out->active + (size_t)i * (neq + nin2) : NULL;
             wbco_tick(st, &in, &out, ws);
             if (first) {
                 job->out->status[i] = out.status;
                 job->out->iters[i] = out.iters;
+                if (job->out->n_active) job->out->n_active[i] = out.n_active;
+                if (job->out->fval) job->out->fval[i] = out.fval;
             }
         }
     }

@@ -151,6 +151,13 @@ typedef struct {
 typedef struct {
     double *x, *tau;
     int *status, *iters;
+    /* the rest of HQPOutput (may each be NULL): the final active set in eiquadprog's convention -- A[0 .. n_active): equality i
+     * tagged -i-1, otherwise the index of the one-sided CI row (SolverHQuadProgFast stacks a two-sided block of m rows as
+     * rows [k, k+m) = A (lower side), [k+m, k+2m) = -A (upper side)); entries beyond n_active are left untouched --
+     * HQPOutput::activeSet, and getObjectiveValue (pos_tracker.hpp:44). */
+    int* active;   /* [batch][neq + nin2] */
+    int* n_active; /* [batch] */
+    double* fval;  /* [batch] 0.5 x'Hx + g'x */
 } wbco_batch_outputs;
 /* reps passes over the batch on nthreads threads (work handed out from one counter, per-thread workspace, no allocation
  * per QP); returns the seconds from the moment every thread stands at the start line to the last thread's end (< 0: error).

@@ -33,3 +33,18 @@ def oracle_mod():
     from oracle import oracle
     oracle.build()
     return oracle
+
+
+def pytest_terminal_summary(terminalreporter):
+    """The figures tests/util.py:assert_parity measured in this session, one line per case: the bars bound them, this prints them (raw contact-point
+    forces in particular: bounded at 1e-4, reported here; active sets: share of QPs whose set equals the oracle's bit for bit)."""
+    from tests import util
+    if not util.MEASURED:
+        return
+    tr = terminalreporter
+    tr.section("parity figures measured against the oracle (tests/util.py:assert_parity)")
+    for what, info in util.MEASURED:
+        tr.write_line("%-58s dv %.1e  wrench %.1e  tau %.1e  raw f %.1e  iters= %.3f  active set= %s (%s checked)  objective %s" % (
+            what[:58], info.get("max_rel_dv", 0.0), info.get("max_rel_wrench", 0.0), info.get("max_rel_tau", 0.0), info.get("max_rel_raw_force", 0.0),
+            info.get("iters_equal", 1.0), ("%.3f" % info["active_set_equal_frac"]) if "active_set_equal_frac" in info else "-",
+            info.get("active_set_checked", "-"), ("%.1e" % info["max_rel_objective"]) if "max_rel_objective" in info else "-"))

@@ -37,7 +37,10 @@ def main():
         tag = "%s_n%g" % (name, noise)
         path = os.path.join(HERE, tag + ".npz")
         np.savez_compressed(path, **{"in_" + k: v for k, v in inp.items()}, x=out["x"], tau=out["tau"],
-                            status=out["status"], iters=out["iters"], task_noise=noise)
+                            status=out["status"], iters=out["iters"], task_noise=noise,
+                            # HQPOutput's other members ("identical active set"): eiquadprog's A (equality i tagged -i-1, else the
+                            # one-sided CI row; padded with INT32_MIN beyond n_active), the same set as the C ABI's 256-bit mask, the objective
+                            active=out["active"], n_active=out["n_active"], active_mask=out["active_mask"], fval=out["fval"])
         print("wrote", path, "iters", out["iters"].tolist())
 
 

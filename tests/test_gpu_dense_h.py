@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from inria_wbc_amd import structure, synth
-from tests.util import assert_parity
+from tests.util import assert_parity, device_outputs, host_outputs
 
 pytestmark = pytest.mark.gpu
 
@@ -111,13 +111,12 @@ def test_device_pointers_ragged_launch_with_a_dense_h_group(handle, oracle_mod):
         refs.append(oracle_mod.tick_batch(st, inp, nthreads=4))
         h.set_structure(gi, st)
         d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items() if v.size}
-        d_out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, st.na, dtype=torch.float64, device=dev),
-                     status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+        d_out = device_outputs(B, st, dev)
         groups.append((gi, B, d_in, d_out))
         outs.append(d_out)
     for _ in range(3):  # the second and third launch run in the order the first left
         h.solve_ragged(groups, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     for st, ref, o in zip(sts, refs, outs):
-        assert_parity(st, {k: v.cpu().numpy() for k, v in o.items()}, ref, what=st.name)
+        assert_parity(st, host_outputs(o, st), ref, what=st.name)
     h.close()

@@ -1,12 +1,14 @@
 """The compact layout's branches that no shipped stack takes together (csrc/wbcqp_api.hip: derive_compact; csrc/wbcqp_compact.hpp: cp::vec_map,
 cp::fric_in_j): 64-entry vector slots WITH the actuation-bound slots, an odd n (rows of J padded, not aliased), n = 2 mod 4 with fewer than fourteen
-equalities (rows aliased on the next row's dead columns, the friction table in the R region), n = 0 mod 4 (padded rows, friction table in J).  Each
+equalities (rows aliased on the next row's dead columns, the friction table over two rows of J per entry), n = 0 mod 4 (padded rows, friction table in J),
+and a small floating-base stack on one contact (n = 30 < 34: cp::fric_in_j == 0, the friction table BEHIND THE ROTATION TABLE IN THE R REGION -- the
+branch whose first two coefficients once shared two doubles with the loop's zeroing pass), with and without actuation bounds.  Each
 stack runs the generic compact kernel -- through the queue, three per CU where it fits -- against the oracle and against round 1's full layout
 (WBCQP_FLAG_FULL_LDS), which shares none of these branches.  The reference contract is the same one as everywhere: controller.cpp:244-251."""
 import numpy as np
 import pytest
 
-from tests.util import assert_parity
+from tests.util import assert_parity, device_outputs, host_outputs
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +25,9 @@ def _stack(name, nv, na, n_contacts, act):
 
 CASES = [("slots64_with_actuation", 38, 32, 2, True),      # n 62 (aliased rows, table in J), VS 64, TL / TU present
          ("odd_n", 37, 31, 2, False),                      # n 61: padded rows
-         ("one_contact_aliased", 38, 32, 1, True),          # n 50 = 2 mod 4, nEq 12: aliased rows, table in the R region
+         ("one_contact_aliased", 38, 32, 1, True),          # n 50 = 2 mod 4, nEq 12: aliased rows, table in columns 2..7 of two rows of J per entry
+         ("table_in_r_region", 18, 12, 1, False),           # n 30 = 2 mod 4, nEq 12, n < 34 nc: cp::fric_in_j == 0, the table behind the rotation table
+         ("table_in_r_region_act", 18, 12, 1, True),        # ... with actuation bounds
          ("n_multiple_of_four", 40, 34, 2, False),          # n 64: padded rows, 80-entry slots, table in J
          ("one_contact_padded", 40, 34, 1, False)]          # n 52 = 0 mod 4, nEq 12
 
@@ -36,12 +40,12 @@ def _solve(st, inputs, flags):
     d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
     h = capi.Handle(0, capi.F64, flags=flags)
     h.set_structure(0, st)
-    o = dict(x=torch.full((B, st.n), float("nan"), dtype=torch.float64, device=dev), tau=torch.full((B, st.na), float("nan"), dtype=torch.float64, device=dev),
-             status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.full((B,), -1, dtype=torch.int32, device=dev))
+    o = device_outputs(B, st, dev)
+    o["x"].fill_(float("nan")); o["tau"].fill_(float("nan")); o["iters"].fill_(-1); o["active_mask"].fill_(-1); o["n_active"].fill_(-1)
     h.solve_batch(0, B, d_in, o, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     h.close()
-    return {k: v.cpu().numpy() for k, v in o.items()}
+    return host_outputs(o, st)
 
 
 @pytest.mark.parametrize("name,nv,na,nc,act", CASES)
@@ -58,7 +62,8 @@ def test_layout_branches_against_the_oracle_and_the_full_layout(oracle_mod, name
     ref = oracle_mod.tick_batch(st, inputs)
     assert (ref["status"] == 0).mean() > 0.9 and ref["iters"].max() >= 8, (name, ref["iters"].max())
     assert_parity(st, got, ref, what=name)
-    for k in ("x", "tau", "status", "iters"):
+    assert_parity(st, full, ref, what=name + " (full layout)")  # round 1's kernel: its own active_mask / objective against the oracle's too
+    for k in ("x", "tau", "status", "iters", "objective", "n_active", "active_mask"):
         assert np.array_equal(got[k], two[k], equal_nan=True), (name, k)  # the queue (two or three per CU) and the dispatcher: same bits
     assert np.array_equal(got["status"], full["status"])
     ok = got["status"] == 0
@@ -67,3 +72,28 @@ def test_layout_branches_against_the_oracle_and_the_full_layout(oracle_mod, name
     # iteration counts: equal on most QPs; on draws this hard (tens of picks per QP) two near-tied picks may swap -- the measured floor of such batches is
     # 0.82 (tests/stress/stress_parity.py, profiles/r05/v33_stress_parity.txt), 0.885 on the hardest case here
     assert (got["iters"] == ref["iters"]).mean() >= 0.8
+
+
+def test_poisoned_lds_build_gives_the_same_bits(tmp_path):
+    """The compact kernel reads no LDS word it did not write itself behind a barrier: the build that fills the QP's whole LDS block with a NaN pattern
+    first (-DWBCQP_POISON_LDS, inria_wbc_amd/build.py:build_poison) must give the product library's bits on every layout branch above -- the R-region
+    friction table included, whose first two coefficients the loop's zeroing pass once overwrote from another wave -- and on the shipped
+    humanoid stacks, through the queue, the hardware dispatcher and the generic kernel.  One process per library."""
+    import os
+    import subprocess
+    import sys
+    from inria_wbc_amd import build
+    build.build()
+    build.build_poison()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name in ("libwbcqp.so", "libwbcqp_poison.so"):
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "chk_variants.py"), name, path], cwd=root)
+        outs[name] = np.load(path)
+    prod, pois = outs["libwbcqp.so"], outs["libwbcqp_poison.so"]
+    assert sorted(prod.files) == sorted(pois.files) and len(prod.files) >= 10 * 3 * 7
+    for k in prod.files:
+        assert np.array_equal(prod[k], pois[k], equal_nan=True), k
+        if k.endswith("/status"):
+            assert (prod[k] == 0).mean() > 0.9, k

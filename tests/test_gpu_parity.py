@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from inria_wbc_amd import structure, synth
-from tests.util import TOL_F64, assert_parity, load_golden
+from tests.util import TOL_F64, assert_parity, device_outputs, host_outputs, load_golden, mask_of
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +26,7 @@ def test_golden_fixtures(handle, case):
     fname, st, inputs, z = case
     handle.set_structure(0, st)
     got = handle.solve_batch_host(0, inputs)
-    ref = dict(x=z["x"], tau=z["tau"], status=z["status"], iters=z["iters"])
+    ref = {k: z[k] for k in ("x", "tau", "status", "iters", "active_mask", "n_active", "fval")}  # (the committed files hold the oracle's active sets too)
     info = assert_parity(st, got, ref, what=fname)
     # measured (tools/iters_floor.py, profiles/r04/iters_floor.txt): every golden QP takes the oracle's iteration count except one of
     # the six of talos_n5 (a tie broken by rounding); the bar is the measured count plus one QP
@@ -128,19 +128,14 @@ def test_device_pointer_path_and_ragged(handle, oracle_mod):
         refs.append((st, oracle_mod.tick_batch(st, inputs)))
         handle.set_structure(8 + slot, st)
         dev_in = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in inputs.items() if v.size}
-        dev_out = dict(x=torch.zeros(batch, st.n, dtype=torch.float64, device="cuda"),
-                       tau=torch.zeros(batch, max(st.na, 1), dtype=torch.float64, device="cuda"),
-                       status=torch.full((batch,), -99, dtype=torch.int32, device="cuda"),
-                       iters=torch.zeros(batch, dtype=torch.int32, device="cuda"))
+        dev_out = device_outputs(batch, st)
         keep.append((dev_in, dev_out))
         groups.append((8 + slot, batch, dev_in, dev_out))
     stream = torch.cuda.current_stream().cuda_stream
     handle.solve_ragged(groups, stream=stream)
     torch.cuda.synchronize()
     for (st, ref), (_, _, _, dev_out) in zip(refs, groups):
-        got = dict(x=dev_out["x"].cpu().numpy(), tau=dev_out["tau"].cpu().numpy()[:, :st.na],
-                   status=dev_out["status"].cpu().numpy(), iters=dev_out["iters"].cpu().numpy())
-        assert_parity(st, got, ref, what="ragged:" + st.name)
+        assert_parity(st, host_outputs(dev_out, st), ref, what="ragged:" + st.name)
 
 
 def test_empty_batch_and_empty_group_are_no_ops(handle, oracle_mod):
@@ -163,15 +158,13 @@ def test_empty_batch_and_empty_group_are_no_ops(handle, oracle_mod):
     inputs = synth.generate(st, batch, synth.SEED_BASE["talos"] + 77, task_noise=1.0)
     ref = oracle_mod.tick_batch(st, inputs)
     dev_in = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in inputs.items() if v.size}
-    dev_out = dict(x=torch.zeros(batch, st.n, dtype=torch.float64, device="cuda"), tau=torch.zeros(batch, st.na, dtype=torch.float64, device="cuda"),
-                   status=torch.full((batch,), -99, dtype=torch.int32, device="cuda"), iters=torch.zeros(batch, dtype=torch.int32, device="cuda"))
+    dev_out = device_outputs(batch, st)
     empty_f = {k: torch.zeros(0, v, dtype=torch.float64, device="cuda") for k, v in sf.field_lengths().items() if v}
     empty_out = dict(x=torch.zeros(0, sf.n, dtype=torch.float64, device="cuda"), tau=torch.zeros(0, sf.na, dtype=torch.float64, device="cuda"),
                      status=torch.zeros(0, dtype=torch.int32, device="cuda"), iters=torch.zeros(0, dtype=torch.int32, device="cuda"))
     handle.solve_ragged([(3, 0, empty_f, empty_out), (2, batch, dev_in, dev_out), (3, 0, empty_f, empty_out)], stream=stream)
     torch.cuda.synchronize()
-    got = dict(x=dev_out["x"].cpu().numpy(), tau=dev_out["tau"].cpu().numpy(), status=dev_out["status"].cpu().numpy(), iters=dev_out["iters"].cpu().numpy())
-    assert_parity(st, got, ref, what="ragged with empty groups")
+    assert_parity(st, host_outputs(dev_out, st), ref, what="ragged with empty groups")
 
 
 def test_full_size_properties(handle, oracle_mod):
@@ -382,7 +375,14 @@ def test_full_size_config3_icub_b4096_f32_boundary(built_lib, oracle_mod):
     xs = np.maximum(1.0, np.abs(ref["x"][:, :st.nv]).max(axis=1, keepdims=True))
     assert (np.abs(got["x"][:64, :st.nv] - ref["x"][:, :st.nv]) / xs).max() < 1e-3
     assert np.abs(got["tau"][:64] - ref["tau"]).max() < 1e-3 * max(1.0, np.abs(ref["tau"]).max())
-    assert (got["iters"][:64] == ref["iters"]).mean() >= 0.9
+    same_it = got["iters"][:64] == ref["iters"]
+    assert same_it.mean() >= 0.9
+    # the active set ("active-set mismatches reported" at f32): the solve runs in f64 on the same f32-rounded inputs, so wherever the
+    # iteration counts agree the sets must be the oracle's bit for bit; the objective comes back rounded to f32
+    same_set = (mask_of(got["active_mask"][:64]) == ref["active_mask"]).all(axis=1)
+    assert same_set[same_it].all() and np.array_equal(got["n_active"][:64][same_it], ref["n_active"][same_it])
+    assert (np.abs(got["objective"][:64] - ref["fval"])[same_it] <= 1e-5 * np.maximum(1.0, np.abs(ref["fval"]))[same_it]).all()
+    print("config 3 sample: active sets equal on %d of 64 QPs (iteration counts equal on %d)" % (int(same_set.sum()), int(same_it.sum())))
 
 
 def test_full_size_config5_ragged_b8192(handle, oracle_mod):
@@ -401,16 +401,14 @@ def test_full_size_config5_ragged_b8192(handle, oracle_mod):
         full = {k: np.ascontiguousarray(np.tile(v, (reps, 1))[:cnt]) for k, v in inp.items()}
         handle.set_structure(8 + slot, st)
         d_in = {k: torch.from_numpy(v).cuda() for k, v in full.items() if v.size}
-        d_out = dict(x=torch.zeros(cnt, st.n, dtype=torch.float64, device="cuda"), tau=torch.zeros(cnt, max(st.na, 1), dtype=torch.float64, device="cuda"),
-                     status=torch.full((cnt,), -99, dtype=torch.int32, device="cuda"), iters=torch.zeros(cnt, dtype=torch.int32, device="cuda"))
+        d_out = device_outputs(cnt, st)
         groups.append((8 + slot, cnt, d_in, d_out))
         metas.append((st, full, inp))
     handle.solve_ragged(groups, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert sum(g[1] for g in groups) == 8192
     for (st, full, inp), (_, cnt, _, d_out) in zip(metas, groups):
-        got = dict(x=d_out["x"].cpu().numpy(), tau=d_out["tau"].cpu().numpy()[:, :st.na], status=d_out["status"].cpu().numpy(),
-                   iters=d_out["iters"].cpu().numpy())
+        got = host_outputs(d_out, st)
         assert (got["status"] == 0).all(), st.name
         if st.nc:
             worst_eq, worst_tau = _equality_and_decode_residuals(st, full, got, 97)

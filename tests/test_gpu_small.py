@@ -5,7 +5,7 @@ launch where the small groups go out as a launch of their own beside the humanoi
 import numpy as np
 import pytest
 
-from tests.util import TOL_F64
+from tests.util import TOL_F64, assert_parity, device_outputs, host_outputs
 
 pytestmark = pytest.mark.gpu
 
@@ -21,12 +21,12 @@ def _solve(st, inputs, flags=0, dtype=None):
     d_in = {k: torch.from_numpy(np.ascontiguousarray(v.astype(ndt))).to(dev) for k, v in inputs.items() if v.size}
     h = capi.Handle(0, dtype, flags=flags)
     h.set_structure(0, st)
-    d_out = dict(x=torch.full((B, st.n), float("nan"), dtype=tdt, device=dev), tau=torch.full((B, st.na), float("nan"), dtype=tdt, device=dev),
-                 status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.full((B,), -1, dtype=torch.int32, device=dev))
+    d_out = device_outputs(B, st, dev, dtype=tdt)
+    d_out["x"].fill_(float("nan")); d_out["tau"].fill_(float("nan")); d_out["iters"].fill_(-1); d_out["active_mask"].fill_(-1)
     h.solve_batch(0, B, d_in, d_out, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     h.close()
-    return {k: v.cpu().numpy() for k, v in d_out.items()}
+    return host_outputs(d_out, st)
 
 
 @pytest.mark.parametrize("robot,batch,noise", [("franka", 1, 0.5), ("franka", 7, 0.5), ("franka", 1025, 2.0), ("tiago", 5, 0.5), ("tiago", 258, 2.0),
@@ -45,6 +45,9 @@ def test_wave_per_qp_matches_oracle_and_the_four_wave_kernel(oracle_mod, robot, 
     assert (np.abs(got["tau"] - ref["tau"]).max(axis=1)[ok] <= TOL_F64 * np.maximum(1.0, np.abs(ref["tau"]).max(axis=1))[ok]).all()
     assert (np.abs(got["x"] - wg["x"]).max(axis=1)[ok] <= 1e-9 * scale[ok]).all()
     assert (got["iters"] == ref["iters"]).mean() >= 0.9, (got["iters"][:20], ref["iters"][:20])
+    # the active set (bit r = one-sided CI row r), n_active and the objective of both kernels against eiquadprog's A, iq, f
+    assert_parity(st, got, ref, what="one wavefront per QP: %s B %d noise %g" % (robot, batch, noise))
+    assert_parity(st, wg, ref, what="four waves per QP: %s B %d noise %g" % (robot, batch, noise))
     if robot == "tiago" and noise >= 8.0:
         assert ref["iters"].max() >= 4  # bounds bind: the active-set loop and its drop path are exercised
 
@@ -72,8 +75,8 @@ def test_ragged_launch_sends_small_groups_to_their_own_kernel(oracle_mod):
         st = structure.STRUCTURES[name]()
         inp = synth.generate(st, cnt, synth.SEED_BASE["ragged"] + 31 * slot, task_noise=2.0, p_bnd=0.3)
         d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items() if v.size}
-        d_out = dict(x=torch.full((cnt, st.n), float("nan"), dtype=torch.float64, device=dev), tau=torch.full((cnt, max(st.na, 1)), float("nan"), dtype=torch.float64, device=dev),
-                     status=torch.full((cnt,), -99, dtype=torch.int32, device=dev), iters=torch.full((cnt,), -1, dtype=torch.int32, device=dev))
+        d_out = device_outputs(cnt, st, dev)
+        d_out["x"].fill_(float("nan")); d_out["tau"].fill_(float("nan")); d_out["iters"].fill_(-1)
         h.set_structure(slot, st)
         groups.append((slot, cnt, d_in, d_out))
         refs.append((st, oracle_mod.tick_batch(st, inp)))
@@ -83,6 +86,7 @@ def test_ragged_launch_sends_small_groups_to_their_own_kernel(oracle_mod):
         assert np.array_equal(d_out["status"].cpu().numpy(), ref["status"]), st.name
         x = d_out["x"].cpu().numpy()
         assert np.abs(x[:, :st.nv] - ref["x"][:, :st.nv]).max() <= TOL_F64 * max(1.0, np.abs(ref["x"]).max()), st.name
+        assert_parity(st, host_outputs(d_out, st), ref, what="ragged, small groups on their own kernel: " + st.name)
     h.close()
 
 
@@ -105,3 +109,4 @@ def test_odd_sizes_on_the_four_wave_compact_kernel(oracle_mod, nv):
         scale = np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
         assert (np.abs(got["x"] - ref["x"]).max(axis=1)[ok] <= TOL_F64 * scale[ok]).all()
         assert (got["iters"] == ref["iters"]).mean() >= 0.9
+        assert_parity(st, got, ref, what="odd n = %d" % st.n)

@@ -22,7 +22,8 @@ def _run(st, inputs, flags, dtype, launches=2):
     for _ in range(launches):  # the second launch runs in the order the first one left
         out = dict(x=torch.full((B, st.n), float("nan"), dtype=tdt, device=dev), tau=torch.full((B, st.na), float("nan"), dtype=tdt, device=dev),
                    status=torch.full((B,), -99, dtype=torch.int32, device=dev), iters=torch.full((B,), -1, dtype=torch.int32, device=dev),
-                   n_active=torch.zeros(B, dtype=torch.int32, device=dev), active_mask=torch.zeros(B, 8, dtype=torch.int32, device=dev))
+                   n_active=torch.zeros(B, dtype=torch.int32, device=dev), active_mask=torch.zeros(B, 8, dtype=torch.int32, device=dev),
+                   objective=torch.zeros(B, dtype=tdt, device=dev))
         h.solve_batch(0, B, d_in, out, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     h.close()
@@ -43,7 +44,7 @@ def test_a_shipped_stacks_own_instantiation_gives_the_generic_kernels_bits(name,
     assert (ref["status"] == 0).all() and ref["iters"].max() >= 10
     for flags in (0, HW, capi.FLAG_INDEX_ORDER):
         got = _run(st, inputs, flags, dt)
-        for k in ("x", "tau", "status", "iters", "n_active", "active_mask"):
+        for k in ("x", "tau", "status", "iters", "n_active", "active_mask", "objective"):
             assert np.array_equal(got[k], ref[k], equal_nan=True), (name, dtype, flags, k)
     gen_hw = _run(st, inputs, G | HW, dt)
     for k in ("x", "tau", "status", "iters"):

@@ -8,7 +8,7 @@ import pytest
 
 from inria_wbc_amd import capi, structure
 from inria_wbc_amd import model as mdl
-from tests.util import assert_parity
+from tests.util import assert_parity, device_outputs, host_outputs
 
 pytestmark = pytest.mark.gpu
 
@@ -185,8 +185,7 @@ def test_problem_data_then_solve_matches_oracle_pipeline(handle, rbd):
     rows["tlb"] = torch.from_numpy(np.tile(-m.tau_max, (B, 1))).to(dev)
     rows["tub"] = torch.from_numpy(np.tile(m.tau_max, (B, 1))).to(dev)
     rows["w"] = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev)
-    out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, st.na, dtype=torch.float64, device=dev),
-               status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+    out = device_outputs(B, st, dev)
     stream = torch.cuda.current_stream().cuda_stream
     handle.problem_data(2, B, state, rows, stream=stream)
     handle.solve_batch(2, B, rows, out, stream=stream)
@@ -194,9 +193,9 @@ def test_problem_data_then_solve_matches_oracle_pipeline(handle, rbd):
     ora_rows = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"], n_threads=8)
     ora_in = dict(ora_rows, tlb=np.tile(-m.tau_max, (B, 1)), tub=np.tile(m.tau_max, (B, 1)), w=np.tile(st.default_weights, (B, 1)))
     ref = orc.tick_batch(st, ora_in, nthreads=8)
-    got = {k: v.cpu().numpy() for k, v in out.items()}
+    got = host_outputs(out, st)
     assert (ref["status"] == 0).all()
-    assert_parity(st, got, ref)
+    assert_parity(st, got, ref, what="rows on the device -> QP (talos-like)")
 
 
 @pytest.mark.parametrize("name", ["talos_torque_cop", "talos_posture_mask"])
@@ -296,8 +295,7 @@ def test_mixed_robots_rows_then_one_ragged_solve(rbd):
         rows["tub"] = torch.from_numpy(np.tile(tmax, (B, 1))).to(dev)
         rows["w"] = torch.from_numpy(np.tile(st.default_weights, (B, 1))).to(dev)
         h.problem_data(slot, B, {k: torch.from_numpy(s[k]).to(dev) for k in ("q", "v", "ref")}, rows, stream=stream)
-        out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, max(st.na, 1), dtype=torch.float64, device=dev),
-                   status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
+        out = device_outputs(B, st, dev)
         groups.append((slot, B, rows, out))
         ora = rbd.task_rows(m, tm, st, s["q"], s["v"], s["ref"], n_threads=4)
         checks.append((st, out, dict(ora, tlb=np.tile(-tmax, (B, 1)), tub=np.tile(tmax, (B, 1)), w=np.tile(st.default_weights, (B, 1)))))
@@ -305,10 +303,9 @@ def test_mixed_robots_rows_then_one_ragged_solve(rbd):
     torch.cuda.synchronize()
     for st, out, ora_in in checks:
         ref = orc.tick_batch(st, ora_in, nthreads=4)
-        got = {k: v.cpu().numpy() for k, v in out.items()}
-        got["tau"] = got["tau"][:, :st.na]
+        got = host_outputs(out, st)
         assert (ref["status"] == 0).all()
-        assert_parity(st, got, ref)
+        assert_parity(st, got, ref, what="rows on the device -> ragged QP launch: " + st.name)
     h.close()
 
 

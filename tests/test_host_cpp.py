@@ -791,3 +791,24 @@ def test_a_bounded_solver_fails_with_the_references_text(host_build, oracle_mod,
     r = subprocess.run([host_build["qp_timer_test"], os.path.join(ROOT, "configs/talos/pos_tracker.yaml"), squat, path, "1", tau_path, str(first_tick)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_dump_tool_compiles_against_declaration_stubs():
+    """tools/dump_reference_vectors.cpp -- the program that will PIN parity on a machine with tsid -- is written against the reference's
+    real API and cannot be built here.  It is at least syntax- and type-checked against declaration-only stubs of the names it uses (tools/stubs/README.md:
+    no bodies, no object file, pins nothing), so that the day such a machine appears the one command does not start with a compile error.  Contract: the
+    calls of /root/reference/src/controllers/controller.cpp:244-251 and pos_tracker.cpp:83-106."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "tools", "stubs"),
+                           os.path.join(root, "tools", "dump_reference_vectors.cpp")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert proc.returncode == 0, proc.stdout
+    # the stubs stay declarations: nothing under tools/stubs defines a function body or is named in any build recipe
+    for dirpath, _, files in os.walk(os.path.join(root, "tools", "stubs")):
+        for f in files:
+            if f == "README.md":
+                continue
+            text = open(os.path.join(dirpath, f)).read()
+            assert "COMPILE-CHECK STUB" in text, f
+    for recipe in ("inria_wbc_amd/build.py", "oracle/Makefile", "__graft_entry__.py"):
+        assert "tools/stubs" not in open(os.path.join(root, recipe)).read(), recipe

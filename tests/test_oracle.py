@@ -126,6 +126,40 @@ def test_golden_fixtures_pin_the_oracle(oracle_mod, case):
     assert np.array_equal(out["iters"], z["iters"])
     assert np.abs(out["x"] - z["x"]).max() <= 1e-9 * max(1.0, np.abs(z["x"]).max())
     assert np.abs(out["tau"] - z["tau"]).max() <= 1e-9 * max(1.0, np.abs(z["tau"]).max())
+    # HQPOutput's other members ("identical active set"; pos_tracker.hpp:44 getObjectiveValue): the committed files hold them too
+    assert np.array_equal(out["n_active"], z["n_active"]) and np.array_equal(out["active"], z["active"])
+    assert np.array_equal(out["active_mask"], z["active_mask"])
+    assert np.abs(out["fval"] - z["fval"]).max() <= 1e-9 * max(1.0, np.abs(z["fval"]).max())
+
+
+@pytest.mark.parametrize("name,noise", [("tiago", 8.0), ("icub", 5.0), ("talos", 5.0), ("talos_single_support", 2.0)])
+def test_batch_active_set_is_the_single_solves_and_means_what_the_header_says(oracle_mod, name, noise):
+    """oracle.tick_batch's active / n_active / fval / active_mask (what the GPU tests compare wbcqp_outputs.active_mask, n_active and objective with):
+    the single-QP entry point's, and -- independently of the solver -- what the numbering claims: entry a >= 0 is the one-sided row a of the CI that
+    wbco_assemble builds ([A; -A] per block), so every such row is tight at x, the equalities come first tagged -1 .. -nEq in order, no row
+    appears twice, a row and its twin of the other side are never both active unless lb = ub, and bit r of the mask is set iff r is in the list."""
+    st = structure.STRUCTURES[name]()
+    B = 12
+    inputs = synth.generate(st, B, synth.SEED_BASE[name] + 4711, task_noise=noise, p_bnd=0.3)
+    out = oracle_mod.tick_batch(st, inputs, nthreads=2)
+    assert (out["status"] == 0).all() and (out["n_active"] - st.neq).max() >= 2
+    for i in range(B):
+        o = oracle_mod.tick_single(st, inputs, i)
+        q = out["n_active"][i]
+        assert q == len(o["active"]) and np.array_equal(out["active"][i, :q], o["active"]) and out["fval"][i] == o["fval"]
+        assert (out["active"][i, q:] == oracle_mod.ACTIVE_PAD).all()
+        A = out["active"][i, :q]
+        assert np.array_equal(A[:st.neq], -1 - np.arange(st.neq)) and (A[st.neq:] >= 0).all() and len(set(A.tolist())) == q
+        H, g, CE, ce0, CI, ci0 = oracle_mod.assemble(st, inputs, i)
+        x = out["x"][i]
+        s = CI @ x + ci0
+        J = np.linalg.inv(np.linalg.cholesky(H)).T
+        psi_tol = CI.shape[0] * np.finfo(float).eps * np.trace(H) * np.trace(J) * 100.0
+        rows = A[st.neq:]
+        assert np.abs(s[rows]).max(initial=0.0) <= 1e-7 * np.maximum(1.0, np.abs(ci0[rows])).max(initial=1.0) + psi_tol, (i, s[rows])
+        assert abs(out["fval"][i] - (0.5 * x @ H @ x + g @ x)) <= 1e-8 * max(1.0, abs(out["fval"][i]))
+        bits = np.unpackbits(out["active_mask"][i].view(np.uint8), bitorder="little")
+        assert np.array_equal(np.nonzero(bits)[0], np.sort(rows[rows < 256]))
 
 
 def test_threads_agree(oracle_mod):

@@ -80,6 +80,16 @@ def emulate_dump(st, inputs, out, root):
         np.save(os.path.join(d, "q.npy"), np.zeros(nv + (1 if nu == 6 else 0))); np.save(os.path.join(d, "v.npy"), np.zeros(nv))
         np.save(os.path.join(d, "x.npy"), out["x"][k]); np.save(os.path.join(d, "tau.npy"), out["tau"][k])
         np.save(os.path.join(d, "status_iters.npy"), np.array([out["status"][k], out["iters"][k]], np.int32))
+        # HQPOutput's other members as the dump tool writes them since round 6 (the whole active list, eiquadprog's tags)
+        np.save(os.path.join(d, "active_set.npy"), out["active"][k, :out["n_active"][k]].astype(np.int32))
+        np.save(os.path.join(d, "objective.npy"), np.array([out["fval"][k]]))
+
+
+def _ineq_rows(a):
+    """the one-sided inequality rows of an active list, whatever slice of eiquadprog's A tsid copied into HQPOutput::activeSet [UPSTREAM-RECALL]:
+    tags >= 0 (equalities are tagged -i-1, padding is INT32_MIN)"""
+    a = np.asarray(a)
+    return set(int(v) for v in a[a >= 0])
 
 
 @pytest.mark.parametrize("robot", ["talos", "icub", "franka", "tiago", "talos_single_support"])
@@ -98,6 +108,9 @@ def test_packer_round_trips_a_dump_in_tsids_order(robot, tmp_path, oracle_mod):
         else:
             assert np.array_equal(got["in_" + k], want), k
     assert np.array_equal(got["x"], out["x"]) and np.array_equal(got["iters"], out["iters"]) and str(got["source"]) == "reference"
+    assert np.array_equal(got["ref_objective"], out["fval"])
+    for k in range(3):
+        assert _ineq_rows(got["ref_active_set"][k]) == _ineq_rows(out["active"][k, :out["n_active"][k]])
 
 
 def test_packer_refuses_a_dump_that_is_not_the_structure(tmp_path, oracle_mod):
@@ -138,6 +151,11 @@ def test_oracle_matches_reference_vectors(path, oracle_mod):
     scale = np.maximum(1.0, np.abs(g["x"]).max(axis=1, keepdims=True))
     assert (np.abs(out["x"] - g["x"]) / scale).max() <= 1e-8
     assert (out["iters"] == g["iters"]).mean() >= 0.9
+    if "ref_active_set" in g.files:  # identical active set, wherever the iteration counts agree
+        for k in np.nonzero(out["iters"] == g["iters"])[0]:
+            assert _ineq_rows(g["ref_active_set"][k]) == _ineq_rows(out["active"][k, :out["n_active"][k]]), k
+    if "ref_objective" in g.files:
+        assert (np.abs(out["fval"] - g["ref_objective"]) <= 1e-8 * np.maximum(1.0, np.abs(g["ref_objective"]))).all()
 
 
 @pytest.mark.gpu
@@ -156,3 +174,8 @@ def test_hip_path_matches_reference_vectors(path):
     scale = np.maximum(1.0, np.abs(g["x"]).max(axis=1, keepdims=True))
     assert (np.abs(out["x"] - g["x"]) / scale).max() <= 1e-8  # SURVEY 8(d) tolerance
     assert np.abs(out["tau"] - g["tau"]).max() <= 1e-8 * max(1.0, np.abs(g["tau"]).max())
+    if "ref_active_set" in g.files and st.nin2 <= 256:
+        from oracle import oracle
+        same = out["iters"] == g["iters"]
+        ref_mask = oracle.active_to_mask(g["ref_active_set"], (g["ref_active_set"] != np.iinfo(np.int32).min).sum(axis=1).astype(np.int32))
+        assert (out["active_mask"].view(np.uint32) == ref_mask)[same].all()

@@ -23,13 +23,30 @@ def load_golden():
 
 
 TOL_RAW_FORCE = 1e-4  # contact-point forces: their internal-force null space is held by the 1e-8 regulariser only
+TOL_OBJECTIVE = 1e-8  # |objective - fval| <= TOL_OBJECTIVE * max(1, |fval|)   (SolverHQPBase::getObjectiveValue, pos_tracker.hpp:44)
+
+MEASURED = []  # (what, dict) per assert_parity call: the figures the bars bound, printed at the end of the session (tests/conftest.py)
 
 
-def assert_parity(st, got, ref, tol=TOL_F64, what=""):
+def mask_of(a):
+    """[B, 8] active_mask as uint32 whatever integer type the caller's buffer has."""
+    return np.ascontiguousarray(a).view(np.uint32).reshape(len(a), -1)
+
+
+def assert_parity(st, got, ref, tol=TOL_F64, what="", active=None):
     """got/ref: dicts with x, tau, status, iters ([B, ...]).  dv, the contact wrenches T f and tau must agree to `tol`
     (relative to max(1, |.|inf)); the raw contact-point forces f only to TOL_RAW_FORCE: H_ff = w F'F + 1e-8 I has rank-6
     F'F, so six directions of f per contact are conditioned like 1e12 (seen: |df| 1.6e-3 on |f| 215 with dv, T f and tau
-    equal to 1e-9, tests/stress/stress_parity.py)."""
+    equal to 1e-9, tests/stress/stress_parity.py).  The measured raw-force deviation is reported (MEASURED, printed by
+    conftest.py), not only bounded.
+
+    SURVEY 8(d)'s "identical active set": when `ref` carries the oracle's active set (oracle.tick_batch: active_mask, n_active, fval;
+    the golden files: the same), `got` MUST carry the C ABI's wbcqp_outputs.active_mask / n_active / objective, and wherever the
+    status is optimal and the iteration counts agree: the 256-bit mask equals {a >= 0 in eiquadprog's A} bit for bit (bit r = one-sided
+    CI row r in SolverHQuadProgFast's stacking), n_active equals iq, |objective - fval| <= TOL_OBJECTIVE max(1, |fval|).  QPs whose
+    iteration count differs (a tie broken by rounding; the callers bound their number) are compared too and COUNTED in
+    active_set_equal_frac, but a different set there is not a failure: at a degenerate vertex two active sets describe one x.
+    active=False: the caller's outputs carry none (say why at the call)."""
     assert np.array_equal(got["status"], ref["status"]), (what, got["status"], ref["status"])
     ok = ref["status"] == 0
     nv = st.nv
@@ -38,6 +55,7 @@ def assert_parity(st, got, ref, tol=TOL_F64, what=""):
     ev = np.abs(gx[:, :nv] - rx[:, :nv]).max(axis=1) / xs
     assert (ev[ok] <= tol).all(), (what, "dv", ev.max(), int(ev.argmax()))
     ex = ev.copy()
+    info = {}
     if st.nc:
         T = np.asarray(st.force_gen()).reshape(st.nc, 6, 12)
         gf = gx[:, nv:].reshape(-1, st.nc, 12)
@@ -49,10 +67,50 @@ def assert_parity(st, got, ref, tol=TOL_F64, what=""):
         ef = np.abs(gf - rf).reshape(len(rx), -1).max(axis=1) / xs
         assert (ef[ok] <= TOL_RAW_FORCE).all(), (what, "raw contact forces", ef.max(), int(ef.argmax()))
         ex = np.maximum(ev, ew)
+        info["max_rel_raw_force"] = float(ef[ok].max(initial=0.0))
+        info["max_rel_wrench"] = float(ew[ok].max(initial=0.0))
     if st.na:
         ts = np.maximum(1.0, np.abs(ref["tau"]).max(axis=1))
         et = np.abs(got["tau"] - ref["tau"]).max(axis=1) / ts
         assert (et[ok] <= tol).all(), (what, "tau", et.max(), int(et.argmax()))
+        info["max_rel_tau"] = float(et[ok].max(initial=0.0))
     # active-set iteration counts: identical path expected up to ties broken by rounding
-    same = float((got["iters"] == ref["iters"]).mean())
-    return dict(max_rel_x=float(ex[ok].max(initial=0.0)), iters_equal=same)
+    same_it = np.asarray(got["iters"]) == np.asarray(ref["iters"])
+    info.update(max_rel_x=float(ex[ok].max(initial=0.0)), max_rel_dv=float(ev[ok].max(initial=0.0)), iters_equal=float(same_it.mean()) if len(same_it) else 1.0)
+    if active is None:
+        active = "active_mask" in ref
+    if active:
+        gm, rm = mask_of(got["active_mask"]), mask_of(ref["active_mask"])
+        same_set = (gm == rm).all(axis=1)
+        fv = np.asarray(ref["fval"], np.float64)
+        eo = np.abs(np.asarray(got["objective"], np.float64) - fv) / np.maximum(1.0, np.abs(fv))
+        must = ok & same_it
+        assert same_set[must].all(), (what, "active set", np.nonzero(must & ~same_set)[0][:8].tolist(),
+                                      [hex(int(v)) for v in gm[must & ~same_set][:1].ravel()], [hex(int(v)) for v in rm[must & ~same_set][:1].ravel()])
+        assert np.array_equal(np.asarray(got["n_active"])[must], np.asarray(ref["n_active"])[must]), (what, "n_active", got["n_active"], ref["n_active"])
+        assert (eo[must] <= TOL_OBJECTIVE).all(), (what, "objective", float(eo[must].max()), int(eo.argmax()))
+        # (popcount of the mask = inequality rows of the active set, wherever all of them have a bit)
+        if st.nin2 <= 256:
+            pop = np.unpackbits(gm.view(np.uint8), axis=1).sum(axis=1)
+            assert np.array_equal(pop[ok], (np.asarray(got["n_active"]) - st.neq)[ok]), (what, "popcount(active_mask) != n_active - nEq")
+        info.update(active_set_equal_frac=float(same_set[ok].mean()) if ok.any() else 1.0, active_set_checked=int(must.sum()),
+                    max_rel_objective=float(eo[must].max(initial=0.0)), max_rel_objective_all=float(eo[ok].max(initial=0.0)))
+    MEASURED.append((what or st.name, info))
+    return info
+
+
+def device_outputs(batch, st, device="cuda", dtype=None):
+    """A complete wbcqp_outputs for the device entry points: x, tau, status, iters AND objective, n_active, active_mask (what assert_parity compares
+    with the oracle's fval / iq / A)."""
+    import torch
+    dtype = dtype or torch.float64
+    return dict(x=torch.zeros(batch, st.n, dtype=dtype, device=device), tau=torch.zeros(batch, max(st.na, 1), dtype=dtype, device=device),
+                status=torch.full((batch,), -99, dtype=torch.int32, device=device), iters=torch.zeros(batch, dtype=torch.int32, device=device),
+                objective=torch.zeros(batch, dtype=dtype, device=device), n_active=torch.zeros(batch, dtype=torch.int32, device=device),
+                active_mask=torch.zeros(batch, 8, dtype=torch.int32, device=device))
+
+
+def host_outputs(dev_out, st):
+    got = {k: v.cpu().numpy() for k, v in dev_out.items()}
+    got["tau"] = got["tau"][:, :st.na]
+    return got

@@ -12,7 +12,7 @@
 // of tests/golden/*.npz, and tests/test_reference_vectors.py then checks the oracle and the HIP path against THOSE numbers
 // (it skips, loudly, while no such file exists).
 //
-// NOT COMPILED HERE (no Eigen / tsid / pinocchio / yaml-cpp in this image).  It follows the reference's own harness
+// NOT BUILT HERE (no Eigen / tsid / pinocchio / yaml-cpp in this image; syntax-checked against declaration stubs, see below).  It follows the reference's own harness
 // (/root/reference/src/robot_dart/qp_timer_test.cpp:15-70) and calls, per tick, exactly what Controller::_solve calls
 // (/root/reference/src/controllers/controller.cpp:231-313):
 //     tsid_->computeProblemData(t, q, dq)      controller.cpp:244
@@ -22,8 +22,10 @@
 // controller; the two must agree (checked: max |ddq_dump - controller->ddq(false)|).
 //
 // Build (on a machine with the reference installed as docs/installation.md describes):
-//     g++ -std=c++14 -O2 tools/dump_reference_vectors.cpp -o dump_reference_vectors \
-//         $(pkg-config --cflags --libs tsid pinocchio eigen3 yaml-cpp) -linria_wbc -lboost_system -lboost_filesystem
+//     g++ -std=c++14 -O2 tools/dump_reference_vectors.cpp -o dump_reference_vectors
+//         $(pkg-config --cflags --libs tsid pinocchio eigen3 yaml-cpp) -linria_wbc -lboost_system -lboost_filesystem      (one command line)
+// Compile check in THIS image (declarations only, tools/stubs/README.md; run by tests/test_host_cpp.py):
+//     g++ -std=c++14 -fsyntax-only -Wall -I tools/stubs tools/dump_reference_vectors.cpp
 // Run:
 //     ./dump_reference_vectors etc/talos/talos_pos_tracker.yaml etc/talos/squat.yaml out_dir/talos_squat 200
 //     ./dump_reference_vectors etc/franka/pos_tracker.yaml etc/franka/cartesian_line.yaml out_dir/franka_line 200
@@ -37,10 +39,13 @@
 //   recall_jac_<frame>.npy     robot->frameJacobianWorld of every self-collision frame (pinocchio WORLD, origin dependent)
 //   recall_bounds.npy          TaskJointPosVelAccBounds' lower / upper acceleration limits (computeAccLimits) at (q, v)
 //   recall_momentum.npy        the centroidal momentum and its drift term as TaskMEquality used them
+#include <algorithm>
+#include <cstdlib>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -178,6 +183,16 @@ int main(int argc, char** argv)
             dump_vector(d + "/tau.npy", tau);
             dump_vector(d + "/dv.npy", dv);
             dump_ints(d + "/status_iters.npy", {static_cast<int>(sol.status), static_cast<int>(sol.iterations)});
+            // the rest of HQPOutput ("identical active set"; pos_tracker.hpp:44 getObjectiveValue): written as tsid hands them out --
+            // [UPSTREAM-RECALL] SolverHQuadProgFast::solve copies eiquadprog's getActiveSet() / getLagrangeMultipliers() (entries: equality i tagged
+            // -i-1, otherwise the one-sided CI row; which slice of them lands in HQPOutput is for the packer to find out from the numbers)
+            dump_ints(d + "/active_set.npy", std::vector<int>(sol.activeSet.data(), sol.activeSet.data() + sol.activeSet.size()));
+            dump_vector(d + "/lambda.npy", sol.lambda);
+            {
+                Eigen::VectorXd fv(1);
+                fv << solver->getObjectiveValue();
+                dump_vector(d + "/objective.npy", fv);
+            }
             dump_matrix(d + "/M.npy", robot->mass(tsid->data()));
             dump_vector(d + "/h.npy", robot->nonLinearEffects(tsid->data()));
             // every constraint of every level, in tsid's own order: that order IS the row order of CE / CI / the level-1 sum

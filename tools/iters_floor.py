@@ -20,9 +20,9 @@ def main():
     for fname, st, inputs, z in load_golden():
         h.set_structure(0, st)
         got = h.solve_batch_host(0, inputs)
-        info = assert_parity(st, got, dict(x=z["x"], tau=z["tau"], status=z["status"], iters=z["iters"]), what=fname)
+        info = assert_parity(st, got, {k: z[k] for k in ("x", "tau", "status", "iters", "active_mask", "n_active", "fval")}, what=fname)
         n = len(z["iters"])
-        print("golden %-32s n %4d iters_equal %.4f (%d differ) max_rel_x %.2e" % (fname, n, info["iters_equal"], round(n * (1 - info["iters_equal"])), info["max_rel_x"]))
+        print("golden %-32s n %4d iters_equal %.4f (%d differ) max_rel_x %.2e active sets equal %.4f raw force %.2e objective %.2e" % (fname, n, info["iters_equal"], round(n * (1 - info["iters_equal"])), info["max_rel_x"], info["active_set_equal_frac"], info.get("max_rel_raw_force", 0.0), info["max_rel_objective"]))
     for name, batch, noise in tp.PARITY_CASES:
         st = structure.STRUCTURES[name]()
         inputs = synth.generate(st, batch, synth.SEED_BASE[name] + 100, task_noise=noise)
@@ -30,7 +30,7 @@ def main():
         h.set_structure(1, st)
         got = h.solve_batch_host(1, inputs)
         info = assert_parity(st, got, ref, what=name)
-        print("parity %-24s noise %.1f n %4d iters_equal %.4f (%d differ) max_rel_x %.2e" % (name, noise, batch, info["iters_equal"], round(batch * (1 - info["iters_equal"])), info["max_rel_x"]))
+        print("parity %-24s noise %.1f n %4d iters_equal %.4f (%d differ) max_rel_x %.2e active sets equal %.4f raw force %.2e objective %.2e" % (name, noise, batch, info["iters_equal"], round(batch * (1 - info["iters_equal"])), info["max_rel_x"], info["active_set_equal_frac"], info.get("max_rel_raw_force", 0.0), info["max_rel_objective"]))
     h.close()
 
 

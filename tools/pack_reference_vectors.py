@@ -39,6 +39,12 @@ def read_tick(d):
     si = np.load(os.path.join(d, "status_iters.npy"))
     out["status"], out["iters"] = int(si[0]), int(si[1])
     out["hqp"] = idx
+    # HQPOutput's other members, when the dump holds them (written since round 6): kept raw -- how tsid slices eiquadprog's active list into
+    # HQPOutput::activeSet is [UPSTREAM-RECALL]; tests/test_reference_vectors.py compares them as SETS of one-sided rows with the oracle's
+    for k in ("active_set", "lambda", "objective"):
+        p = os.path.join(d, k + ".npy")
+        if os.path.exists(p):
+            out[k] = np.load(p)
     return out
 
 
@@ -130,9 +136,10 @@ def pack(dump_dir, st):
     ticks = sorted(d for d in os.listdir(dump_dir) if d.startswith("tick"))
     if not ticks:
         raise PackError("no tick directories in " + dump_dir)
-    rows, outs = [], {"x": [], "tau": [], "status": [], "iters": [], "q": [], "v": []}
+    rows, outs, extras = [], {"x": [], "tau": [], "status": [], "iters": [], "q": [], "v": []}, []
     for d in ticks:
         t = read_tick(os.path.join(dump_dir, d))
+        extras.append({k: t[k] for k in ("active_set", "lambda", "objective") if k in t})
         rows.append(pack_tick(st, t))
         for k in outs:
             outs[k].append(t[k])
@@ -143,6 +150,14 @@ def pack(dump_dir, st):
     out.update({k: np.asarray(v) for k, v in outs.items()})
     out["status"] = out["status"].astype(np.int32)
     out["iters"] = out["iters"].astype(np.int32)
+    if all("objective" in t_ for t_ in extras):
+        out["ref_objective"] = np.array([float(t_["objective"][0]) for t_ in extras])
+    if all("active_set" in t_ for t_ in extras):
+        width = max(t_["active_set"].size for t_ in extras)
+        a = np.full((len(extras), max(width, 1)), np.iinfo(np.int32).min, np.int32)
+        for i, t_ in enumerate(extras):
+            a[i, :t_["active_set"].size] = t_["active_set"]
+        out["ref_active_set"] = a
     out["source"] = np.array("reference")
     out["structure"] = np.array(st.name)
     return out
