@@ -713,7 +713,13 @@ def main():
     # optional exchange step: the library's own RCCL entry point on a communicator of this job's ranks
     gather = {"ok": False, "err": None, "comm": None}
     tau_all = None
-    if distributed and args.allgather:
+    exchange_skipped = None  # why the line carries no all-gather figures although the run is distributed (never silently absent)
+    if distributed and args.backend != "nccl":
+        exchange_skipped = ("backend %s%s: wbcqp_allgather_tau is RCCL's ncclAllGather and needs one GPU per rank (backend nccl); the solve path itself has no "
+                            "collective, so `value` is unaffected" % (args.backend, ", every rank on cuda:0 (--single-device)" if args.single_device else ""))
+    elif distributed and args.no_exchange and not args.allgather:
+        exchange_skipped = "--no-exchange"
+    if distributed and args.allgather and exchange_skipped is None:
         try:
             from inria_wbc_amd import rccl
             gather["comm"] = rccl.comm_from_torch(dist, rank, world, dev)
@@ -888,6 +894,8 @@ def main():
                 result["config"]["rccl_nranks_error"] = repr(e)
         if window is not None:
             result["window"] = window
+        if exchange is None and distributed:
+            result["allgather_tau"] = {"skipped_reason": exchange_skipped or gather["err"] or "not requested"}
         if exchange is not None:
             result["allgather_tau"] = {k: v for k, v in exchange.items() if k != "hung"}
             if "rccl_nranks" in exchange:

@@ -252,14 +252,16 @@ def tick_batch_timed(st, inputs: Dict[str, np.ndarray], nthreads: int = 1, reps:
     arrs = _prep_inputs(st, inputs, batch)
     x = np.zeros((batch, st.n)); tau = np.zeros((batch, max(st.na, 1)))
     status = np.zeros(batch, np.int32); iters = np.zeros(batch, np.int32)
+    active = np.full((batch, max(st.neq + st.nin2, 1)), ACTIVE_PAD, np.int32); n_active = np.zeros(batch, np.int32); fval = np.zeros(batch)
     bin_ = _BatchInputs(*[_dp(arrs[k]) for k in _FIELDS])
-    bout = _BatchOutputs(_dp(x), _dp(tau), _ip(status), _ip(iters), None, None, None)
+    bout = _BatchOutputs(_dp(x), _dp(tau), _ip(status), _ip(iters), _ip(active), _ip(n_active), _dp(fval))  # (pass 0 writes them: a few stores per QP)
     f = (native_lib() if native else lib()).wbco_tick_batch_timed
     f.restype = C.c_double
     secs = f(C.byref(ost.c), int(batch), C.byref(bin_), C.byref(bout), int(nthreads), int(reps))
     if secs < 0.0:
         raise RuntimeError("wbco_tick_batch_timed failed (threads)")
-    return float(secs), dict(x=x, tau=tau[:, :st.na], status=status, iters=iters)
+    return float(secs), dict(x=x, tau=tau[:, :st.na], status=status, iters=iters, active=active, n_active=n_active, fval=fval,
+                             active_mask=active_to_mask(active, n_active))
 
 
 def tick_single(st, inputs: Dict[str, np.ndarray], index: int = 0):

@@ -108,6 +108,35 @@ def test_ragged_shards_balance_cost_and_cover_every_qp():
     assert shard.contiguous_shards(8192, 8)[3] == (3072, 4096)
 
 
+def test_the_bench_lines_8_rank_ragged_partition_replayed():
+    """BASELINE config 5 over 8 ranks, exactly the partition bench.py's line reports as `other_configs.config5_ragged_b8192.shards_8_ranks`
+    (tools/ragged_bench.py: the same seed draws the mix, shard.ragged_shards cuts it): every QP on exactly one rank, every rank's n^3 cost within one
+    Talos QP of the mean, and the counts the line prints are the counts of the plan."""
+    from inria_wbc_amd import shard, structure
+    from tools import ragged_bench
+    kinds = np.random.default_rng(5_000_000).integers(0, len(ragged_bench.NAMES), size=8192)
+    groups = [(structure.STRUCTURES[name]().n, int((kinds == slot).sum())) for slot, name in enumerate(ragged_bench.NAMES)]
+    groups = [g for g in groups if g[1]]
+    assert sum(c for _, c in groups) == 8192 and len(groups) == len(ragged_bench.NAMES)
+    plan = shard.ragged_shards(groups, 8)
+    cost = shard.shard_costs(groups, plan)
+    mean = sum(cost) / 8
+    nmax = max(n for n, _ in groups)
+    assert max(abs(c - mean) for c in cost) <= float(nmax) ** 3, (cost, mean)
+    per_rank = [sum(e - b for _, b, e in pieces) for pieces in plan]
+    assert sum(per_rank) == 8192 and min(per_rank) > 0
+    covered = {gi: 0 for gi in range(len(groups))}
+    for pieces in plan:
+        for gi, b, e in pieces:
+            assert b == covered[gi]  # (contiguous, in order, no QP twice)
+            covered[gi] = e
+    assert all(covered[gi] == cnt for gi, (_, cnt) in enumerate(groups))
+    # by count the ranks would be far apart: the small robots cost a thousandth of a humanoid
+    assert max(per_rank) > 2 * min(per_rank)
+    share = [c / sum(cost) for c in cost]
+    assert max(share) - min(share) < 0.01
+
+
 def _clean_env():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):

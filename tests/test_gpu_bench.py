@@ -51,6 +51,17 @@ def test_the_n_gpus_2_line_carries_the_cpu_baseline_and_the_parity_sample(built_
     assert d["roofline"]["frac"] > 0
 
 
+def test_allgather_asked_without_rccl_says_why_it_was_skipped(built_lib):
+    """`--allgather` on a run whose ranks cannot form an RCCL communicator (gloo, both ranks on cuda:0): the line must SAY that the exchange leg was
+    skipped and why (`allgather_tau.skipped_reason`) instead of omitting the key -- a SCALE record without exchange figures is then explained by its own line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--allgather",
+                        "--steps", "4", "--warmup", "2", "--headline-only"], capture_output=True, text=True, timeout=900, env=_env())
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["allgather_tau"] is False
+    assert "skipped_reason" in d["allgather_tau"] and "one GPU per rank" in d["allgather_tau"]["skipped_reason"]
+
+
 def test_n1_line_has_the_contract_keys(built_lib):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
                         "--no-sweep", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900, env=_env())
@@ -64,6 +75,9 @@ def test_n1_line_has_the_contract_keys(built_lib):
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["parity"]["status_equal"] and d["parity"]["max_rel_dx"] <= 1e-8
+    # identical active set -- the last timed launch's active_mask / n_active / objective against the oracle's A / iq / f on the sample
+    assert d["parity"]["active_set_equal_frac"] >= d["parity"]["iters_equal_frac"] - 1e-12 and d["parity"]["active_set_equal_frac"] >= 0.95
+    assert d["parity"]["n_active_equal_frac"] >= 0.95 and d["parity"]["max_rel_dobjective"] <= 1e-6
     # no leg of the line may have failed quietly: a leg that raises leaves {"error": ...} in its place (round 4: `before_path` did, for
     # three profile passes, over an empty record field)
     def errors(node, path=""):
