@@ -44,7 +44,7 @@ def pytest_terminal_summary(terminalreporter):
     tr = terminalreporter
     tr.section("parity figures measured against the oracle (tests/util.py:assert_parity)")
     for what, info in util.MEASURED:
-        tr.write_line("%-58s dv %.1e  wrench %.1e  tau %.1e  raw f %.1e  iters= %.3f  active set= %s (%s checked)  objective %s" % (
+        tr.write_line("%-58s dv %.1e  wrench %.1e  tau %.1e  raw f %.1e  iters= %.3f  active set= %s (%s checked, facets differ on %s)  objective %s" % (
             what[:58], info.get("max_rel_dv", 0.0), info.get("max_rel_wrench", 0.0), info.get("max_rel_tau", 0.0), info.get("max_rel_raw_force", 0.0),
             info.get("iters_equal", 1.0), ("%.3f" % info["active_set_equal_frac"]) if "active_set_equal_frac" in info else "-",
-            info.get("active_set_checked", "-"), ("%.1e" % info["max_rel_objective"]) if "max_rel_objective" in info else "-"))
+            info.get("active_set_checked", "-"), info.get("facets_differ", "-"), ("%.1e" % info["max_rel_objective"]) if "max_rel_objective" in info else "-"))
