@@ -54,7 +54,10 @@ def mask_bits(m, nin2):
     return np.unpackbits(np.ascontiguousarray(m).view(np.uint8), axis=1, bitorder="little")[:, :min(nin2, 256)].astype(bool)
 
 
-def assert_parity(st, got, ref, tol=TOL_F64, what="", active=None, facets_differ=0):
+TOL_FACET_FORCE = 1e-6  # where only friction facets differ, the raw point forces themselves must agree this well (measured: <= 7.4e-9): one vertex, two descriptions
+
+
+def assert_parity(st, got, ref, tol=TOL_F64, what="", active=None, facets_differ=None):
     """got/ref: dicts with x, tau, status, iters ([B, ...]).  dv, the contact wrenches T f and tau must agree to `tol`
     (relative to max(1, |.|inf)); the raw contact-point forces f only to TOL_RAW_FORCE: H_ff = w F'F + 1e-8 I has rank-6
     F'F, so six directions of f per contact are conditioned like 1e12 (seen: |df| 1.6e-3 on |f| 215 with dv, T f and tau
@@ -67,12 +70,15 @@ def assert_parity(st, got, ref, tol=TOL_F64, what="", active=None, facets_differ
       * the mask equals {a >= 0 in eiquadprog's A} BIT FOR BIT on every row the solution determines -- acceleration bounds, torque limits, the
         contacts' normal-force sums (bit r = one-sided CI row r in SolverHQuadProgFast's stacking);
       * |objective - fval| <= TOL_OBJECTIVE max(1, |fval|);
-      * on the friction-pyramid facets of the contact POINTS (friction_facet_rows) the sets are equal too, and then n_active equals iq, except on
-        at most `facets_differ` QPs (default 0; a caller's figure is the measured count plus one, like its iteration-count bar).  Why those rows
-        are apart: the twelve point forces of a contact are determined by its wrench up to six internal-force directions that only the 1e-8
-        regulariser holds, so WHICH facets carry a binding internal force is decided by the last bits of s -- the oracle itself moves them under a
-        1-ulp perturbation of its inputs, with the same iteration count and the same dv / wrench / tau (tools/active_set_diag.py --ulp: every such
-        difference is facet-only); the reference's own run-to-run bar (test_determinism.cpp:51) sees none of it.
+      * on the friction-pyramid facets of the contact POINTS (friction_facet_rows) the sets are equal too, and then n_active equals iq -- OR the two
+        sets describe the same vertex: the whole of x, raw point forces included, agrees to TOL_FACET_FORCE (measured <= 7.4e-9; the general bar on raw
+        forces is 1e-4).  `facets_differ` bounds the number of such QPs (None: counted and reported only; the easy cases pass 0).  Why those rows are
+        apart: the regulariser pulls a contact's internal (wrench-free) tangential forces to zero, so the two facets +-t of a point's pyramid are
+        violated by amounts that differ by 2 f_t ~ 1e-12 -- a near-tie in EVERY such pick, decided by the last bits of s -- and a point that carries no
+        force sits at its pyramid's apex, where any three of its four facets describe the same vertex.  The oracle itself moves these rows under a
+        1-ulp perturbation of its inputs with the same iteration count and the same x (tools/active_set_diag.py --ulp; GPU against oracle,
+        profiles/r06/active_set_diag.txt: 1208 facet-only differences in 8.7 k QPs, none on any other row); the reference's own run-to-run bar
+        (test_determinism.cpp:51, 1e-8 on q) sees none of it.
     QPs whose iteration count differs (a tie broken by rounding; the callers bound their number) are compared too and COUNTED in
     active_set_equal_frac, but a different set there is not a failure.  active=False: the caller's outputs carry none (say why at the call)."""
     assert np.array_equal(got["status"], ref["status"]), (what, got["status"], ref["status"])
@@ -121,10 +127,12 @@ def assert_parity(st, got, ref, tol=TOL_F64, what="", active=None, facets_differ
                                [np.nonzero(gb[i] != rb[i])[0].tolist() for i in bad[:4]])
         assert (eo[must] <= TOL_OBJECTIVE).all(), (what, "objective", float(eo[must].max()), int(eo.argmax()))
         facet_only = must & ~same_set
-        if os.environ.get("WBCQP_MEASURE_FACETS"):  # measurement pass (how the callers' figures were taken): report, do not bound
-            facets_differ = len(ok)
-        assert int(facet_only.sum()) <= facets_differ, (what, "friction facets differ on %d QPs (allowed %d)" % (int(facet_only.sum()), facets_differ),
-                                                        np.nonzero(facet_only)[0][:8].tolist())
+        if facets_differ is not None:
+            assert int(facet_only.sum()) <= facets_differ, (what, "friction facets differ on %d QPs (allowed %d)" % (int(facet_only.sum()), facets_differ),
+                                                            np.nonzero(facet_only)[0][:8].tolist())
+        if st.nc and facet_only.any():  # same vertex, other description: then the point forces agree far better than the 1e-4 they are held to in general
+            assert (ef[facet_only] <= TOL_FACET_FORCE).all(), (what, "facets differ AND the raw forces differ", float(ef[facet_only].max()))
+            info["max_rel_raw_force_where_facets_differ"] = float(ef[facet_only].max())
         full = must & same_set
         assert np.array_equal(np.asarray(got["n_active"])[full], np.asarray(ref["n_active"])[full]), (what, "n_active", got["n_active"], ref["n_active"])
         # (popcount of the mask = inequality rows of the active set, wherever all of them have a bit)
