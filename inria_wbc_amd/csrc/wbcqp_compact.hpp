@@ -1259,74 +1259,6 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
             // ---- B: pending update + z on waves 0-2; r, t1 and the step's scalars on wave 3
             {
                 const int mi = iq0 - neq;
-#ifdef WBCQP_V_ROWPAIR
-                if (c.wave < 3) {
-                    // a QUAD per PAIR of rows (2 g, 2 g + 1): a lane takes a quarter of the row's 16-byte pairs for BOTH rows, so the pending v and the pick's d
-                    // are read once per two rows -- 6 units of LDS traffic per row pair where the lane-pair-per-row form moved 8 (the pass is bound by the LDS
-                    // pipe: 133 KB per pick at 128 B per clock).  z of a row is a quad sum (two DPP steps instead of one).
-                    const int g = tid >> 2, q = tid & 3;
-                    const int r0 = 2 * g, r1 = r0 + 1;
-                    const int cs = pc & ~1;
-                    const int P = (ne - cs) >> 1;           // 16-byte pairs of a row from cs on
-                    const int T = max(2, (P + 3) >> 2);     // per lane
-                    bool zbig = false;
-                    if (r0 < n) {
-                        const bool live1 = r1 < n;
-                        double* J0 = c.J + r0 * ldj;
-                        double* J1 = c.J + (live1 ? r1 : r0) * ldj;
-                        const double w0 = Wp[r0], w1 = live1 ? Wp[r1] : 0.0;
-                        const int p0 = q * T, pe = min(P, p0 + T);
-                        const int off = iq0 - cs; // 0, 1 or 2: where column iq sits in the first pairs
-                        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, stash0 = 0.0, stash1 = 0.0;
-                        for (int s0 = 0; s0 < T; s0 += 4) {
-                            double2v ja[4], jb[4], vv[4], dv[4];
-                            int cc[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int p = p0 + s0 + u;
-                                cc[u] = (p < pe && s0 + u < T) ? cs + 2 * p : ne; // past the lane's share: the row's pad pair (zeros, written back as zeros)
-                                ja[u] = ld2(J0 + cc[u]);
-                                jb[u] = ld2(J1 + cc[u]);
-                                vv[u] = ld2(Vp + cc[u]);
-                                dv[u] = ld2(Vn + cc[u]);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                ja[u].x = fma(-w0, vv[u].x, ja[u].x);
-                                ja[u].y = fma(-w0, vv[u].y, ja[u].y);
-                                jb[u].x = fma(-w1, vv[u].x, jb[u].x);
-                                jb[u].y = fma(-w1, vv[u].y, jb[u].y);
-                                *reinterpret_cast<double2v*>(__builtin_assume_aligned(J0 + cc[u], 16)) = ja[u];
-                                if (live1) *reinterpret_cast<double2v*>(__builtin_assume_aligned(J1 + cc[u], 16)) = jb[u];
-                            }
-                            if (s0 == 0) {
-                                stash0 = (off == 0) ? ja[0].x : ((off == 1) ? ja[0].y : ja[1].x);
-                                stash1 = (off == 0) ? jb[0].x : ((off == 1) ? jb[0].y : jb[1].x);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                a0 = fma(ja[u].x, dv[u].x, a0);
-                                a1 = fma(ja[u].y, dv[u].y, a1);
-                                b0 = fma(jb[u].x, dv[u].x, b0);
-                                b1 = fma(jb[u].y, dv[u].y, b1);
-                            }
-                        }
-                        const double z0 = quad_sum(a0 + a1), z1 = quad_sum(b0 + b1);
-                        if (q == 0) {
-                            c.z[r0] = z0;
-                            c.part[r0] = stash0; // column iq of J, for the w of phase C
-                            if (live1) {
-                                c.z[r1] = z1;
-                                c.part[r1] = stash1;
-                            }
-                        }
-                        zbig = (z0 * z0 > eps) || (live1 && z1 * z1 > eps);
-                    }
-                    STAMP(18)
-                    const unsigned long long any = __ballot(zbig);
-                    if (c.lane == 0) LSi[lp::BZF + c.wave] = (any != 0ull) ? 1 : 0;
-                }
-#else
                 if (c.wave < 3) {
                     const int idx = tid >> 1, hf = tid & 1; // lane pair per row
                     const int cs = pc & ~1;
@@ -1377,50 +1309,12 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     const unsigned long long any = __ballot(zbig);
                     if (c.lane == 0) LSi[lp::BZF + c.wave] = (any != 0ull) ? 1 : 0;
                 }
-#endif
                 else {
                     const int i = c.lane;
                     if (i == 0) { // the step length's election slots (their last readers are two barriers back)
                         EL[lp::ET1] = inf;
                         ELu[lp::ET1POS] = 0x7fffffffu;
                     }
-#ifdef WBCQP_V_W3
-                    // r = Ri d_I with TWO lanes per row while the active block has at most 32 rows (lanes i and i + 32 take alternate eight-element
-                    // chunks of row i and exchange their halves once): the loop is half as long where it is the wave's long pole -- the stragglers' picks
-                    const int li = c.lane;
-                    const bool two = (mi <= 32) & (MM >= 8); // (MM >= 8: the half that reads sixteen elements further stays inside the R region)
-                    const int hh = two ? (li >> 5) : 0;
-                    const int ir = two ? (li & 31) : li;
-                    const double* Rr = Ri + lp::rio(min(ir, MM - 1), MM) + 8 * hh;
-                    const double* dq = dI + ir + 8 * hh;
-                    const int tstep = two ? 16 : 8;
-                    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
-                    for (int t0 = 0; t0 < mi; t0 += tstep) { // (past mi: zeros on one side or the other)
-                        double rv[8], dv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            rv[u] = Rr[t0 + u];
-                            dv[u] = dq[t0 + u];
-                        }
-                        r0 = fma(rv[0], dv[0], r0); r1 = fma(rv[1], dv[1], r1); r2 = fma(rv[2], dv[2], r2); r3 = fma(rv[3], dv[3], r3);
-                        r0 = fma(rv[4], dv[4], r0); r1 = fma(rv[5], dv[5], r1); r2 = fma(rv[6], dv[6], r2); r3 = fma(rv[7], dv[7], r3);
-                    }
-                    double rsum = (r0 + r1) + (r2 + r3);
-                    if (two) rsum += __shfl_xor(rsum, 32);
-                    const bool rown = (ir < mi) & (hh == 0); // the lane that speaks for row ir
-                    const double rl = rown ? rsum : 0.0;
-                    const double vq = Vn[neq + min(li, MM - 1)];
-                    const double diq = Vn[iq0 < n ? iq0 : n - 1];
-                    if (rown) c.r[neq + ir] = rl;
-                    // step 2b's partial step length t1 (dual feasibility): elected among the lanes with r > 0, first position on ties
-                    double ratio = inf;
-                    if (rl > 0.0) {
-                        ratio = ratio_pos(c.u[neq + ir], rl);
-                        lds_min_f64(EL + lp::ET1, ratio);
-                    }
-                    const double dn2 = wave_sum((li < MM) ? vq * vq : 0.0); // |d2|^2 = z'n (V is zero below iq)
-                    if (rl > 0.0 && ratio == EL[lp::ET1]) lds_min_u32(ELu + lp::ET1POS, (unsigned)(neq + ir));
-#else
                     const double* Rr = Ri + lp::rio(min(i, MM - 1), MM);
                     const double* dq = dI + i;
                     double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
@@ -1446,7 +1340,6 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     }
                     const double dn2 = wave_sum((i < MM) ? vq * vq : 0.0); // |d2|^2 = z'n (V is zero below iq)
                     if (rl > 0.0 && ratio == EL[lp::ET1]) lds_min_u32(ELu + lp::ET1POS, (unsigned)(neq + i));
-#endif
                     // the reflector of a full step, H = I - tau v v' with v = d[iq:] - alpha e_0, and the step length t2
                     double alpha = (iq0 < n) ? diq : 0.0, v0 = 0.0, tau = 0.0;
                     if (iq0 + 1 < n && dn2 > 0.0) {
