@@ -788,7 +788,11 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     }
 
     // ---------------- the actuation rows into registers (from the record: L2) ----------------
+    // With actuation bounds they are inequality rows of the loop and are loaded here.  Without (iCub: etc/icub/tasks.yaml has no actuation-bounds task) only the
+    // decode's tau = h_a + M_a dv - J_a' f reads them: they are loaded BEHIND the loop then, and the loop does not carry their 38 registers -- which is what the
+    // three-per-CU twin of such a stack (168 VGPRs) kept in scratch (round 5: 148 B/lane, a third of the scratch instructions inside the loop).
     ActRegs ar;
+    auto load_act_rows = [&]() __attribute__((always_inline)) {
     if (na > 0) {
         const int rr = min(tid >> 2, na - 1), q4 = tid & 3;
         const int row = nu + rr;
@@ -831,6 +835,8 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
 #pragma unroll
         for (int u = 0; u < cp::KQ; ++u) ar.aj[u] = 0.0;
     }
+    };
+    if (D.act_bounds) load_act_rows();
 
     STAMP(7)
 
@@ -1641,6 +1647,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     STAMP(16)
     // ---------------- phase 5: decode + write-out ----------------
     // tau = h_a + M_a dv - J_a' f   (getActuatorForces)
+    if (!D.act_bounds) load_act_rows(); // (no actuation inequality rows: the decode is their only reader; the loads fly under the barrier and the x stores)
     bsync();
     TI* xo = ga.x + qp * n;
     for (int i = tid; i < n; i += kThreads) xo[i] = (TI)c.x[i];
