@@ -1492,10 +1492,16 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 // ---- (ii) dual step / (iii) partial step: move, then drop l.  Two barriers; d, z, r, z'n, |d2|^2, s(ip) follow
                 //      the drop by rank-one updates (delta = the entry of d that leaves the active block):
                 //      z += delta J(:, iq'), r_i -= delta Z(i, last), z'n += delta^2, |d2|^2 += delta^2, s(ip) += t z'n.
+                DSTAMP(36)
                 const bool primal = t2 < inf;
                 const int l = c.A[lpos];
                 const int qq = lpos, p = lpos - neq, mi = iq - neq;
                 const int L = iq - 1 - qq; // rotations
+                double qP = 0.0; // wave 2, lane i: P_L of row i of Ri (formed in D1, used in D2)
+#ifdef WBCQP_STAMP_DROP
+                c.st_acc_[45] += L;
+                c.st_acc_[46] += mi;
+#endif
                 {
                     if (tid < n) {
                         const double xv = c.x[tid];
@@ -1504,6 +1510,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                     }
                     if (c.wave == 3 && c.lane < mi) c.u[neq + c.lane] = fma(-t, c.r[neq + c.lane], c.u[neq + c.lane]);
                     if (tid == kThreads - 1) act[l] = 0;
+                    DSTAMP(37)
                     if (c.wave == 1) {
                         // row p of Ri -> the coefficients of the L rotations, and d's own entries through them
                         const int ll = c.lane;
@@ -1512,10 +1519,13 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         const double rho1 = (ll < L) ? Rp[min(ll + 1, L)] : 0.0;
                         const double dl = (ll <= L) ? dI[p + min(ll, L)] : 0.0;
                         const double dl1 = (ll < L) ? dI[p + min(ll + 1, L)] : 0.0;
+                        DSTAMP(32)
                         const double Sl = wave_scan_incl(rho * rho);
                         const double Pd = wave_scan_incl(rho * dl);
+                        DSTAMP(33)
                         const double S1 = fma(rho1, rho1, Sl);
                         const double rs = rsqrt(Sl), rs1 = rsqrt(S1);
+                        DSTAMP(34)
                         if (ll < L) {
                             const double al = -rho1 * (rs * rs1);      // -rho_{l+1} / sqrt(S_l S_{l+1})
                             const double bl = (Sl * rs) * rs1;          //  sqrt(S_l / S_{l+1})
@@ -1535,7 +1545,33 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                             LS[lp::DCL] = cl;
                         }
                         if (ll == 0) LS[lp::DRHO0] = rho;
+                        DSTAMP(35)
                     }
+                    else if (c.wave == 2) {
+                        // (idle until round 6) P_L = sum_{l <= L} rho_l Ri(i, p + l) of every row i of Ri, by the very sequence of FMAs the rotation's
+                        // running sum takes in D2 (rotate_row_ps) -- the same bits: what leaves row i, Z(i, last) = cl P_L, then needs no rotation, and
+                        // this wave moves r, u, A and elects t1 in D2 BESIDE wave 3's rotation of the rows instead of behind it on the same wave
+                        // (the drop's longest chain: 2.7 k of D2's 2.85 k cycles, profiles/r06/drop_profile_before.txt).  Nobody writes Ri in D1.
+                        const int i = c.lane;
+                        const int ic = min(i, MM - 1);
+                        const double* Rrow = Ri + lp::rio(ic, MM);
+                        const double* Rp = Ri + lp::rio(p, MM);
+                        const int sh = p - ic;
+                        double P = Rp[0] * Rrow[max(sh, -1)];
+                        for (int l0 = 0; l0 < L; l0 += 8) {
+                            double x1[8], rh[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { // (reads past L stay inside LDS and are not used)
+                                x1[u] = Rrow[max(sh + l0 + u + 1, -1)];
+                                rh[u] = Rp[min(l0 + u + 1, L)];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (l0 + u < L) P = fma(rh[u], x1[u], P);
+                        }
+                        qP = P;
+                    }
+                    DCOUNT(44)
                     if (primal) sip = fma(t, znp, sip);
                     uiq += t;
                     slow = true;
@@ -1553,6 +1589,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         double* Jk = c.J + kr * ldj + qq;
                         double Pk = rho0 * Jk[0];
                         lp::rotate_row_ps(prm, L, Pk, [&](int jj) { return Jk[jj]; }, [&](int jj, double v) { if (live) Jk[jj] = v; });
+                        DSTAMP(38)
                         bool zbig = false;
                         if (live) {
                             const double tj = cl * Pk;
@@ -1566,7 +1603,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         if (c.lane == 0) LSi[lp::BZF + c.wave] = (any != 0ull) ? 1 : 0;
                     }
                     else if (c.wave == 3) {
-                        // rows of Ri, r, u, A, t1.  Row i <= p has all its elements from column p on; row i > p begins at column i (left of it
+                        // rows of Ri.  Row i <= p has all its elements from column p on; row i > p begins at column i (left of it
                         // the clamped address reads a zero: the spare element that ends the row before), moves up one row, and its first new
                         // element (column i - 1) is the fill-in of rotation i - p - 1.  What a row's rotation produces left of its new diagonal is an
                         // exact zero (no element of the row has entered the running sum yet): those stores land on the same spare element.
@@ -1578,17 +1615,25 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         const double* Rrow = Ri + lp::rio(ic, MM);              // (i, i): the row's first element; Rrow[-1] reads zero
                         double* Rnew = Ri + lp::rio(i2c, MM);                   // (i2, i2)
                         const int sh = p - ic, sh2 = p - i2c;                   // element (i, p + jj) at Rrow[sh + jj]
-                        if (i == 0) {
-                            EL[lp::ET1] = inf;
-                            ELu[lp::ET1POS] = 0x7fffffffu;
-                        }
                         double Pk = rho0 * Rrow[max(sh, -1)];
                         lp::rotate_row_ps(prm, L, Pk,
                                           [&](int jj) { return Rrow[max(sh + jj, -1)]; },
                                           [&](int jj, double v) { if (has) Rnew[max(sh2 + jj, -1)] = v; });
-                        const double tj = row ? cl * Pk : 0.0; // Z(i, last): leaves the matrix
+                        DSTAMP(39)
                         if (has) Rnew[sh2 + L] = 0.0;          // the last column is gone (row i2 keeps its zeros from the new mi on)
                         if (i == mi - 1) Ri[lp::rio(i, MM)] = 0.0; // ... and so is row mi - 1 (it moved up, or it was row p): its storage reads zero again
+                    }
+                    else {
+                        // wave 2: r, u, A, t1 from the P_L it formed in D1 (Z(i, last) = cl P_L leaves the matrix)
+                        const int i = c.lane;
+                        const bool row = i < mi;
+                        const bool has = row && i != p;
+                        const int i2 = i - ((i > p) ? 1 : 0);
+                        if (i == 0) {
+                            EL[lp::ET1] = inf;
+                            ELu[lp::ET1POS] = 0x7fffffffu;
+                        }
+                        const double tj = row ? cl * qP : 0.0;
                         const double rn = row ? fma(-delta, tj, c.r[neq + min(i, mi - 1)]) : 0.0;
                         const double uu = c.u[neq + min(i, mi - 1)];
                         const int aa = c.A[neq + min(i, mi - 1)];
@@ -1598,12 +1643,14 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                             c.A[neq + i2] = aa;
                         }
                         if (i == mi) c.A[iq - 1] = ip; // the candidate moves with its position
+                        DSTAMP(40)
                         double ratio = inf;
                         if (has && rn > 0.0) {
                             ratio = ratio_pos(uu, rn);
                             lds_min_f64(EL + lp::ET1, ratio);
                         }
                         if (has && rn > 0.0 && ratio == EL[lp::ET1]) lds_min_u32(ELu + lp::ET1POS, (unsigned)(neq + i2));
+                        DSTAMP(41)
                     }
                 }
                 STAMP(28)
@@ -1633,6 +1680,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                         v0 = delta - alpha;
                         tau = fast_rcp(fma(nx, fabs(delta), dn2));
                     }
+                    DSTAMP(42)
                 }
             }
             if (status != -2) break;

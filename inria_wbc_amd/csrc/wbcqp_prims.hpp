@@ -137,7 +137,15 @@ __device__ __forceinline__ double gi_distance(double a, double b)
 #ifndef WBCQP_STAMP_TID
 #define WBCQP_STAMP_TID 0
 #endif
+#ifdef WBCQP_STAMP_DROP // (tools/drop_profile.py: finer stamps inside a drop's two phases, a drop counter)
+constexpr int kStamps = 48;
+#define DSTAMP(i) STAMP(i)
+#define DCOUNT(i) { c.st_acc_[i] += 1; }
+#else
 constexpr int kStamps = 32;
+#define DSTAMP(i)
+#define DCOUNT(i)
+#endif
 #define STAMP_DECL c.st_prev_ = stamp_now(); for (int i_ = 0; i_ < kStamps; ++i_) c.st_acc_[i_] = 0;
 // (the counter is read by an asm volatile with a memory clobber: the compiler may not move it across LDS operations, barriers or the loop's other asm
 //  statements -- clock64() was seen hoisted above the code it was meant to time)
@@ -151,6 +159,8 @@ __device__ __forceinline__ long long stamp_now()
 #else
 #define STAMP_DECL
 #define STAMP(i)
+#define DSTAMP(i)
+#define DCOUNT(i)
 #endif
 
 // ------------------------------------------------------------------------------------------------

@@ -32,7 +32,7 @@
 //     ./dump_reference_vectors etc/icub/humanoid_pos_tracker.yaml etc/icub/squat.yaml out_dir/icub_squat 200
 //     python tools/pack_reference_vectors.py out_dir/talos_squat talos tests/golden/reference/talos_squat.npz
 //
-// First things to look at in the output (the [UPSTREAM-RECALL] items of oracle/rbd_oracle.c): the
+// First things to look at in the output (the [UPSTREAM-RECALL] items of oracle/rbd_oracle.c, docs/HISTORY.md section 6c): the
 // program also writes, per tick, what those four recalled pieces produce upstream so that the packer can compare them with
 // the oracle's versions one by one:
 //   recall_se3_<task>.npy      the SE(3) task's position error (errorInSE3: translation + log3 of M^-1 M_ref) and its constraint b
