@@ -12,6 +12,7 @@
 #include "../../include/wbcqp.h"
 
 #include <dlfcn.h>
+#include <limits>
 
 #include <algorithm>
 #include <cmath>
@@ -39,6 +40,8 @@ struct Slot {
     int spec = 0;               // 1-based index of the compact kernel's instantiation for this very layout (kSpecDims), 0: the generic kernel
     std::vector<int> sel_col_h;       // host copies of what wbcqp_set_model needs of the structure: the posture task's columns
     std::vector<double> force_gen_h;  // and the contacts' force generators (the contact points sit in their skew blocks)
+    double* ffc_dev = nullptr;  // the force blocks' factor for one weight (DevStruct::ffc; owned through `allocs`), null: none (no contacts, not compact, disabled)
+    bool ffc_built = false;     // ... made from the first QP of the slot's first compact launch (solve_ragged)
     bool has_model = false;     // wbcqp_set_model: tree + task bindings for wbcqp_problem_data
     TermsDev terms{};
     std::vector<void*> model_allocs;
@@ -113,6 +116,7 @@ struct wbcqp_handle {
     int queue_lds[2 + kNumSpecs], queue_occ[2 + kNumSpecs] = {}; // occupancy of solve_queue_kernel<., CP, SPEC> at queue_lds bytes of LDS
     int queue_occ_warm[2 + kNumSpecs] = {};                      // ... of solve_queue_kernel_warm<., SPEC> (WBCQP_FLAG_WARM_START launches that kernel)
     bool debug_launch = false;                                   // env WBCQP_DEBUG_LAUNCH, read once at wbcqp_create (never on the per-tick path)
+    bool no_ffcache = false;                                     // env WBCQP_DEBUG_NO_FFCACHE: every QP eliminates its force blocks itself (what tests compare the cache with)
     int queue_occ3[2 + kNumSpecs] = {};                          // ... of solve_queue3_kernel<., SPEC> where queue_three says it holds three
     bool warned_occupancy = false;                               // the one-time note of launch() when the runtime's occupancy answer is overruled
     bool queue_three[2 + kNumSpecs] = {};                        // ... and whether solve_queue3_kernel<., SPEC> holds three workgroups per CU at that size
@@ -710,6 +714,7 @@ int wbcqp_create(const wbcqp_desc* desc, wbcqp_handle** out)
     for (int& q : h->queue_lds) q = -1;
     if (const char* pad = std::getenv("WBCQP_DEBUG_LDS_PAD")) h->lds_pad = std::atoi(pad);
     h->debug_launch = std::getenv("WBCQP_DEBUG_LAUNCH") != nullptr;
+    h->no_ffcache = std::getenv("WBCQP_DEBUG_NO_FFCACHE") != nullptr;
     *out = h;
     return WBCQP_OK;
 }
@@ -755,9 +760,12 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     std::string why;
     int rc = derive(st, D, HB, L, why);
     if (rc != WBCQP_OK) return fail(h, rc, why);
+    D.ffc = nullptr;
     HIP_TRY(h, hipSetDevice(h->device));
     Slot& s = h->slots[slot];
     release(s);
+    s.ffc_dev = nullptr;
+    s.ffc_built = false;
     const int nc = D.nc;
     // F'F and F' of the force-regularisation block, F = diag(w_f) T  (6 x 12)
     std::vector<double> ftf((size_t)nc * 144 + 1, 0.0), ft((size_t)nc * 72 + 1, 0.0);
@@ -832,6 +840,15 @@ int wbcqp_set_structure(wbcqp_handle* h, int slot, const wbcqp_structure* st)
     if (!(h->flags & WBCQP_FLAG_FULL_LDS) && derive_compact(D, s.host_cp)) {
         s.lds_cp = s.host_cp.lds_doubles * 8;
         set_lds(L, s.lds_cp, true, s.host_cp.act_bounds != 0);
+        if (nc > 0 && !h->no_ffcache) { // room for the force blocks' factor (DevStruct::ffc), invalid (weight NaN) until the slot's first launch makes it
+            std::vector<double> init((size_t)nc * kFfcStride, 0.0);
+            for (int c = 0; c < nc; ++c) init[(size_t)c * kFfcStride] = std::numeric_limits<double>::quiet_NaN();
+            const double* dev = nullptr;
+            rc = upload(h, s, init.data(), init.size(), &dev);
+            if (rc != WBCQP_OK) { release(s); return rc; }
+            s.ffc_dev = const_cast<double*>(dev);
+            s.host_cp.ffc = dev;
+        }
     }
     s.small = small_ok(D, HB);
     L.wave_per_qp = s.small ? 1 : 0;
@@ -862,10 +879,19 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
     }
     for (int g = 0; g < n_groups; ++g) {
         const wbcqp_group& G = groups[g];
-        const Slot& s = h->slots[G.slot];
+        Slot& s = h->slots[G.slot];
         int rc = check_io(h, s, G.batch, &G.in, &G.out);
         if (rc != WBCQP_OK) return rc;
         if (G.batch == 0) continue;
+        if (compact && s.ffc_dev && !s.ffc_built && !h->capturing && !(wave_per_qp && s.small)) {
+            // the slot's first compact launch: the force blocks' factor for the weights of its first QP, by the kernels' own code, ahead of the solve on its
+            // stream; waited for once, so that a launch on another stream never meets a half-written entry
+            if (h->dtype == WBCQP_F64) hipLaunchKernelGGL(ffcache_kernel<double>, dim3(1), dim3(128), 0, static_cast<hipStream_t>(stream), s.host_cp, static_cast<const double*>(G.in.w), s.ffc_dev);
+            else hipLaunchKernelGGL(ffcache_kernel<float>, dim3(1), dim3(128), 0, static_cast<hipStream_t>(stream), s.host_cp, static_cast<const float*>(G.in.w), s.ffc_dev);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+            s.ffc_built = true;
+        }
         if (wave_per_qp && s.small) { // one wavefront per QP: a launch of their own (wbcqp_small.hpp)
             if (h->dtype == WBCQP_F64) fill_group(s64.g[used_small], s, false, G.batch, &G.in, &G.out);
             else fill_group(s32.g[used_small], s, false, G.batch, &G.in, &G.out);

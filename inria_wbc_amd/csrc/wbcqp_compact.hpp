@@ -296,6 +296,56 @@ template <int SPEC> __device__ __forceinline__ Dims dims_of(const DevStruct& S)
     else return dims_from(S);
 }
 
+// One contact's force block on one wave (8 x 8 lane grid, 2 x 2 positions per lane): H_ff = wt F'F + reg I eliminated to (1 / sqrt(pivot), Y) with
+// J_ff = Y diag(1 / sqrt(pivot)).  hF enters as the lane's tile of F'F; tF returns the lane's (at most two) diagonal elements of H_ff, in the order the
+// kernel adds them to tr(H).  The solve kernels and ffcache_kernel (which makes DevStruct::ffc) both run THIS function: a cached factor is the computed
+// one bit for bit.
+__device__ __forceinline__ void force_block_factor(Ctx& c, double (&hF)[2][2], double (&yF)[2][2], double (&tF)[2], double wt, double reg, int la, int le,
+                                                   double* RBf, double* YBf, double* dinv_out, int lane)
+{
+    tF[0] = 0.0;
+    tF[1] = 0.0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int r = la + 8 * u, q = le + 8 * w;
+            if (r < 12 && q < 12) {
+                hF[u][w] = wt * hF[u][w] + ((r == q) ? reg : 0.0);
+                if (r == q) tF[u] = hF[u][w]; // (r == q needs u == w: la, le < 8)
+            }
+            else hF[u][w] = (r == q) ? 1.0 : 0.0;
+            yF[u][w] = 0.0;
+        }
+    publish_panel<3, 2, true, 0>(c, hF, yF, la, le, 0, RBf, YBf);
+    eliminate_block<3, 2, true, 0>(c, hF, yF, la, le, 12, RBf, YBf, dinv_out, lane < 4, lane & 3);
+}
+
+// makes DevStruct::ffc from the force-regularisation weights of ONE QP (wbcqp_api.hip launches it once per slot, ahead of the slot's first solve, on that
+// launch's stream): one wave per contact, the solve kernels' own code
+template <typename TI>
+__global__ __launch_bounds__(128) void ffcache_kernel(const DevStruct S, const TI* w, double* out)
+{
+    __shared__ __align__(16) double scr[2 * 128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= S.nc) return;
+    const int la = lane >> 3, le = lane & 7;
+    double hF[2][2], yF[2][2], tF[2];
+    const double* ftf = S.ftf + wave * 144;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ww = 0; ww < 2; ++ww) hF[u][ww] = ftf[min(la + 8 * u, 11) * 12 + min(le + 8 * ww, 11)];
+    const double wt = (double)w[S.forcereg_task[wave]];
+    Ctx c;
+    double* o = out + wave * kFfcStride;
+    force_block_factor(c, hF, yF, tF, wt, S.hessian_reg, la, le, scr + wave * 128, scr + wave * 128 + 64, o + 2, lane);
+    double* ol = o + 16 + 6 * lane;
+    ol[0] = yF[0][0]; ol[1] = yF[0][1]; ol[2] = yF[1][0]; ol[3] = yF[1][1]; ol[4] = tF[0]; ol[5] = tF[1];
+    __builtin_amdgcn_s_waitcnt(0); // (every store of the entry before the weight that validates it; readers are later launches in stream order anyway)
+    if (lane == 0) o[0] = wt;
+}
+
 // SPEC > 0: the instantiation for the shipped stack kSpecDims[SPEC - 1] -- every size and LDS offset below is a literal
 template <typename TI, int SPEC = 0, bool WARM = false>
 __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const DevStruct& S, const int b, double* lds, const int tid, const int brec = -1)
@@ -595,28 +645,34 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         eliminate_block<4, NU, false, 0>(c, h, y, ta, te, opaque_uniform((nv + 3) & ~3) /* not a constant for the unroller (a specialised build would lay out thirteen panel bodies: 256 VGPRs + 256 AGPRs + scratch) */, RB, YB, c.dinv, tid >= 128 && tid < 132, tid & 3);
         STAMP(2)
         bsync(); // staged rows and panels are dead: the region becomes J
-        for (int e = tid; e < n * ldj + 2; e += kThreads) c.J[e] = 0.0; // (+ 2: the last row's pad pair when the rows are exactly n long, derive_compact)
-        // ---- force blocks: wave-local (8 x 8 lane grid, 2 x 2 positions per lane), one contact per wave (nc <= 2), panels
-        //      in the (idle) s slot
+        // ---- force blocks: wave-local (8 x 8 lane grid, 2 x 2 positions per lane), one contact per wave (nc <= 2), panels in the (idle) s slot.
+        //      The factor depends on the record through ONE number, the contact's force-regularisation weight: a QP that carries the weight DevStruct::ffc
+        //      was made for takes the factor from there (its loads fly while J is zeroed) instead of eliminating the block again
         const int fb = nv + 12 * c.wave;
+        double wtF = 0.0, cw = 0.0, cy[6], cd = 0.0;
+        const bool probe = c.wave < nc && S.ffc != nullptr;
+        if (c.wave < nc) wtF = c.w[S.forcereg_task[c.wave]];
+        if (probe) {
+            const double* fc = S.ffc + c.wave * kFfcStride;
+            cw = fc[0];
+            cd = fc[2 + min(c.lane, 11)];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) cy[u] = fc[16 + 6 * c.lane + u];
+        }
+        for (int e = tid; e < n * ldj + 2; e += kThreads) c.J[e] = 0.0; // (+ 2: the last row's pad pair when the rows are exactly n long, derive_compact)
         if (c.wave < nc) {
-            const double wt = c.w[S.forcereg_task[c.wave]];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    const int r = la + 8 * u, q = le + 8 * w;
-                    if (r < 12 && q < 12) {
-                        hF[u][w] = wt * hF[u][w] + ((r == q) ? S.hessian_reg : 0.0);
-                        if (r == q) trace += hF[u][w];
-                    }
-                    else hF[u][w] = (r == q) ? 1.0 : 0.0;
-                    yF[u][w] = 0.0;
-                }
-            double* RBf = c.s + c.wave * 128;
-            double* YBf = RBf + 64;
-            publish_panel<3, 2, true, 0>(c, hF, yF, la, le, 0, RBf, YBf);
-            eliminate_block<3, 2, true, 0>(c, hF, yF, la, le, 12, RBf, YBf, c.dinv + fb, c.lane < 4, c.lane & 3);
+            if (probe && wtF == cw) { // (wave-uniform: one weight per contact; NaN -- no entry yet -- equals nothing)
+                yF[0][0] = cy[0]; yF[0][1] = cy[1]; yF[1][0] = cy[2]; yF[1][1] = cy[3];
+                trace += cy[4];
+                trace += cy[5];
+                if (c.lane < 12) c.dinv[fb + c.lane] = cd;
+            }
+            else {
+                double tF[2];
+                force_block_factor(c, hF, yF, tF, wtF, S.hessian_reg, la, le, c.s + c.wave * 128, c.s + c.wave * 128 + 64, c.dinv + fb, c.lane);
+                trace += tF[0];
+                trace += tF[1];
+            }
         }
         bsync(); // J is zero, every 1/sqrt(pivot) is published
         // tr(H) and sum 1/sqrt(pivot) (the stopping rule's c1, c2): the waves' partial sums ride on the barrier that ends the J writes below

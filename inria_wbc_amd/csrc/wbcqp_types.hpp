@@ -74,7 +74,15 @@ struct DevStruct {
     int n_acteq, acteq_task, cop_task;
     const int* acteq_joint;  // [n_acteq]
     const double* acteq_scale;
+    // the force blocks' factor for ONE weight (compact kernels; null: none).  H_ff = w F'F + reg I depends on the record only through the level-1 weight w
+    // of the contact's force-regularisation task (tasks.hpp:23 w_force_feet: a constant in every shipped stack), so its 12 x 12 elimination -- 2.9 k cycles of
+    // a QP's set-up, on one wave, while two waves idle -- is the same for every QP that carries that weight.  Layout per contact (kFfcStride doubles):
+    // [0] the weight the entry was made for (NaN: none yet), [2 .. 14) 1 / sqrt(pivot), [16 + 6 lane ..): the lane's y tile (4) and its two additions to tr(H).
+    // Made on the device by the kernels' own elimination code (ffcache_kernel: the same instructions, the same bits) from the weights of the first QP of the
+    // slot's first launch; a QP with another weight computes as before.
+    const double* ffc;
 };
+constexpr int kFfcStride = 16 + 6 * 64;
 
 // The integer sizes and LDS offsets of a structure on the compact layout as the kernel sees them.  The compact kernels exist once for ANY
 // structure (these read from the DevStruct at run time) and once per SHIPPED stack with all of them as literals: every address then folds
