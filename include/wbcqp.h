@@ -29,7 +29,8 @@
  * nothing in the steady state (upstream's solver runs under EIGEN_MALLOC_NOT_ALLOWED); the FIRST launch
  * on a stream of a larger batch than any before it on that stream (launch-order buffer, 8 bytes per QP,
  * with one synchronisation of that stream) and the first launch on a new stream (an 8-byte queue counter)
- * do allocate.  A captured tick (wbcqp_tick_graph_create) owns its buffers and never does.
+ * do allocate.  A captured tick (wbcqp_tick_graph_create) owns its buffers and never does.  The first solve of a slot after
+ * wbcqp_set_structure also synchronises its stream once (the force blocks' factor cache, interface history 151).
  */
 #ifndef WBCQP_H
 #define WBCQP_H
@@ -43,13 +44,17 @@ extern "C" {
 
 /* Interface history (WBCQP_VERSION = 100 major + 10 minor + patch; round 5 changed no declaration of this header -- wbcqp_layout.waves_per_cu may now be 3,
  * and wbcqp_structure.max_iter no longer decides whether a shipped stack runs its own instantiation):
+ *   151  no declaration changed.  wbcqp_tick_host fills wbcqp_outputs.active_mask when given; the numbering of active_mask's bits is documented (below);
+ *        a slot's FIRST solve on the compact layout makes the force blocks' factor for the force-regularisation weights of its first QP (one small kernel
+ *        and one synchronisation of the launch's stream, once per wbcqp_set_structure; never inside a stream capture) -- later QPs that carry those weights
+ *        take the factor from there, others compute it as before: the same bits either way (env WBCQP_DEBUG_NO_FFCACHE=1, read at wbcqp_create, turns it off)
  *   150  launch-order state per (handle, stream), active_mask written by every kernel, torque / cop task rows
  *        (wbcqp_structure.n_acteq, cop_*), posture mask
  *   140  wbcqp_rollout, wbcqp_outputs.active_mask (WBCQP_FLAG_WARM_START), wbcqp_state.momentum, wbcqp_layout.wave_per_qp
  *        (WBCQP_FLAG_WORKGROUP_PER_QP)
  *   130  wbcqp_integrate, wbcqp_set_model / wbcqp_problem_data / wbcqp_tick and companions
  *   121  queue + packed launch order, wbcqp_launch_order */
-#define WBCQP_VERSION 150
+#define WBCQP_VERSION 151
 #define WBCQP_MAX_STRUCTURES 16
 #define WBCQP_MAX_INEQ_BLOCKS 16
 #define WBCQP_MAX_VARS 126 /* n = nv + 12*nc: every per-QP vector fits one 128-entry LDS slot, n + 2 <= 128 */

@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     nm = subprocess.run(["nm", "-D", "--defined-only", built_lib], capture_output=True, text=True).stdout
     exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln and ln.split()[-1].startswith("wbcqp_")}
     assert exported == declared, exported ^ declared
-    assert lib.wbcqp_version() == 150
+    assert lib.wbcqp_version() == 151
 
 
 def test_layout_without_gpu(built_lib):
