@@ -883,7 +883,13 @@ int wbcqp_solve_ragged(wbcqp_handle* h, int n_groups, const wbcqp_group* groups,
         int rc = check_io(h, s, G.batch, &G.in, &G.out);
         if (rc != WBCQP_OK) return rc;
         if (G.batch == 0) continue;
-        if (compact && s.ffc_dev && !s.ffc_built && !h->capturing && !(wave_per_qp && s.small)) {
+        bool user_capture = false; // (a caller capturing this very call into a graph of its own: no synchronisation there -- the cache waits for a plain launch)
+        if (compact && s.ffc_dev && !s.ffc_built && !h->capturing) {
+            hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cst) != hipSuccess) (void)hipGetLastError();
+            user_capture = cst != hipStreamCaptureStatusNone;
+        }
+        if (compact && s.ffc_dev && !s.ffc_built && !h->capturing && !user_capture && !(wave_per_qp && s.small)) {
             // the slot's first compact launch: the force blocks' factor for the weights of its first QP, by the kernels' own code, ahead of the solve on its
             // stream; waited for once, so that a launch on another stream never meets a half-written entry
             if (h->dtype == WBCQP_F64) hipLaunchKernelGGL(ffcache_kernel<double>, dim3(1), dim3(128), 0, static_cast<hipStream_t>(stream), s.host_cp, static_cast<const double*>(G.in.w), s.ffc_dev);
