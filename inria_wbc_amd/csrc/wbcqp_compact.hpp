@@ -770,6 +770,39 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         }
     }
 
+    // The actuation rows' global loads (rows nu .. nv - 1 of M, the contact Jacobians' columns: from the record, L2 or HBM by now) are ISSUED as soon as the
+    // equality QR has released its registers and CONSUMED behind the phases that follow it (y, x, u): their latency -- most of the 3.1 k cycles the phase
+    // "actuation rows -> registers" took -- runs under those phases' barriers.
+    TI act_mv[cp::NVQ];
+    TI act_av[2][6];
+    double act_tv[cp::KQ][6]; // the force generators' coefficients of the lane's columns (a constant table of the structure: L2)
+    bool act_issued = false;
+    auto issue_act_loads = [&]() __attribute__((always_inline)) {
+        if (na > 0) {
+            const int rr = min(tid >> 2, na - 1), q4 = tid & 3;
+            const int row = nu + rr;
+#pragma unroll
+            for (int u = 0; u < cp::NVQ; ++u) {
+                const int j = min(q4 + 4 * u, nv - 1);
+                const int hi = max(row, j), lo = min(row, j);
+                act_mv[u] = pM[hi * (hi + 1) / 2 + lo];
+            }
+            if (nc > 0) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) act_av[ct][r] = pAc[(min(ct, nc - 1) * 6 + r) * nv + row];
+#pragma unroll
+                for (int u = 0; u < cp::KQ; ++u) {
+                    const int mcol = min(q4 + 4 * u, k - 1);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) act_tv[u][r] = S.force_gen[(u / 3) * 72 * ((nc > 1) ? 1 : 0) + r * 12 + (mcol - 12 * (u / 3) * ((nc > 1) ? 1 : 0))];
+                }
+            }
+        }
+        act_issued = true;
+    };
+
     // ---------------- phase 3: equality constraints, blocked (equality_phase_blocked with N already in place) ----------------
     if (neq > 0) {
         const int m = neq;
@@ -818,6 +851,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         bool ok = qr_unified<NTQ>(c, Nm, c.s, c.s + 160);
         if (!ok) status = HQP_ERROR; // redundant equalities
         else {
+            if (D.act_bounds) issue_act_loads();
             bsync();
             STAMP(6)
             if (c.wave == 0) {
@@ -850,29 +884,11 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     ActRegs ar;
     auto load_act_rows = [&]() __attribute__((always_inline)) {
     if (na > 0) {
-        const int rr = min(tid >> 2, na - 1), q4 = tid & 3;
-        const int row = nu + rr;
-        TI mv[cp::NVQ];
-#pragma unroll
-        for (int u = 0; u < cp::NVQ; ++u) {
-            const int j = min(q4 + 4 * u, nv - 1);
-            const int hi = max(row, j), lo = min(row, j);
-            mv[u] = pM[hi * (hi + 1) / 2 + lo];
-        }
-        TI av[2][6];
-        double tv[cp::KQ][6];
-        if (nc > 0) {
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 6; ++r) av[ct][r] = pAc[(min(ct, nc - 1) * 6 + r) * nv + row];
-#pragma unroll
-            for (int u = 0; u < cp::KQ; ++u) {
-                const int mcol = min(q4 + 4 * u, k - 1);
-#pragma unroll
-                for (int r = 0; r < 6; ++r) tv[u][r] = S.force_gen[(u / 3) * 72 * ((nc > 1) ? 1 : 0) + r * 12 + (mcol - 12 * (u / 3) * ((nc > 1) ? 1 : 0))];
-            }
-        }
+        if (!act_issued) issue_act_loads();
+        const int q4 = tid & 3;
+        TI (&mv)[cp::NVQ] = act_mv;
+        TI (&av)[2][6] = act_av;
+        double (&tv)[cp::KQ][6] = act_tv;
 #pragma unroll
         for (int u = 0; u < cp::NVQ; ++u) ar.am[u] = (q4 + 4 * u < nv) ? (double)mv[u] : 0.0;
 #pragma unroll
