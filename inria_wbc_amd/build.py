@@ -135,6 +135,29 @@ def check_barriers(path: str):
     return total, bad
 
 
+def check_resources(usage: dict) -> None:
+    """The refusals of build(), on {kernel: {field: int}} as _resource_usage returns it.  An EMPTY or solve-kernel-free table is itself refused: for a
+    whole round the remarks' spelling under -save-temps was not the one the parser knew, the table came back empty and every check below passed
+    vacuously (a generic kernel with 96 AGPRs and one workgroup per CU shipped into a measurement pass: profiles/r06/not_kept.txt item 9)."""
+    solve = [n for n in usage if "solve_queue_kernel" in n]
+    if len(solve) < 8 or any("VGPRs" not in usage[n] or "Occupancy [waves/SIMD]" not in usage[n] for n in solve):
+        raise RuntimeError("kernel-resource remarks not understood: %d solve_queue_kernel entries among %d kernels -- the build's register checks would "
+                           "pass vacuously; refuse to ship" % (len(solve), len(usage)))
+    for name, u in usage.items():
+        if ("solve_kernel" in name or "solve_queue_kernel" in name or "terms_kernel" in name or "integrate_kernel" in name) and (u.get("AGPRs", 0) != 0 or u.get("ScratchSize [bytes/lane]", 0) != 0 or u.get("VGPRs Spill", 0) != 0):
+            raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, VGPR spills %s -- refuse to ship (see the comment in build.py)" %
+                               (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("VGPRs Spill")))
+        # two workgroups per CU is what the queue kernels are sized and measured for (four waves each, one per SIMD: two waves per SIMD)
+        if "solve_queue_kernel" in name and u.get("Occupancy [waves/SIMD]", 0) < 2:
+            raise RuntimeError("%s: %s VGPRs, occupancy %s waves per SIMD -- refuse to ship" % (name, u.get("VGPRs"), u.get("Occupancy [waves/SIMD]")))
+        # the three-per-CU twin of the compact queue kernel is the one place scratch is admitted: it is compiled for 168 VGPRs and measured
+        # faster WITH its spills than the two-per-CU kernel without (tools/occ3_probe.py).  It must really reach three waves per SIMD, keep
+        # AGPRs out (the bug above) and its spills bounded.
+        if "solve_queue3_kernel" in name and (u.get("AGPRs", 0) != 0 or u.get("Occupancy [waves/SIMD]", 0) < 3 or u.get("ScratchSize [bytes/lane]", 0) > 320):
+            raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, occupancy %s -- refuse to ship" %
+                               (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("Occupancy [waves/SIMD]")))
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     if not force and not needs_build():
         return LIB
@@ -158,20 +181,11 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         if proc.returncode != 0:
             sys.stderr.write(proc.stdout)
             raise subprocess.CalledProcessError(proc.returncode, cmd)
+        check_resources(usage)
         for line in proc.stdout.splitlines():
             if "remark:" not in line and "kernel-resource-usage" not in line and line.strip() and not line.lstrip().startswith(("|", "^")) \
                     and not line.strip()[:5].strip().isdigit():
                 print(line, file=sys.stderr)
-        for name, u in usage.items():
-            if ("solve_kernel" in name or "solve_queue_kernel" in name or "terms_kernel" in name or "integrate_kernel" in name) and (u.get("AGPRs", 0) != 0 or u.get("ScratchSize [bytes/lane]", 0) != 0 or u.get("VGPRs Spill", 0) != 0):
-                raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, VGPR spills %s -- refuse to ship (see the comment in build.py)" %
-                                   (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("VGPRs Spill")))
-            # the three-per-CU twin of the compact queue kernel is the one place scratch is admitted: it is compiled for 168 VGPRs and measured
-            # faster WITH its spills than the two-per-CU kernel without (tools/occ3_probe.py).  It must really reach three waves per SIMD, keep
-            # AGPRs out (the bug above) and its spills bounded.
-            if "solve_queue3_kernel" in name and (u.get("AGPRs", 0) != 0 or u.get("Occupancy [waves/SIMD]", 0) < 3 or u.get("ScratchSize [bytes/lane]", 0) > 320):
-                raise RuntimeError("%s: AGPRs %s, scratch %s B/lane, occupancy %s -- refuse to ship" %
-                                   (name, u.get("AGPRs"), u.get("ScratchSize [bytes/lane]"), u.get("Occupancy [waves/SIMD]")))
         # The device assembly is part of the build too: every workgroup barrier must wait for the wave's own LDS traffic first
         # (tools/check_barriers.py says why; bsync() in wbcqp_prims.hpp issues the wait).
         asm = [f for f in os.listdir(tmpdir) if f.endswith("gfx950.s")]
@@ -221,7 +235,10 @@ def _resource_usage(text: str) -> dict:
     for line in text.splitlines():
         if "remark:" not in line:
             continue
-        body = line.split("remark:", 1)[1].split("[-Rpass", 1)[0].strip()
+        # two spellings: "<file>:<line>:<col>: remark: Function Name: ..." (one-step compile) and "remark: <file>:<line>:<col>: Function Name: ..." (the
+        # device compile run from a saved temporary, -save-temps, which is how build() compiles) -- take what follows the LAST "<digits>: " or "remark: "
+        body = line.split("[-Rpass", 1)[0]
+        body = re.split(r"(?:remark:|:\d+:\d+:)\s*", body)[-1].strip()
         if body.startswith("Function Name:"):
             cur = body.split(":", 1)[1].strip()
             out[cur] = {}

@@ -777,7 +777,7 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     TI act_av[2][6];
     double act_tv[cp::KQ][6]; // the force generators' coefficients of the lane's columns (a constant table of the structure: L2)
     bool act_issued = false;
-    auto issue_act_loads = [&]() __attribute__((always_inline)) {
+    auto issue_act_loads_into = [&](TI (&act_mv)[cp::NVQ], TI (&act_av)[2][6], double (&act_tv)[cp::KQ][6]) __attribute__((always_inline)) {
         if (na > 0) {
             const int rr = min(tid >> 2, na - 1), q4 = tid & 3;
             const int row = nu + rr;
@@ -800,6 +800,9 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
                 }
             }
         }
+    };
+    auto issue_act_loads = [&]() __attribute__((always_inline)) {
+        issue_act_loads_into(act_mv, act_av, act_tv);
         act_issued = true;
     };
 
@@ -851,7 +854,11 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
         bool ok = qr_unified<NTQ>(c, Nm, c.s, c.s + 160);
         if (!ok) status = HQP_ERROR; // redundant equalities
         else {
-            if (D.act_bounds) issue_act_loads();
+            // (the specialised kernels only: in the generic one, whose dimensions are run-time values, the loaded values' longer life pushed the allocator
+            // past 256 VGPRs -- AGPR copies, one workgroup per CU; tools/kernel_regs.py, profiles/r06/not_kept.txt item 9)
+            if constexpr (SPEC != 0) {
+                if (D.act_bounds) issue_act_loads();
+            }
             bsync();
             STAMP(6)
             if (c.wave == 0) {
@@ -884,21 +891,30 @@ __device__ __forceinline__ void solve_one_compact(const GroupArgs<TI>& ga, const
     ActRegs ar;
     auto load_act_rows = [&]() __attribute__((always_inline)) {
     if (na > 0) {
-        if (!act_issued) issue_act_loads();
         const int q4 = tid & 3;
-        TI (&mv)[cp::NVQ] = act_mv;
-        TI (&av)[2][6] = act_av;
-        double (&tv)[cp::KQ][6] = act_tv;
+        auto consume = [&](TI (&mv)[cp::NVQ], TI (&av)[2][6], double (&tv)[cp::KQ][6]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < cp::NVQ; ++u) ar.am[u] = (q4 + 4 * u < nv) ? (double)mv[u] : 0.0;
+            for (int u = 0; u < cp::NVQ; ++u) ar.am[u] = (q4 + 4 * u < nv) ? (double)mv[u] : 0.0;
 #pragma unroll
-        for (int u = 0; u < cp::KQ; ++u) {
-            double sacc = 0.0;
-            if (nc > 0) {
+            for (int u = 0; u < cp::KQ; ++u) {
+                double sacc = 0.0;
+                if (nc > 0) {
 #pragma unroll
-                for (int r = 0; r < 6; ++r) sacc = fma(tv[u][r], (double)av[u / 3][r], sacc);
+                    for (int r = 0; r < 6; ++r) sacc = fma(tv[u][r], (double)av[u / 3][r], sacc);
+                }
+                ar.aj[u] = (q4 + 4 * u < k) ? sacc : 0.0;
             }
-            ar.aj[u] = (q4 + 4 * u < k) ? sacc : 0.0;
+        };
+        if constexpr (SPEC == 0) { // (the generic kernel: loads and use in one place, the values live nowhere else -- see the early issue behind the QR)
+            TI mv[cp::NVQ];
+            TI av[2][6];
+            double tv[cp::KQ][6];
+            issue_act_loads_into(mv, av, tv);
+            consume(mv, av, tv);
+        }
+        else {
+            if (!act_issued) issue_act_loads();
+            consume(act_mv, act_av, act_tv);
         }
     }
     else {

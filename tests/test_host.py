@@ -215,6 +215,63 @@ _ZN5wbcqp1kEv:                          ; @_ZN5wbcqp1kEv
     assert total == 3 and [ln for _, ln in flagged] == [5, 9, 11] and flagged[0][0] == "_ZN5wbcqp1kEv"
 
 
+def _remarks(spelling, kernels):
+    """clang's -Rpass-analysis=kernel-resource-usage output in either of the two spellings ROCm 7.2 emits (one-step compile / the device
+    compile run from a saved temporary, which is what build() does)."""
+    out = []
+    for name, fields in kernels:
+        for k, v in [("Function Name", name)] + list(fields.items()):
+            body = "%s: %s" % (k, v) if k == "Function Name" else "    %s: %s" % (k, v)
+            if spelling == "one-step":
+                out += ["/x/wbcqp_device.hpp:1014:1: remark: %s [-Rpass-analysis=kernel-resource-usage]" % body, " 1014 | {", "      | ^"]
+            else:
+                out.append("remark: /x/wbcqp_device.hpp:1014:0: %s [-Rpass-analysis=kernel-resource-usage]" % body)
+    return "\n".join(out)
+
+
+@pytest.mark.parametrize("spelling", ["one-step", "save-temps"])
+def test_the_build_reads_the_register_remarks_in_both_spellings_and_refuses_an_empty_table(spelling):
+    """Round 6: under -save-temps the remarks come as `remark: file:line:col: Function Name: ...`; the parser only knew `file:line:col: remark:
+    Function Name: ...`, returned an empty table and every register check passed vacuously -- a generic kernel with 96 AGPRs at one workgroup
+    per CU went into a measurement pass.  Both spellings are parsed now and a table without the solve kernels is itself a refusal."""
+    from inria_wbc_amd.build import _resource_usage, check_resources
+    ok = {"TotalSGPRs": 106, "VGPRs": 238, "AGPRs": 0, "ScratchSize [bytes/lane]": 0, "Occupancy [waves/SIMD]": 2, "VGPRs Spill": 0, "LDS Size [bytes/block]": 16}
+    names = ["_ZN5wbcqp18solve_queue_kernelIdLb1ELi%dEEEvNS_10GroupTableIT_EEPii" % i for i in range(8)]
+    good = [(n, ok) for n in names] + [("_ZN5wbcqp19solve_queue3_kernelIdLi2EEEvNS_10GroupTableIT_EEPii", dict(ok, VGPRs=168, **{"ScratchSize [bytes/lane]": 72, "Occupancy [waves/SIMD]": 3}))]
+    u = _resource_usage(_remarks(spelling, good))
+    assert len(u) == 9 and u[names[0]]["VGPRs"] == 238 and u[names[0]]["Occupancy [waves/SIMD]"] == 2
+    check_resources(u)
+    for bad, what in ((dict(ok, VGPRs=256, AGPRs=96, **{"Occupancy [waves/SIMD]": 1}), "AGPRs 96"), (dict(ok, **{"ScratchSize [bytes/lane]": 8}), "scratch 8"),
+                      (dict(ok, VGPRs=300, **{"Occupancy [waves/SIMD]": 1}), "occupancy 1")):
+        with pytest.raises(RuntimeError, match=what):
+            check_resources(_resource_usage(_remarks(spelling, good[:3] + [(names[3], bad)] + good[4:])))
+    with pytest.raises(RuntimeError, match="occupancy 2"):  # the three-per-CU twin that does not reach three
+        check_resources(_resource_usage(_remarks(spelling, good[:8] + [(good[8][0], dict(good[8][1], **{"Occupancy [waves/SIMD]": 2}))])))
+    with pytest.raises(RuntimeError, match="not understood"):
+        check_resources({})
+    with pytest.raises(RuntimeError, match="not understood"):
+        check_resources(_resource_usage(_remarks(spelling, good).replace("Function Name", "Kernel Name")))
+
+
+def test_the_library_on_disk_holds_no_agprs_and_no_scratch_in_its_solve_kernels(built_lib):
+    """What the build refuses, read back from the code object of the library the tests and the bench load (tools/kernel_regs.py): a library put in
+    place by another route -- a variant from tools/variants.sh copied over -- does not pass through build()'s checks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_regs", os.path.join(os.path.dirname(__file__), "..", "tools", "kernel_regs.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not os.path.exists(kr.LLVM + "/llvm-readelf"):
+        pytest.skip("no llvm-readelf")
+    rows = kr.kernels(built_lib)
+    queue = [r for r in rows if "solve_queue_kernel" in r[4]]
+    assert len(queue) >= 14
+    for v, a, scratch, _, name in rows:
+        if "solve_queue_kernel" in name or "solve_kernel" in name:
+            assert (a, scratch) == (0, 0) and v <= 256, (name, v, a, scratch)  # two workgroups per CU: 512 / 256
+        if "solve_queue3_kernel" in name:
+            assert a == 0 and v <= 168 and scratch <= 320, (name, v, a, scratch)  # three: 512 / 168
+
+
 def test_every_workgroup_barrier_in_the_sources_is_bsync():
     """Source-level half of the barrier rule (the build checks the assembly): __syncthreads() appears once, inside bsync(), which issues the
     LDS wait the compiler may drop (csrc/wbcqp_prims.hpp)."""
