@@ -40,7 +40,14 @@ def main():
     for f in keep:
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
-    kern = "solve_queue_kernel"
+    # the dominant kernel is whatever the pass's bench line names (round 6: B = 1024 goes to the dispatcher, solve_kernel; before: the queue kernel)
+    kernel_full = "wbcqp::solve_queue_kernel<double, true, 1>"
+    try:
+        with open(os.path.join(src, "bench.json")) as fh:
+            kernel_full = json.loads(fh.read().strip().splitlines()[-1])["roofline"]["kernel"]
+    except Exception:  # noqa: BLE001
+        pass
+    kern = kernel_full.split("::", 1)[1]  # (as rocprofv3 prints it after "wbcqp::"; "solve_kernel<" does not match "solve_queue_kernel<")
     fe = per_dispatch(os.path.join(src, "pmc_fetch_size.csv"), kern)
     wr = per_dispatch(os.path.join(src, "pmc_write_size.csv"), kern)
     sq = per_dispatch(os.path.join(src, "pmc_sq.csv"), kern)
@@ -48,7 +55,7 @@ def main():
     w_kb, nw = mean(wr, "WRITE_SIZE")
     waves, _ = mean(sq, "SQ_WAVES")
     cyc, _ = mean(sq, "SQ_WAVE_CYCLES")
-    out = {"round": int(rnd.lstrip("r")), "kernel": "wbcqp::solve_queue_kernel<double, true, 1>", "workload": "talos_pos_tracker_b1024_fp64_squat_tick_stream",
+    out = {"round": int(rnd.lstrip("r")), "kernel": kernel_full, "workload": "talos_pos_tracker_b1024_fp64_squat_tick_stream",
            "batch": 1024, "fetch_size_kb": round(f_kb, 2), "write_size_kb": round(w_kb, 2), "launches_fetch_pass": nf, "launches_write_pass": nw,
            "traffic_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0, "traffic_over_algorithmic": (2.0 * f_kb + w_kb) * 1024.0 / (35152.0 * 1024),
            "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, then the SQ counters) over `bench.py --steps 20 --warmup 4 --headline-only` "
@@ -61,7 +68,8 @@ def main():
                            "wait_inst_any": mean(sq, "SQ_WAIT_INST_ANY")[0] / cyc,
                            "valu_per_wave": mean(sq, "SQ_INSTS_VALU")[0] / waves, "salu_per_wave": mean(sq, "SQ_INSTS_SALU")[0] / waves,
                            "lds_per_wave": mean(sq, "SQ_INSTS_LDS")[0] / waves,
-                           "note": "per wave of a launch; a wave slot of the 512 resident workgroups solves 2 QPs of a 1024-QP launch: halve for per-QP figures"}}
+                           "note": "per wave of a launch: 4096 waves = one workgroup (four waves) per QP; 2048 = the queue's 512 resident workgroups, each wave slot solving 2 QPs of "
+                                   "a 1024-QP launch (halve for per-QP figures)"}}
     # ---- what names the limiter (tools/profile_kernels.sh passes; absent files leave the keys out) ----
     kern_ms = None
     try:

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--stamps", action="store_true", help="also run the longest QP alone through the -DWBCQP_STAMPS build and print its phase cycles\n"
                     "(a second process state is not needed: the stamped library is loaded INSTEAD of the product one)")
+    ap.add_argument("--queue", action="store_true", help="the QPs alone through the queue kernel (solve_queue_kernel, one workgroup) instead of solve_kernel")
     ap.add_argument("--lib", default=None, help="a variant library (tools/variants.sh) instead of inria_wbc_amd/lib/libwbcqp.so")
     args = ap.parse_args()
     import torch
@@ -43,7 +44,7 @@ def main():
     d_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inputs.items() if v.size}
     out = dict(x=torch.zeros(B, st.n, dtype=torch.float64, device=dev), tau=torch.zeros(B, st.na, dtype=torch.float64, device=dev),
                status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
-    h = capi.Handle(0, capi.F64, flags=capi.FLAG_INDEX_ORDER | capi.FLAG_HW_DISPATCH)
+    h = capi.Handle(0, capi.F64, flags=capi.FLAG_INDEX_ORDER | (capi.FLAG_QUEUE if args.queue else capi.FLAG_HW_DISPATCH))
     h.set_structure(0, st)
     sp = torch.cuda.current_stream().cuda_stream
     h.solve_batch(0, B, d_in, out, stream=sp)
